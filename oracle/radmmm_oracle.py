@@ -1,0 +1,836 @@
+"""CPU oracle for the RAD-MMM flow-decoder hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a *restatement* (functional, fp32 or fp64, torch-CPU/numpy) of the
+arithmetic the reference performs on the path named by BASELINE.json.  It is the
+checker for the HIP kernels; it is never the thing shipped or measured.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it.  The product package (`rad_mmm_amd`) must never import from here.
+
+Pinning: the reference has no tests or golden vectors of its own, so
+the oracle is pinned against outputs of the reference itself, imported in the
+build container by `tests/golden/make_golden.py`; the resulting fixtures live in
+`tests/golden/*.npz` and `tests/test_oracle_golden.py` replays them.  One piece
+is "parity unpinned": the Slaney mel filterbank (`mel_filterbank_slaney`), which
+the reference takes from librosa 0.8.0 (absent here) -- see DESIGN.md.
+
+All tensors use the reference's layout: activations [B, C, T], conv weights
+[C_out, C_in, k].  Parameters are passed as a flat dict keyed by the reference's
+state_dict names so that `ref_module.state_dict()` can be fed in directly.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# masks / squeeze
+# --------------------------------------------------------------------------
+def lengths_to_mask(lengths: Tensor, max_len: Optional[int] = None) -> Tensor:
+    """bool [B, max_len], True where t < len_b.  common.py:105-116."""
+    if max_len is None:
+        max_len = int(lengths.max())
+    ids = torch.arange(max_len, device=lengths.device)
+    return ids[None, :] < lengths[:, None]
+
+
+def squeeze_time(x: Tensor, g: int) -> Tensor:
+    """[B,C,T] -> [B,C*g,T//g] with out[b,c*g+k,l] = x[b,c,l*g+k].
+
+    Equals nn.Unfold(kernel=(g,1), stride=g) on x[..., None]
+    (decoders.py:118-122,178; models/radmmm.py:114-120).  Trailing T % g frames
+    are dropped.
+    """
+    if g == 1:
+        return x
+    B, C, T = x.shape
+    Tg = T // g
+    return x[:, :, :Tg * g].reshape(B, C, Tg, g).permute(0, 1, 3, 2).reshape(B, C * g, Tg)
+
+
+def unsqueeze_time(x: Tensor, g: int) -> Tensor:
+    """Inverse of squeeze_time (decoders.py:150-160, `fold`)."""
+    if g == 1:
+        return x
+    B, Cg, Tg = x.shape
+    C = Cg // g
+    return x.reshape(B, C, g, Tg).permute(0, 1, 3, 2).reshape(B, C, Tg * g)
+
+
+# --------------------------------------------------------------------------
+# weight norm, partial conv, WN
+# --------------------------------------------------------------------------
+def weight_norm_fold(v: Tensor, g: Tensor) -> Tensor:
+    """w = g * v / ||v||_2, norm over all dims but 0 (torch weight_norm dim=0;
+    common.py:173-174,791,813)."""
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def _wn_weight(p: Params, prefix: str) -> Tensor:
+    if prefix + "weight_v" in p:
+        return weight_norm_fold(p[prefix + "weight_v"], p[prefix + "weight_g"])
+    return p[prefix + "weight"]
+
+
+def partial_conv1d(x: Tensor, mask: Optional[Tensor], w: Tensor, b: Optional[Tensor],
+                   dilation: int) -> Tensor:
+    """Length-mask-aware conv re-normalisation.  partialconv1d.py:58-94.
+
+    mask: float [B,1,T] or None (None -> all-ones window count, which still
+    renormalises the zero-padded borders).
+    """
+    k = w.shape[-1]
+    pad = dilation * (k - 1) // 2
+    B, _, T = x.shape
+    ones_k = torch.ones(1, 1, k, dtype=x.dtype)
+    m = mask if mask is not None else torch.ones(1, 1, T, dtype=x.dtype)
+    cnt = F.conv1d(m, ones_k, padding=pad, dilation=dilation)
+    ratio = k / (cnt + 1e-6)
+    upd = cnt.clamp(0, 1)
+    ratio = ratio * upd
+    raw = F.conv1d(x * mask if mask is not None else x, w, b, padding=pad, dilation=dilation)
+    if b is not None:
+        bv = b.view(1, -1, 1)
+        return ((raw - bv) * ratio + bv) * upd
+    return raw * ratio
+
+
+def conv_norm(p: Params, prefix: str, x: Tensor, mask: Optional[Tensor], dilation: int = 1,
+              partial: bool = True) -> Tensor:
+    """ConvNorm.forward without batch-norm.  common.py:179-191."""
+    w = _wn_weight(p, prefix + "conv.")
+    b = p.get(prefix + "conv.bias")
+    if partial:
+        y = partial_conv1d(x, mask, w, b, dilation)
+    else:
+        k = w.shape[-1]
+        y = F.conv1d(x, w, b, padding=dilation * (k - 1) // 2, dilation=dilation)
+    if mask is not None:
+        y = y * mask
+    return y
+
+
+def wn_forward(p: Params, prefix: str, z0: Tensor, ctx: Tensor, mask: Optional[Tensor],
+               n_layers: int, activation: str = "softplus", partial: bool = True) -> Tensor:
+    """WN.forward.  common.py:816-835 (no gated tanh, no residual path)."""
+    act = F.softplus if activation == "softplus" else torch.relu
+    h = F.conv1d(torch.cat((z0, ctx), 1), _wn_weight(p, prefix + "start."), p[prefix + "start.bias"])
+    out = torch.zeros_like(h)
+    for i in range(n_layers):
+        h = act(conv_norm(p, f"{prefix}in_layers.{i}.", h, mask, 2 ** i, partial))
+        r = act(F.conv1d(h, _wn_weight(p, f"{prefix}res_skip_layers.{i}."),
+                         p[f"{prefix}res_skip_layers.{i}.bias"]))
+        out = out + r
+    return F.conv1d(out, p[prefix + "end.weight"], p[prefix + "end.bias"])
+
+
+def fused_add_tanh_sigmoid_multiply(a: Tensor, b: Tensor, n: int) -> Tensor:
+    """common.py:66-73 (only WaveNetOriginal uses it; no config instantiates it)."""
+    x = a + b
+    return torch.tanh(x[:, :n]) * torch.sigmoid(x[:, n:])
+
+
+# --------------------------------------------------------------------------
+# coupling layers
+# --------------------------------------------------------------------------
+def scaling_and_log(su: Tensor, fn: str) -> Tuple[Tensor, Tensor]:
+    """AffineTransformationLayer.get_scaling_and_logs.  common.py:1127-1140."""
+    if fn == "tanh":
+        s = torch.tanh(su) + 1 + 1e-6
+        return s, torch.log(s)
+    if fn == "exp":
+        return torch.exp(su), su
+    if fn == "sigmoid":
+        s = torch.sigmoid(su + 10) + 1e-6
+        return s, torch.log(s)
+    if fn == "translate":
+        return torch.exp(su * 0), su * 0
+    raise ValueError(fn)
+
+
+def affine_coupling_forward(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Optional[Tensor],
+                            n_layers: int, scaling_fn: str = "tanh",
+                            activation: str = "softplus", partial: bool = True
+                            ) -> Tuple[Tensor, Tensor]:
+    """AffineTransformationLayer.forward (affine_model='wavenet').  common.py:1163-1185."""
+    h = z.shape[1] // 2
+    z0, z1 = z[:, :h], z[:, h:]
+    o = wn_forward(p, prefix + "affine_param_predictor.", z0, ctx, mask, n_layers, activation, partial)
+    s, log_s = scaling_and_log(o[:, :h], scaling_fn)
+    return torch.cat((z0, s * z1 + o[:, h:]), 1), log_s
+
+
+def affine_coupling_inverse(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Optional[Tensor],
+                            n_layers: int, scaling_fn: str = "tanh",
+                            activation: str = "softplus", partial: bool = True) -> Tensor:
+    """common.py:1178-1181."""
+    h = z.shape[1] // 2
+    z0, z1 = z[:, :h], z[:, h:]
+    o = wn_forward(p, prefix + "affine_param_predictor.", z0, ctx, mask, n_layers, activation, partial)
+    s, _ = scaling_and_log(o[:, :h], scaling_fn)
+    return torch.cat((z0, (z1 - o[:, h:]) / s), 1)
+
+
+# --------------------------------------------------------------------------
+# invertible 1x1 convs
+# --------------------------------------------------------------------------
+def lus_weight(p: Params, prefix: str) -> Tensor:
+    """W = P (L U), L unit-lower, U = triu(upper,1)+diag(upper_diag).  common.py:529-531."""
+    U = torch.triu(p[prefix + "upper"], 1) + torch.diag(p[prefix + "upper_diag"])
+    L = torch.tril(p[prefix + "lower"], -1) + torch.diag(p[prefix + "lower_diag"])
+    return p[prefix + "p"] @ (L @ U)
+
+
+def inv1x1_lus_forward(p: Params, prefix: str, z: Tensor) -> Tuple[Tensor, Tensor]:
+    """Invertible1x1ConvLUS.forward.  common.py:527-548."""
+    W = lus_weight(p, prefix)
+    return F.conv1d(z, W[..., None]), torch.log(torch.abs(p[prefix + "upper_diag"])).sum()
+
+
+def whiten_weight(p: Params, prefix: str) -> Tensor:
+    """common.py:598."""
+    return torch.triu(p[prefix + "upper"], 1) + torch.diag(p[prefix + "upper_diag"])
+
+
+def inv1x1_whiten_forward(p: Params, prefix: str, z: Tensor) -> Tuple[Tensor, Tensor]:
+    """DataInitializedInvertible1x1Conv.forward (already initialised).  common.py:612-617."""
+    W = whiten_weight(p, prefix)
+    z = z - p[prefix + "input_mean"].unsqueeze(0)
+    return F.conv1d(z, W[..., None]), torch.log(torch.abs(p[prefix + "upper_diag"])).sum()
+
+
+def whiten_initialize(z: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """Data-dependent init of flow 0: returns (input_mean [C,1], upper_diag [C], upper [C,C]).
+
+    common.py:569-591: gather the valid frames of every item, covariance / N,
+    inverse, upper Cholesky factor.
+    """
+    cols = [z[b, :, : int(lengths[b])] for b in range(z.shape[0])]
+    data = torch.cat(cols, 1)
+    N = data.shape[1]
+    mean = data.mean(1, keepdim=True)
+    cen = data - mean
+    cov = (cen @ cen.t()) / N
+    wm = torch.linalg.cholesky(torch.inverse(cov), upper=True).contiguous()
+    return mean, torch.diag(wm).clone(), torch.triu(wm, 1)
+
+
+# --------------------------------------------------------------------------
+# splines (piecewise quadratic, zunis-style)  splines.py:241-339
+# --------------------------------------------------------------------------
+def weighted_softmax(v: Tensor, w: Tensor) -> Tensor:
+    """splines.py:267-272."""
+    v = v - v.max(dim=-1, keepdim=True)[0]
+    v = torch.exp(v) + 1e-8
+    area = ((v[..., :-1] + v[..., 1:]) / 2 * w).sum(-1, keepdim=True)
+    return v / area
+
+
+def piecewise_quadratic_transform(x: Tensor, w_tilde: Tensor, v_tilde: Tensor,
+                                  inverse: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """splines.py:274-339.  x in [0,1), any leading shape; w_tilde [...,K], v_tilde [...,K+1]."""
+    eps = torch.finfo(x.dtype).eps
+    w = torch.softmax(w_tilde, -1)
+    v = weighted_softmax(v_tilde, w)
+    wc = torch.cumsum(w, -1)
+    wc[..., -1] = 1.0
+    wc_shift = F.pad(wc, (1, 0))
+    cdf = torch.cumsum((v[..., 1:] + v[..., :-1]) / 2 * w, -1)
+    cdf[..., -1] = 1.0
+    cdf_shift = F.pad(cdf, (1, 0))
+    edges = cdf if inverse else wc
+    idx = torch.searchsorted(edges, x.unsqueeze(-1))
+    take = lambda t, i: torch.gather(t, -1, i).squeeze(-1)
+    w_b, w_l = take(w, idx), take(wc_shift, idx)
+    v_b, v_r = take(v, idx), take(v, idx + 1)
+    c_l = take(cdf_shift, idx)
+    if not inverse:
+        a = (x - w_l) / w_b.clamp(min=eps)
+        y = a ** 2 / 2 * (v_r - v_b) * w_b + a * v_b * w_b + c_l
+        logj = torch.lerp(v_b, v_r, a).clamp(min=eps).log()
+        return y.clamp(min=eps, max=1.0 - eps), logj
+    qa = (v_r - v_b) * w_b / 2
+    qb = v_b * w_b
+    qc = c_l - x
+    a = (-qb + torch.sqrt(qb ** 2 - 4 * qa * qc)) / (2 * qa)
+    return (a * w_b + w_l).clamp(min=eps, max=1.0 - eps), None
+
+
+def unbounded_piecewise_quadratic_transform(x: Tensor, w_tilde: Tensor, v_tilde: Tensor,
+                                            upper: float = 1, lower: float = 0,
+                                            inverse: bool = False):
+    """Identity outside [lower, upper).  splines.py:241-265.
+
+    Restated with a select instead of boolean-mask gather/scatter (same values:
+    the inside branch is evaluated on clamped stand-ins for outside elements
+    and discarded).
+    """
+    rng = upper - lower
+    inside = (x >= lower) & (x < upper)
+    xs = torch.where(inside, (x - lower) / rng, torch.full_like(x, 0.5))
+    y, logj = piecewise_quadratic_transform(xs, w_tilde, v_tilde, inverse)
+    out = torch.where(inside, y * rng + lower, x)
+    if inverse:
+        return out, None
+    return out, torch.where(inside, logj, torch.zeros_like(logj))
+
+
+def masked_batchnorm1d(p: Params, prefix: str, x: Tensor, mask: Tensor, training: bool,
+                       eps: float = 1e-5) -> Tensor:
+    """MaskedBatchNorm1d.forward, single process.  maskedbatchnorm1d.py:53-118.
+
+    Running-stat updates are not restated (side effect; they do not enter the
+    training-mode output)."""
+    n = mask.sum()
+    me = mask.expand(x.shape)
+    if training and n > 1:
+        mean = (me * x).sum([0, 2]) / n
+        var = (me * x ** 2).sum([0, 2]) / n - mean ** 2
+    else:
+        mean, var = p[prefix + "running_mean"], p[prefix + "running_var"]
+    y = (x - mean[None, :, None]) / torch.sqrt(var[None, :, None] + eps)
+    return y * p[prefix + "weight"][None, :, None] + p[prefix + "bias"][None, :, None]
+
+
+def film_stack_forward(p: Params, prefix: str, x: Tensor, ctx: Tensor, mask: Tensor, n_layers: int,
+                       use_bn: bool, training: bool = True) -> Tensor:
+    """FiLMStack / FiLMResBlock.  common.py:706-773."""
+    for i in range(n_layers):
+        q = f"{prefix}in_layers.{i}."
+        x1 = conv_norm(p, q + "input_conv.", x, mask, 1)
+        c1 = conv_norm(p, q + "cond_conv.", ctx, mask, 1)
+        n_out = x1.shape[1]
+        scale, bias = c1[:, :n_out] + 1, c1[:, n_out:]
+        x1r = F.leaky_relu(x1)
+        x2 = conv_norm(p, q + "hidden_conv.", x1r, mask, 2 ** i)
+        if use_bn:
+            x2 = masked_batchnorm1d(p, q + "bn.", x2, mask, training)
+        x2 = F.leaky_relu(x2 * scale + bias)
+        x = 0.5 * (x2 + x1r)
+    return F.conv1d(x, p[prefix + "end.weight"], p[prefix + "end.bias"])
+
+
+def spline_coupling_forward(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Tensor,
+                            n_layers: int, n_bins: int = 32, bound: float = 3.0,
+                            use_bn: bool = True, training: bool = True) -> Tuple[Tensor, Tensor]:
+    """SplineTransformationLayer.forward, use_quadratic=True.  common.py:1040-1090
+    (left=bottom=-bound, right=top=bound as wired by decoders.py:51-61)."""
+    B, C, T = z.shape
+    h = C // 2
+    z0, z1 = z[:, :h], z[:, h:]
+    z1n = (z1 + bound) / (2 * bound)
+    q = film_stack_forward(p, prefix + "param_predictor.", z0, ctx, mask, n_layers, use_bn, training)
+    nb = 2 * n_bins + 1
+    x = z1n.permute(0, 2, 1).reshape(B * T, h)
+    qt = q.permute(0, 2, 1).reshape(B * T, h, nb)
+    y, logj = unbounded_piecewise_quadratic_transform(
+        x.float(), qt[:, :, :nb // 2].float(), qt[:, :, nb // 2:].float())
+    z1o = y.reshape(B, T, h).permute(0, 2, 1) * (2 * bound) - bound
+    log_s = logj.sum(1).reshape(B, T).unsqueeze(1)  # + h*(log(2b)-log(2b)) == 0
+    return torch.cat((z0, z1o), 1), log_s
+
+
+# --------------------------------------------------------------------------
+# decoder
+# --------------------------------------------------------------------------
+class DecoderConfig:
+    """Mirror of RADMMMFlow's ctor arguments that matter to the arithmetic
+    (decoders.py:83-143; models/radmmm.py:30-101)."""
+
+    def __init__(self, n_speaker_dim=16, n_accent_dim=8, n_text_dim=512, n_group_size=2,
+                 n_mel_channels=80, n_f0_dims=1, n_energy_avg_dims=1, n_flows=8,
+                 n_conv_layers_per_step=4, n_early_size=2, n_early_every=2,
+                 scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+                 n_splines=0, use_bn=True, use_accent_emb_for_decoder=True,
+                 context_w_f0_and_energy=True, use_context_lstm=True):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    @property
+    def lstm_in(self):
+        n = (self.n_f0_dims + self.n_energy_avg_dims + self.n_text_dim) * self.n_group_size
+        n += self.n_speaker_dim
+        if self.use_accent_emb_for_decoder:
+            n += self.n_accent_dim
+        return n
+
+    @property
+    def lstm_hidden(self):
+        n = self.n_speaker_dim + self.n_text_dim * self.n_group_size
+        if self.use_accent_emb_for_decoder:
+            n += self.n_accent_dim
+        return int(n / 2)
+
+    @property
+    def cond_dims(self):
+        return 2 * self.lstm_hidden
+
+    def flow_channels(self) -> List[int]:
+        c = self.n_mel_channels * self.n_group_size
+        out = []
+        for i in range(self.n_flows):
+            if i > 0 and i % self.n_early_every == 0:
+                c -= self.n_early_size
+            out.append(c)
+        return out
+
+    def exit_steps(self) -> List[int]:
+        return [i for i in range(self.n_flows) if i > 0 and i % self.n_early_every == 0]
+
+
+def lstm_bidir_packed(p: Params, prefix: str, x: Tensor, lengths: Tensor, hidden: int) -> Tensor:
+    """Packed bi-LSTM over [B,T,F] -> [B,T,2H], zeros at padded frames.
+    models/radmmm.py:136-146 (torch.nn.LSTM is torch itself, available here)."""
+    lstm = torch.nn.LSTM(x.shape[-1], hidden, num_layers=1, batch_first=True, bidirectional=True)
+    lstm = lstm.to(x.dtype)
+    sd = {k: p[prefix + k] for k in lstm.state_dict().keys()}
+    # keep autograd connectivity to p: functional call
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.cpu(), batch_first=True,
+                                                     enforce_sorted=False)
+    out, _ = torch.func.functional_call(lstm, sd, (packed,))
+    y, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
+    return y
+
+
+def preprocess_context(p: Params, cfg: DecoderConfig, context: Tensor, spk: Tensor, lengths: Tensor,
+                       f0: Optional[Tensor], energy: Optional[Tensor],
+                       accent: Optional[Tensor]) -> Tensor:
+    """RADMMM.preprocess_context.  models/radmmm.py:103-148."""
+    g = cfg.n_group_size
+    ctx = squeeze_time(context, g)
+    T = ctx.shape[2]
+    parts = [ctx, spk[:, :, None].expand(-1, -1, T)]
+    if cfg.use_accent_emb_for_decoder:
+        parts.append(accent[:, :, None].expand(-1, -1, T))
+    if cfg.context_w_f0_and_energy:
+        if f0 is not None:
+            parts.append(squeeze_time(f0[:, None], g))
+        if energy is not None:
+            parts.append(squeeze_time(energy[:, None], g))
+    x = torch.cat(parts, 1)
+    if not cfg.use_context_lstm:
+        return x
+    ul = torch.div(lengths, g, rounding_mode="floor").long()
+    y = lstm_bidir_packed(p, "context_lstm.", x.transpose(1, 2), ul, cfg.lstm_hidden)
+    return y.transpose(1, 2)
+
+
+def decoder_forward(p: Params, cfg: DecoderConfig, mel: Tensor, spk: Tensor, context: Tensor,
+                    lengths: Tensor, f0: Optional[Tensor] = None, energy: Optional[Tensor] = None,
+                    accent: Optional[Tensor] = None, training: bool = True) -> Dict[str, object]:
+    """RADMMMFlow.forward.  decoders.py:168-205."""
+    g = cfg.n_group_size
+    ctx = preprocess_context(p, cfg, context, spk, lengths, f0, energy, accent)
+    z = squeeze_time(mel, g)
+    ul = torch.div(lengths, g, rounding_mode="floor").long()
+    mask = lengths_to_mask(ul)[:, None].to(mel.dtype)
+    exits = cfg.exit_steps()
+    z_out, log_s_list, log_det_list = [], [], []
+    for i in range(cfg.n_flows):
+        if i in exits:
+            z_out.append(z[:, : cfg.n_early_size])
+            z = z[:, cfg.n_early_size:]
+        pre = f"flows.{i}."
+        if i == 0:
+            z, ld = inv1x1_whiten_forward(p, pre + "invtbl_conv.", z)
+        else:
+            z, ld = inv1x1_lus_forward(p, pre + "invtbl_conv.", z)
+        if i < cfg.n_splines:
+            z, ls = spline_coupling_forward(p, pre + "coupling_tfn.", z, ctx, mask,
+                                            cfg.n_conv_layers_per_step, use_bn=cfg.use_bn,
+                                            training=training)
+        else:
+            z, ls = affine_coupling_forward(p, pre + "coupling_tfn.", z, ctx, mask,
+                                            cfg.n_conv_layers_per_step, cfg.scaling_fn,
+                                            cfg.affine_activation, cfg.use_partial_padding)
+        log_s_list.append(ls)
+        log_det_list.append(ld)
+    z_out.append(z)
+    return {"z_mel": torch.cat(z_out, 1), "log_det_W_list": log_det_list,
+            "log_s_list": log_s_list, "context_w_spkvec": ctx}
+
+
+def compute_flow_loss(z: Tensor, log_det_W_list: Sequence[Tensor], log_s_list: Sequence[Tensor],
+                      n_elements, n_dims: int, mask: Tensor, sigma: float = 1.0
+                      ) -> Tuple[Tensor, Tensor]:
+    """loss.py:85-110 (no log 2*pi term)."""
+    log_s_total = sum(torch.sum(ls * mask) for ls in log_s_list)
+    log_det_total = sum(log_det_W_list) * n_elements if len(log_det_W_list) else 0.0
+    zm = z * mask
+    prior = torch.sum(zm * zm) / (2 * sigma * sigma)
+    denom = n_elements * n_dims
+    return (prior - log_s_total - log_det_total) / denom, prior / denom
+
+
+def decoder_loss(out: Dict[str, object], lengths: Tensor, g: int, sigma: float = 1.0):
+    """The flow part of RADMMMLoss.forward.  loss.py:518-532."""
+    n_el = torch.div(lengths.sum(), g, rounding_mode="floor")
+    mask = lengths_to_mask(torch.div(lengths, g, rounding_mode="floor"))[:, None].float()
+    z = out["z_mel"]
+    return compute_flow_loss(z, out["log_det_W_list"], out["log_s_list"], n_el, z.shape[1],
+                             mask.to(z.dtype), sigma)
+
+
+# --------------------------------------------------------------------------
+# alignment attention, MAS, attention losses
+# --------------------------------------------------------------------------
+def conv_attention_forward(p: Params, prefix: str, queries: Tensor, keys: Tensor,
+                           key_pad_mask: Optional[Tensor], attn_prior: Optional[Tensor]
+                           ) -> Tuple[Tensor, Tensor]:
+    """ConvAttention.forward.  common.py:1239-1277.
+
+    queries [B,n_mel,T1], keys [B,n_txt,T2], key_pad_mask bool [B,T2,1] True at
+    PADDED text positions, attn_prior [B,T1,T2].  Returns (attn, attn_logprob)
+    both [B,1,T1,T2].
+    """
+    def cn(name, x, k):
+        w = _wn_weight(p, f"{prefix}{name}.conv.")
+        return F.conv1d(x, w, p[f"{prefix}{name}.conv.bias"], padding=(k - 1) // 2)
+    kk = cn("key_proj.2", torch.relu(cn("key_proj.0", keys, 3)), 1)
+    q = torch.relu(cn("query_proj.0", queries, 3))
+    q = torch.relu(cn("query_proj.2", q, 1))
+    q = cn("query_proj.4", q, 1)
+    d = ((q[:, :, :, None] - kk[:, :, None]) ** 2).sum(1, keepdim=True)
+    a = -0.0005 * d
+    if attn_prior is not None:
+        a = torch.log_softmax(a, 3) + torch.log(attn_prior[:, None] + 1e-8)
+    logprob = a.clone()
+    if key_pad_mask is not None:
+        a = a.masked_fill(key_pad_mask.permute(0, 2, 1).unsqueeze(2), -float("inf"))
+    return torch.softmax(a, 3), logprob
+
+
+def mas_width1(attn_map: np.ndarray) -> np.ndarray:
+    """Monotonic alignment search, width 1 (INTEGER/INDEX path, bit-exact).
+
+    alignment.py:31-59: Viterbi over log(attn) [T_mel, T_txt]; first row forced
+    to column 0; moves are {stay, +1}; ties go to the diagonal (>=); backtrack
+    from the last text index.  Output 0/1 matrix of attn_map's dtype.
+    """
+    T1, T2 = attn_map.shape
+    with np.errstate(divide="ignore"):
+        lp = np.log(attn_map)
+    lp[0, 1:] = -np.inf
+    acc = np.zeros_like(lp)
+    acc[0] = lp[0]
+    prev = np.zeros((T1, T2), dtype=np.int64)
+    cols = np.arange(T2)
+    for i in range(1, T1):
+        stay = acc[i - 1]
+        diag = np.concatenate(([-np.inf], acc[i - 1, :-1])).astype(lp.dtype)
+        take_diag = diag >= stay
+        take_diag[0] = False
+        acc[i] = lp[i] + np.where(take_diag, diag, stay)
+        prev[i] = np.where(take_diag, cols - 1, cols)
+    opt = np.zeros_like(attn_map)
+    j = T2 - 1
+    for i in range(T1 - 1, -1, -1):
+        opt[i, j] = 1
+        j = prev[i, j]
+    opt[0, j] = 1
+    return opt
+
+
+def binarize_attention(attn: Tensor, in_lens: Tensor, out_lens: Tensor) -> Tensor:
+    """TTSModel.binarize_attention.  tts_lightning_modules.py:270-284.
+    attn [B,1,T_mel_max,T_txt_max] -> same shape 0/1."""
+    a = attn.detach().cpu().numpy()
+    out = np.zeros_like(a)
+    for b in range(a.shape[0]):
+        out[b, 0, : int(out_lens[b]), : int(in_lens[b])] = mas_width1(
+            a[b, 0, : int(out_lens[b]), : int(in_lens[b])].copy())
+    return torch.from_numpy(out)
+
+
+def attention_ctc_loss(attn_logprob: Tensor, in_lens: Tensor, out_lens: Tensor,
+                       blank_logprob: float = -1) -> Tensor:
+    """AttentionCTCLoss.forward.  loss.py:119-141."""
+    padded = F.pad(attn_logprob, (1, 0), value=blank_logprob)
+    total = 0.0
+    B = attn_logprob.shape[0]
+    for b in range(B):
+        kl, ql = int(in_lens[b]), int(out_lens[b])
+        tgt = torch.arange(1, kl + 1).unsqueeze(0)
+        lp = padded[b].permute(1, 0, 2)[:ql, :, : kl + 1]
+        lp = torch.log_softmax(lp, -1)
+        total = total + F.ctc_loss(lp, tgt, input_lengths=out_lens[b:b + 1],
+                                   target_lengths=in_lens[b:b + 1], zero_infinity=True)
+    return total / B
+
+
+def attention_binarization_loss(hard: Tensor, soft: Tensor) -> Tensor:
+    """AttentionBinarizationLoss.forward.  loss.py:147-151:  mean(-log soft[hard==1])
+    (torch BCE clamps log at -100)."""
+    sel = soft[hard == 1]
+    return F.binary_cross_entropy(sel, torch.ones_like(sel), reduction="mean")
+
+
+# --------------------------------------------------------------------------
+# STFT -> mel
+# --------------------------------------------------------------------------
+def hann_periodic(n: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', n, fftbins=True)  (audio_processing.py:212)."""
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def stft_magnitude(audio: np.ndarray, n_fft: int, hop: int, win: int) -> np.ndarray:
+    """STFT.transform magnitude.  audio_processing.py:227-255.
+
+    audio [B, S] -> [B, n_fft//2+1, 1 + S//hop].  Reflect-pad n_fft/2 both
+    sides, frames of n_fft at stride hop, window = periodic hann(win) centre-
+    padded to n_fft, DFT basis in float32 as the reference's conv1d weights.
+    """
+    B, S = audio.shape
+    w = hann_periodic(win)
+    lp = (n_fft - win) // 2
+    w = np.pad(w, (lp, n_fft - win - lp))
+    cutoff = n_fft // 2 + 1
+    k = np.arange(cutoff)[:, None]
+    n = np.arange(n_fft)[None, :]
+    ang = 2.0 * np.pi * k * n / n_fft
+    basis_re = (np.cos(ang)).astype(np.float32) * w.astype(np.float32)
+    basis_im = (-np.sin(ang)).astype(np.float32) * w.astype(np.float32)
+    x = np.pad(audio.astype(np.float32), ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+    n_frames = (x.shape[1] - n_fft) // hop + 1
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = x[:, idx]                                # [B, F, n_fft]
+    re = np.einsum("bfn,kn->bkf", frames, basis_re, dtype=np.float32)
+    im = np.einsum("bfn,kn->bkf", frames, basis_im, dtype=np.float32)
+    return np.sqrt(re * re + im * im).astype(np.float32)
+
+
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank_slaney(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: Optional[float]
+                          ) -> np.ndarray:
+    """Published algorithm of librosa 0.8.0 `filters.mel(sr, n_fft, n_mels, fmin, fmax)`
+    with its defaults (htk=False -> Slaney scale, norm='slaney'); call site
+    audio_processing.py:124-125.  PARITY UNPINNED: librosa is absent from the
+    reference tree and from this image; self-checked only (tests/test_oracle_golden.py).
+    """
+    if fmax is None:
+        fmax = sr / 2.0
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz_slaney(np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    wts = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        wts[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2: n_mels + 2] - mel_f[:n_mels])
+    return (wts * enorm[:, None]).astype(np.float32)
+
+
+def mel_spectrogram(audio: np.ndarray, mel_basis: np.ndarray, n_fft: int, hop: int, win: int
+                    ) -> np.ndarray:
+    """TacotronSTFT.mel_spectrogram.  audio_processing.py:137-154 + :98-104."""
+    mag = stft_magnitude(audio, n_fft, hop, win)
+    mel = np.einsum("mk,bkf->bmf", mel_basis.astype(np.float32), mag, dtype=np.float32)
+    return np.log(np.maximum(mel, 1e-5)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# procedural weights (shared by the golden generator, tests and bench)
+# --------------------------------------------------------------------------
+def procedural_tensor(shape: Sequence[int], salt: int, scale: float = 1.0) -> np.ndarray:
+    """Closed-form pseudo-random fp32 tensor: a deterministic hash of the flat
+    index (no RNG state, identical everywhere).  Values roughly uniform in
+    [-scale, scale]."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    i = np.arange(n, dtype=np.uint64)
+    x = i + np.uint64((int(salt) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)   # wraps mod 2^64
+    x ^= x >> np.uint64(30)
+    x = (x * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(27)
+    x = (x * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return ((2.0 * u - 1.0) * scale).astype(np.float32).reshape(shape)
+
+
+def _salt(name: str) -> int:
+    h = 1469598103934665603
+    for ch in name.encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h & 0x7FFFFFFF
+
+
+def procedural_decoder_state(shapes: Dict[str, Tuple[int, ...]], end_scale: float = 0.02
+                             ) -> Dict[str, np.ndarray]:
+    """Deterministic, well-conditioned values for every tensor of a decoder
+    state_dict given only names and shapes.
+
+    * conv / lstm weights ~ U(-a, a) with a = sqrt(3 / fan_in)
+    * weight_g = 1 + small, biases small
+    * `end` conv (zero-init in the reference, common.py:799-801) gets
+      U(-end_scale, end_scale) so the coupling is not the identity
+    * LUS factors: unit-ish diagonal, small off-diagonals, identity permutation
+      (a valid member of the reference's parameterisation, common.py:529-531)
+    * whitening layer: initialised=True, mean 2.5-ish (mel scale), upper as LUS
+    """
+    out: Dict[str, np.ndarray] = {}
+    for name, shp in shapes.items():
+        s = _salt(name)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "p":
+            out[name] = np.eye(shp[0], dtype=np.float32)
+        elif leaf == "lower_diag":
+            out[name] = np.ones(shp, dtype=np.float32)
+        elif leaf == "initialized":
+            out[name] = np.array(True)
+        elif leaf == "input_mean":
+            out[name] = 2.5 + procedural_tensor(shp, s, 0.2)
+        elif leaf == "upper_diag":
+            d = 1.0 + procedural_tensor(shp, s, 0.25)
+            sign = np.where(procedural_tensor(shp, s + 1, 1.0) > 0.6, -1.0, 1.0)
+            out[name] = (d * sign).astype(np.float32)
+        elif leaf in ("upper", "lower"):
+            out[name] = procedural_tensor(shp, s, 0.5 / math.sqrt(shp[0]))
+        elif leaf == "weight_g":
+            out[name] = 1.0 + procedural_tensor(shp, s, 0.1)
+        elif leaf == "num_batches_tracked":
+            out[name] = np.array(0, dtype=np.int64)
+        elif leaf == "running_mean":
+            out[name] = np.zeros(shp, dtype=np.float32)
+        elif leaf == "running_var":
+            out[name] = np.ones(shp, dtype=np.float32)
+        elif ".end." in name or name.startswith("end."):
+            out[name] = procedural_tensor(shp, s, end_scale)
+        elif ".bn." in name and leaf == "weight":
+            out[name] = 1.0 + procedural_tensor(shp, s, 0.1)
+        elif leaf.startswith("bias"):
+            out[name] = procedural_tensor(shp, s, 0.05)
+        else:  # weight_v / weight / lstm weight_*
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else int(shp[0])
+            out[name] = procedural_tensor(shp, s, math.sqrt(3.0 / max(fan_in, 1)))
+    return out
+
+
+def decoder_state_shapes(cfg: DecoderConfig, wn_channels: int = 1024, film_hidden: int = 512
+                         ) -> Dict[str, Tuple[int, ...]]:
+    """Names and shapes of RADMMMFlow.state_dict() for `cfg` (verified
+    against the reference by tests/golden/make_golden.py)."""
+    sh: Dict[str, Tuple[int, ...]] = {}
+    H, I = cfg.lstm_hidden, cfg.lstm_in
+    for suf in ("", "_reverse"):
+        sh[f"context_lstm.weight_ih_l0{suf}"] = (4 * H, I)
+        sh[f"context_lstm.weight_hh_l0{suf}"] = (4 * H, H)
+        sh[f"context_lstm.bias_ih_l0{suf}"] = (4 * H,)
+        sh[f"context_lstm.bias_hh_l0{suf}"] = (4 * H,)
+    D = cfg.cond_dims
+    L = cfg.n_conv_layers_per_step
+    for i, C in enumerate(cfg.flow_channels()):
+        pre = f"flows.{i}.invtbl_conv."
+        if i == 0:
+            sh[pre + "input_mean"] = (C, 1)
+            sh[pre + "initialized"] = ()
+            sh[pre + "p"] = (C, C)
+            sh[pre + "upper_diag"] = (C,)
+            sh[pre + "upper"] = (C, C)
+        else:
+            sh[pre + "p"] = (C, C)
+            sh[pre + "lower_diag"] = (C,)
+            sh[pre + "lower"] = (C, C)
+            sh[pre + "upper_diag"] = (C,)
+            sh[pre + "upper"] = (C, C)
+        h = C // 2
+        if i < cfg.n_splines:
+            q = f"flows.{i}.coupling_tfn.param_predictor."
+            sh[q + "end.weight"] = (h * 65, film_hidden, 1)
+            sh[q + "end.bias"] = (h * 65,)
+            for j in range(L):
+                cin = h if j == 0 else film_hidden
+                for nm, co, ci, k in (("input_conv", film_hidden, cin, 1),
+                                      ("cond_conv", 2 * film_hidden, D, 1),
+                                      ("hidden_conv", film_hidden, film_hidden, 5)):
+                    b = f"{q}in_layers.{j}.{nm}.conv."
+                    sh[b + "bias"] = (co,)
+                    sh[b + "weight_g"] = (co, 1, 1)
+                    sh[b + "weight_v"] = (co, ci, k)
+                if cfg.use_bn:
+                    b = f"{q}in_layers.{j}.bn."
+                    sh[b + "weight"] = (film_hidden,)
+                    sh[b + "bias"] = (film_hidden,)
+                    sh[b + "running_mean"] = (film_hidden,)
+                    sh[b + "running_var"] = (film_hidden,)
+                    sh[b + "num_batches_tracked"] = ()
+        else:
+            q = f"flows.{i}.coupling_tfn.affine_param_predictor."
+            W = wn_channels
+            sh[q + "start.bias"] = (W,)
+            sh[q + "start.weight_g"] = (W, 1, 1)
+            sh[q + "start.weight_v"] = (W, h + D, 1)
+            sh[q + "end.weight"] = (C, W, 1)
+            sh[q + "end.bias"] = (C,)
+            for j in range(L):
+                b = f"{q}in_layers.{j}.conv."
+                sh[b + "bias"] = (W,)
+                sh[b + "weight_g"] = (W, 1, 1)
+                sh[b + "weight_v"] = (W, W, 5)
+                b = f"{q}res_skip_layers.{j}."
+                sh[b + "bias"] = (W,)
+                sh[b + "weight_g"] = (W, 1, 1)
+                sh[b + "weight_v"] = (W, W, 1)
+    return sh
+
+
+def synthetic_batch(B: int, T: int, cfg: DecoderConfig, seed: int = 1234, ragged: bool = False
+                    ) -> Dict[str, np.ndarray]:
+    """Synthetic decoder inputs: mel ~ N(2.5, 0.5^2) (already
+    'scale_mel'-ed), context ~ N(0,1), spk/accent ~ N(0,1), f0 in [0,6) with 30%
+    zeros, energy ~ U(0,1).  numpy PCG64(seed)."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    d = {
+        "mel": (2.5 + 0.5 * r.standard_normal((B, cfg.n_mel_channels, T))).astype(np.float32),
+        "context": r.standard_normal((B, cfg.n_text_dim, T)).astype(np.float32),
+        "spk": r.standard_normal((B, cfg.n_speaker_dim)).astype(np.float32),
+        "accent": r.standard_normal((B, cfg.n_accent_dim)).astype(np.float32),
+    }
+    f0 = (6.0 * r.random((B, T))).astype(np.float32)
+    f0[r.random((B, T)) < 0.3] = 0.0
+    d["f0"] = f0
+    d["energy"] = r.random((B, T)).astype(np.float32)
+    if ragged:
+        lens = np.sort(r.integers(int(0.6 * T), T + 1, size=B))[::-1].copy()
+        lens[0] = T
+    else:
+        lens = np.full((B,), T)
+    d["lengths"] = lens.astype(np.int64)
+    # zero-pad like DataCollate (data.py:621-790)
+    for b in range(B):
+        L = int(lens[b])
+        d["mel"][b, :, L:] = 0
+        d["context"][b, :, L:] = 0
+        d["f0"][b, L:] = 0
+        d["energy"][b, L:] = 0
+    return d

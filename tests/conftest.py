@@ -1,0 +1,42 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+    return get
+
+
+def sub(d, prefix):
+    """{k[len(prefix):]: v} for keys starting with prefix."""
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
