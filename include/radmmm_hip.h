@@ -1,0 +1,244 @@
+/*
+ * radmmm_hip.h -- C ABI of libradmmm_hip.so: hand-written gfx950 (MI355X) kernels for
+ * the RAD-MMM flow-decoder training step.
+ *
+ * The reference (NVIDIA/RAD-MMM) is pure Python/PyTorch and has NO C/FFI boundary
+ * (SURVEY.md §8b): its plug-in mechanism is jsonargparse `class_path`
+ * (configs/RADTTS_model_config.yaml:16-48, tts_main.py:64-65).  The drop-in is
+ * therefore the Python package `rad_mmm_amd` (same ctor kwargs / forward signature /
+ * state_dict names as decoders.RADMMMFlow and loss.RADMMMLoss); THIS header is the
+ * boundary underneath it, i.e. what a binding for the reference's operators would
+ * bind.  Each entry point cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; radmmm_last_error() returns a
+ *    thread-local message for the last failure on the calling thread.
+ *  - all pointers are DEVICE pointers into caller-owned memory (no ownership
+ *    transfer, no allocation inside the library, no internal threads, no global
+ *    mutable state apart from the error string).
+ *  - every call takes the hipStream_t to launch on (as void*) and is asynchronous.
+ *  - activations are CHANNELS-LAST fp32: a [B, C, T] tensor of the reference is held
+ *    as a row-major matrix [B*T rows][ld floats] with row r = b*T + t.  ld % 4 == 0
+ *    and 16-byte aligned bases are required wherever a matrix feeds a GEMM.
+ *  - `lens` is an int32 device array [B] of valid frames per item (already divided by
+ *    n_group_size); NULL means all T frames valid.
+ */
+#ifndef RADMMM_HIP_H
+#define RADMMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RADMMM_ABI_VERSION 1
+
+typedef void* radmmm_stream_t; /* hipStream_t */
+
+const char* radmmm_last_error(void);
+int radmmm_abi_version(void);
+
+/* activation codes (forward) / derivative-from-output codes (backward) */
+enum { RADMMM_ACT_NONE = 0, RADMMM_ACT_SOFTPLUS = 1, RADMMM_ACT_RELU = 2, RADMMM_ACT_LEAKY = 3 };
+/* scaling functions of the affine coupling, common.py:1127-1140 */
+enum { RADMMM_SCALE_TANH = 0, RADMMM_SCALE_EXP = 1, RADMMM_SCALE_SIGMOID = 2, RADMMM_SCALE_TRANSLATE = 3 };
+
+/* ------------------------------------------------------------------------------------
+ * Row GEMM with taps: the Conv1d family in channels-last form, fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32, exact fp32).
+ *
+ *   acc[r, n] = sum_{tap} sum_{k<K} Am[r + shift(tap), k] * Bt[tap](k, n)
+ *   shift(tap) = sign * (tap - taps/2) * dil
+ *   Am[row, :] = A[row, :] if the shifted frame lies in the same item and inside
+ *                [0, T) (a_mask_mode 0) or [0, lens[b]) (a_mask_mode 1), else 0
+ *   Bt[tap](k, n) = B[tap*b_tap_stride + n*ldb + k]   (b_layout 0: [N][K], forward)
+ *                 = B[tap*b_tap_stride + k*ldb + n]   (b_layout 1: [K][N], data-grad)
+ *
+ * Epilogue, applied in this order to v = acc:
+ *   pconv     : v *= taps_r / (cnt + 1e-6), cnt = #taps of a (ratio_taps, ratio_dil)
+ *               window centred on r whose frame is < lens[b]  (0 if cnt == 0)
+ *   premask   : v *= [t < lens[b]]
+ *   bias      : v += bias[n]
+ *   add       : v += add[r*ldadd + n]
+ *   postmask  : v *= [t < lens[b]]
+ *   dact      : v *= act'(y) expressed from the saved OUTPUT y = dact_src[r*lddact+n]
+ *               (softplus: 1 - exp(-y); relu: y > 0; leaky: y > 0 ? 1 : 0.01)
+ *   rowscale  : 1: v *= mask ; 2: v *= mask * ratio (same ratio definition as pconv)
+ *   act       : v = act(v)
+ *   C[r*ldc+n] = v ;  if C2: C2[r*ldc2+n] = (c2_accum ? C2[...] : 0) + v
+ *
+ * Replaces: F.conv1d / PartialConv1d / ConvNorm / weight-normed 1x1 convs and their
+ * autograd data-gradients (common.py:179-191, 816-835; partialconv1d.py:58-94), and
+ * the invertible 1x1 channel mix (common.py:546, 615).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* A; int lda;
+  int64_t a_item_stride; /* 0: row r at A + r*lda; else item b, frame t at A + b*a_item_stride + t*lda
+                            (rows of one item may then overlap: lda < K is allowed, STFT framing) */
+  const float* B; int ldb; int64_t b_tap_stride; int b_layout;
+  float* C; int ldc;
+  int M, N, K;
+  int taps, dil, sign;
+  int T;                 /* frames per item; M must be a multiple of T */
+  const int32_t* lens;   /* [M/T] or NULL */
+  int a_mask_mode;
+  const float* bias;
+  int pconv, premask, postmask;
+  int ratio_taps, ratio_dil;
+  const float* add; int ldadd;
+  const float* dact_src; int lddact; int dact;
+  int rowscale;
+  int act;
+  float* C2; int ldc2; int c2_accum;
+} radmmm_rowgemm_desc;
+
+int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight-gradient GEMM (contraction over frames), fp32 MFMA:
+ *   P[split][tap][m][n] = sum_{r in split} GY[r, m] * Xm[r + shift(tap), n]
+ * m < Mc (out channels), n < Nc (in channels); Xm masked as in radmmm_rowgemm_f32.
+ * `splits` partial slabs are written (deterministic; the consumer sums them),
+ * P slab layout [taps][Mc][ldp].  Replaces conv weight-gradients of autograd
+ * (aten::convolution_backward) for common.py:816-835.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* GY; int ldgy;
+  const float* X; int ldx;
+  float* P; int ldp; int64_t split_stride;  /* floats between slabs */
+  int R;                 /* total rows (B*T) */
+  int Mc, Nc;
+  int taps, dil;
+  int T; const int32_t* lens; int x_mask_mode;
+  int splits;
+} radmmm_wgrad_desc;
+
+int radmmm_wgrad_f32(const radmmm_wgrad_desc* d, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight norm fold / unfold  (torch weight_norm dim=0; common.py:173-174,791,813)
+ *   forward : W[tap][co][col(ci)] = g[co] * v[co][ci][tap] / ||v[co]||_2 ,
+ *             inv_norm[co] = 1/||v[co]||
+ *             col(ci) = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi
+ *             (columns not hit by col() are left untouched: zero them once)
+ *   backward: from `splits` slabs of dL/dW (layout of W) -> dL/dv [co][ci][tap], dL/dg [co]
+ * v is in the reference's checkpoint layout [Cout][Cin][taps].
+ * ------------------------------------------------------------------------------------ */
+int radmmm_weightnorm_fwd(const float* v, const float* g, float* W, float* inv_norm,
+                          int Cout, int Cin, int taps, int ldw,
+                          int perm_split, int off_lo, int off_hi, radmmm_stream_t stream);
+int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
+                          const float* dW, int splits, int64_t split_stride,
+                          float* dv, float* dg,
+                          int Cout, int Cin, int taps, int ldw,
+                          int perm_split, int off_lo, int off_hi, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * WN input assembly (cat((z0, context), 1), common.py:819) in channels-last, K-padded:
+ *   X0[r, 0:D] = ctx[r, 0:D] ; X0[r, D:D+h] = z[r, 0:h] ; X0[r, D+h:ldx0] = 0
+ * and its gradient scatter:
+ *   gctx[r, 0:D] (+)= gX0[r, 0:D] ; gz[r, 0:h] += gX0[r, D:D+h]
+ * ------------------------------------------------------------------------------------ */
+int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz,
+                        float* X0, int ldx0, int rows, int D, int h, radmmm_stream_t stream);
+int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int ctx_accum,
+                        float* gz, int ldz, int rows, int D, int h, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Affine coupling (AffineTransformationLayer.forward, common.py:1163-1185):
+ *   su = O[r, 0:h], b = O[r, h:2h]; (s, log_s) = scaling(su)
+ *   zout[r, 0:h] = z[r, 0:h]; zout[r, h:2h] = s * z[r, h:2h] + b; zout[r, 2h:ldz] = z[...]
+ *   log_s[r, 0:h] stored with row stride h.
+ * backward: given gzout, glog_s (may be NULL), O, z:
+ *   gO[r, 0:h] = (gzout1 * z1 + glog_s * dlog_s/ds) * ds/dsu ; gO[r, h:2h] = gzout1
+ *   gz[r, 0:h] = gzout[r, 0:h]; gz[r, h:2h] = gzout1 * s ; gz[r, 2h:ldz] = gzout[...]
+ * ------------------------------------------------------------------------------------ */
+int radmmm_affine_coupling_fwd(const float* O, int ldo, const float* z, int ldz,
+                               float* zout, float* log_s, int rows, int h, int scaling,
+                               radmmm_stream_t stream);
+int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* z, int ldz,
+                               const float* gzout, const float* glog_s,
+                               float* gO, float* gz, int rows, int h, int scaling,
+                               radmmm_stream_t stream);
+
+/* y[r, c] = g[r, c] * act'(saved[r, c])  (derivative from the saved OUTPUT), c < cols */
+int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y, int ldy,
+                    int rows, int cols, int dact, radmmm_stream_t stream);
+
+/* out[c] = sum_r w(r) * X[r, c];  row_weight 0: 1 ; 1: [t < lens[b]] ; 2: (cnt+1e-6)/taps over
+ * valid rows (undoes the partial-conv ratio: bias gradient of PartialConv1d)          */
+int radmmm_colsum(const float* X, int ldx, float* out, float* scratch, int rows, int cols,
+                  int row_weight, int T, const int32_t* lens, int taps, int dil,
+                  radmmm_stream_t stream);
+int64_t radmmm_colsum_scratch_floats(int rows, int cols);
+
+/* ------------------------------------------------------------------------------------
+ * Flow NLL reductions (compute_flow_loss, loss.py:85-110) on arbitrary-stride
+ * [B, C, T] views:  mode 0: sum(x*m), mode 1: sum((x*m)^2);   m = [t < lens[b]].
+ * Deterministic two-stage reduction; `out` receives one float.
+ * backward (elementwise): gx[b,c,t] = coef[0] * m * (mode 1 ? 2*x : 1); gx uses x's strides
+ * ------------------------------------------------------------------------------------ */
+int radmmm_masked_reduce(const float* x, int B, int C, int T, int64_t sb, int64_t sc, int64_t st,
+                         const int32_t* lens, int mode, float* out, float* scratch,
+                         radmmm_stream_t stream);
+int64_t radmmm_masked_reduce_scratch_floats(int B, int C, int T);
+int radmmm_masked_reduce_bwd(const float* x, int B, int C, int T, int64_t sb, int64_t sc,
+                             int64_t st, const int32_t* lens, int mode, const float* coef,
+                             float* gx, radmmm_stream_t stream);
+
+/* fused_add_tanh_sigmoid_multiply (common.py:66-73): y[r, c] = tanh(a+b)[r, c] *
+ * sigmoid(a+b)[r, n + c], c < n.  Not on any config's path (WaveNetOriginal only). */
+int radmmm_fused_add_tanh_sigmoid_multiply(const float* a, const float* b, int ld, float* y,
+                                           int ldy, int rows, int n, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Piecewise-quadratic spline coupling transform (splines.py:241-339, forward branch)
+ * on x [rows, h] (already normalised to [0,1) by (z+bound)/(2 bound)), q [rows, h*(2K+1)]
+ * channels-last with channel index c*(2K+1)+j (first K: widths, last K+1: heights).
+ *   y [rows, h], logj_sum[0:rows] = sum_c logj; logj_sum must have room for rows + rows*h
+ *   floats (the tail receives the per-element log-jacobians the sums are reduced from)
+ * backward: gy [rows,h], glogj [rows] -> gx [rows,h], gq [rows, h*(2K+1)]
+ * ------------------------------------------------------------------------------------ */
+int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int ldq, float* y, int ldy,
+                         float* logj_sum, int rows, int h, int K, radmmm_stream_t stream);
+int radmmm_pq_spline_bwd(const float* x, int ldx, const float* q, int ldq, const float* gy,
+                         int ldgy, const float* glogj, float* gx, int ldgx, float* gq, int ldgq,
+                         int rows, int h, int K, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Alignment attention (ConvAttention.forward, common.py:1262-1277), from projected
+ * queries Q [B, T1, Ca] and keys Kx [B, T2, Ca] (channels-last):
+ *   d[b,t,s] = -temp * sum_c (Q[b,t,c]-K[b,s,c])^2
+ *   logprob = log_softmax_s(d) + log(prior + 1e-8)   (prior NULL: logprob = d)
+ *   attn = softmax_s(logprob masked to s < in_lens[b])
+ * outputs attn, logprob [B, T1, T2].  backward: gattn, glogprob -> gQ, gK.
+ * ------------------------------------------------------------------------------------ */
+int radmmm_attn_fwd(const float* Q, const float* Kx, const float* prior, const int32_t* in_lens,
+                    float* attn, float* logprob, int B, int T1, int T2, int Ca, float temp,
+                    radmmm_stream_t stream);
+int radmmm_attn_bwd(const float* Q, const float* Kx, const float* prior, const int32_t* in_lens,
+                    const float* attn, const float* logprob, const float* gattn,
+                    const float* glogprob, float* gQ, float* gK, float* gd_scratch /* B*T1*T2 */,
+                    int B, int T1, int T2, int Ca, float temp, radmmm_stream_t stream);
+
+/* Monotonic alignment search, width 1 (alignment.py:31-59; INTEGER/INDEX path, bit-exact
+ * given identical log inputs).  logp [B, T1, T2] = log(attn) (caller's log), per item the
+ * [out_lens[b], in_lens[b]] corner is aligned; hard [B, T1, T2] receives 0/1 (zeroed
+ * outside).  scratch: radmmm_mas_scratch_bytes(B, T1, T2). */
+int radmmm_mas_width1(const float* logp, const int32_t* in_lens, const int32_t* out_lens,
+                      float* hard, void* scratch, int B, int T1, int T2, radmmm_stream_t stream);
+int64_t radmmm_mas_scratch_bytes(int B, int T1, int T2);
+
+/* STFT magnitude -> mel -> log-clamp (audio_processing.py:137-154, 227-255).
+ * audio [B, S]; basis [2*(n_fft/2+1)][n_fft] windowed DFT rows (re then im);
+ * mel_basis [n_mel][n_fft/2+1]; out mel [B, n_mel, 1 + S/hop] (reference layout). */
+int radmmm_stft_mel(const float* audio, const float* basis, const float* mel_basis, float* mel,
+                    float* scratch, int B, int S, int n_fft, int hop, int n_mel,
+                    float clip, radmmm_stream_t stream);
+int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_mel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADMMM_HIP_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of libradmmm_hip.so (the C-ABI in include/radmmm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+compute call below goes through the C-ABI with raw device pointers.  There is NO CPU
+or eager fallback: if the shared library is missing the import of this module raises,
+and every op raises on a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradmmm_hip.so")
+
+ACT_NONE, ACT_SOFTPLUS, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
+SCALE = {"tanh": 0, "exp": 1, "sigmoid": 2, "translate": 3}
+ACT = {"none": 0, "softplus": 1, "relu": 2, "leaky_relu": 3}
+
+
+class RadmmmError(RuntimeError):
+    pass
+
+
+class RowGemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int),
+        ("a_item_stride", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int), ("b_tap_stride", C.c_int64), ("b_layout", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("taps", C.c_int), ("dil", C.c_int), ("sign", C.c_int),
+        ("T", C.c_int),
+        ("lens", C.c_void_p),
+        ("a_mask_mode", C.c_int),
+        ("bias", C.c_void_p),
+        ("pconv", C.c_int), ("premask", C.c_int), ("postmask", C.c_int),
+        ("ratio_taps", C.c_int), ("ratio_dil", C.c_int),
+        ("add", C.c_void_p), ("ldadd", C.c_int),
+        ("dact_src", C.c_void_p), ("lddact", C.c_int), ("dact", C.c_int),
+        ("rowscale", C.c_int),
+        ("act", C.c_int),
+        ("C2", C.c_void_p), ("ldc2", C.c_int), ("c2_accum", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("GY", C.c_void_p), ("ldgy", C.c_int),
+        ("X", C.c_void_p), ("ldx", C.c_int),
+        ("P", C.c_void_p), ("ldp", C.c_int), ("split_stride", C.c_int64),
+        ("R", C.c_int),
+        ("Mc", C.c_int), ("Nc", C.c_int),
+        ("taps", C.c_int), ("dil", C.c_int),
+        ("T", C.c_int), ("lens", C.c_void_p), ("x_mask_mode", C.c_int),
+        ("splits", C.c_int),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or rad_mmm_amd/csrc/build.sh (hipcc --offload-arch=gfx950). rad_mmm_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.radmmm_last_error.restype = C.c_char_p
+    lib.radmmm_abi_version.restype = C.c_int
+    if lib.radmmm_abi_version() != 1:
+        raise ImportError("libradmmm_hip.so ABI version mismatch")
+    i, i64, p = C.c_int, C.c_int64, C.c_void_p
+    f = C.c_float
+    sig = {
+        "radmmm_rowgemm_f32": [C.POINTER(RowGemmDesc), p],
+        "radmmm_wgrad_f32": [C.POINTER(WgradDesc), p],
+        "radmmm_weightnorm_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
+        "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p],
+        "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p],
+        "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
+        "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
+        "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
+        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, p],
+        "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, p],
+        "radmmm_masked_reduce": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
+        "radmmm_masked_reduce_bwd": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
+        "radmmm_fused_add_tanh_sigmoid_multiply": [p, p, i, p, i, i, i, p],
+        "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
+        "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
+        "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
+        "radmmm_attn_bwd": [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, f, p],
+        "radmmm_mas_width1": [p, p, p, p, p, i, i, i, p],
+        "radmmm_stft_mel": [p, p, p, p, p, i, i, i, i, i, f, p],
+    }
+    missing = [n for n in sig if not hasattr(lib, n)]
+    if missing:
+        raise ImportError(f"libradmmm_hip.so lacks symbols {missing}: rebuild it")
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, args in {"radmmm_colsum_scratch_floats": [i, i],
+                       "radmmm_masked_reduce_scratch_floats": [i, i, i],
+                       "radmmm_mas_scratch_bytes": [i, i, i],
+                       "radmmm_stft_mel_scratch_floats": [i, i, i, i, i]}.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int64
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RadmmmError(f"{what} failed ({rc}): {lib.radmmm_last_error().decode()}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RadmmmError("rad_mmm_amd ops need GPU tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """contiguous fp32 view/copy"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def rowgemm(**kw) -> None:
+    d = RowGemmDesc()
+    d.sign = 1
+    d.taps = 1
+    d.dil = 1
+    d.ratio_taps = 1
+    d.ratio_dil = 1
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = ptr(v)
+        setattr(d, k, v)
+    check(lib.radmmm_rowgemm_f32(C.byref(d), stream()), "radmmm_rowgemm_f32")
+
+
+def wgrad(**kw) -> None:
+    d = WgradDesc()
+    d.taps = 1
+    d.dil = 1
+    d.splits = 1
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = ptr(v)
+        setattr(d, k, v)
+    check(lib.radmmm_wgrad_f32(C.byref(d), stream()), "radmmm_wgrad_f32")

@@ -1,0 +1,92 @@
+// Shared helpers for libradmmm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/radmmm_hip.h"
+
+namespace radmmm {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+#define RADMMM_REQUIRE(cond, ...)      \
+  do {                                 \
+    if (!(cond)) {                     \
+      radmmm::set_error(__VA_ARGS__);  \
+      return -1;                       \
+    }                                  \
+  } while (0)
+
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- device helpers -------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) {
+  // torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case RADMMM_ACT_SOFTPLUS: return softplus_f(v);
+    case RADMMM_ACT_RELU: return v > 0.f ? v : 0.f;
+    case RADMMM_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+// derivative of the activation expressed from its OUTPUT y
+__device__ __forceinline__ float dact_from_out(float y, int act) {
+  switch (act) {
+    case RADMMM_ACT_SOFTPLUS: return y > 20.f ? 1.f : -expm1f(-y);  // sigmoid(x) = 1 - exp(-softplus(x))
+    case RADMMM_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case RADMMM_ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+// partial-conv renormalisation ratio for frame t of an item with `len` valid frames
+// (partialconv1d.py:75-81): taps/(cnt+1e-6) * clamp(cnt,0,1)
+__device__ __forceinline__ float pconv_ratio(int t, int len, int taps, int dil) {
+  int cnt = 0;
+  const int c = taps / 2;
+  for (int k = 0; k < taps; ++k) {
+    const int ts = t + (k - c) * dil;
+    cnt += (ts >= 0 && ts < len) ? 1 : 0;
+  }
+  return cnt > 0 ? (float)taps / ((float)cnt + 1e-6f) : 0.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in all threads
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 17 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (w == 0) {
+    float t = lane < nw ? sh[lane] : 0.f;
+    t = wave_sum(t);
+    if (lane == 0) sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+}  // namespace radmmm

@@ -1,0 +1,452 @@
+// HBM-bound kernels of the flow step: weight-norm fold/unfold, WN input assembly, affine
+// coupling, activation-derivative products, column sums (bias gradients) and the masked
+// NLL reductions.  All fp32, channels-last rows; every kernel keeps consecutive lanes on
+// consecutive addresses (coalesced 256 B per wave-instruction or float4 where the layout
+// allows) and reduces through wavefront shuffles (64 lanes) before touching LDS.
+#include "common.h"
+
+namespace {
+
+using radmmm::block_sum;
+using radmmm::wave_sum;
+
+__device__ __forceinline__ int perm_col(int ci, int perm_split, int off_lo, int off_hi) {
+  return ci < perm_split ? ci + off_lo : ci - perm_split + off_hi;
+}
+
+// ------------------------------------------------------------------ weight norm
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ W,
+    float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldw, int perm_split,
+    int off_lo, int off_hi) {
+  __shared__ float sh[17];
+  const int co = blockIdx.x;
+  const int n = Cin * taps;
+  const float* vr = v + (long long)co * n;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(vr[i], vr[i], ss);
+  ss = block_sum(ss, sh);
+  const float nrm = sqrtf(ss);
+  const float scale = g[co] / nrm;
+  if (threadIdx.x == 0) inv_norm[co] = 1.f / nrm;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ci = i / taps, k = i - ci * taps;
+    W[((long long)k * Cout + co) * ldw + perm_col(ci, perm_split, off_lo, off_hi)] = vr[i] * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
+    const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
+    float* __restrict__ dg, int Cout, int Cin, int taps, int ldw, int perm_split, int off_lo,
+    int off_hi) {
+  __shared__ float sh[17];
+  const int co = blockIdx.x;
+  const int n = Cin * taps;
+  const float* vr = v + (long long)co * n;
+  auto gw_at = [&](int i) {
+    const int ci = i / taps, k = i - ci * taps;
+    const long long off = ((long long)k * Cout + co) * ldw + perm_col(ci, perm_split, off_lo, off_hi);
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += dW[sp * split_stride + off];
+    return s;
+  };
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dot = fmaf(gw_at(i), vr[i], dot);
+  dot = block_sum(dot, sh);
+  const float inv = inv_norm[co], gg = g[co];
+  if (threadIdx.x == 0) dg[co] = dot * inv;
+  const float a = gg * inv, b = gg * dot * inv * inv * inv;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    dv[(long long)co * n + i] = a * gw_at(i) - b * vr[i];
+}
+
+// ------------------------------------------------------------------ WN input assembly
+__global__ __launch_bounds__(256) void wn_input_fwd_kernel(
+    const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz,
+    float* __restrict__ X0, int ldx0, int rows, int D, int h) {
+  const long long total = (long long)rows * ldx0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldx0), c = (int)(i - (long long)r * ldx0);
+    float v = 0.f;
+    if (c < D) v = ctx[(long long)r * ldctx + c];
+    else if (c < D + h) v = z[(long long)r * ldz + (c - D)];
+    X0[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_input_bwd_kernel(
+    const float* __restrict__ gX0, int ldx0, float* __restrict__ gctx, int ldctx, int ctx_accum,
+    float* __restrict__ gz, int ldz, int rows, int D, int h) {
+  const int W = D + h;
+  const long long total = (long long)rows * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / W), c = (int)(i - (long long)r * W);
+    const float v = gX0[(long long)r * ldx0 + c];
+    if (c < D) {
+      float* p = gctx + (long long)r * ldctx + c;
+      *p = ctx_accum ? *p + v : v;
+    } else {
+      gz[(long long)r * ldz + (c - D)] += v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ affine coupling
+__device__ __forceinline__ void scale_fwd(float su, int mode, float& s, float& ls) {
+  switch (mode) {
+    case RADMMM_SCALE_TANH: s = tanhf(su) + 1.f + 1e-6f; ls = logf(s); break;
+    case RADMMM_SCALE_EXP: s = expf(su); ls = su; break;
+    case RADMMM_SCALE_SIGMOID: s = 1.f / (1.f + expf(-(su + 10.f))) + 1e-6f; ls = logf(s); break;
+    default: s = 1.f; ls = 0.f; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_coupling_fwd_kernel(
+    const float* __restrict__ O, int ldo, const float* __restrict__ z, int ldz,
+    float* __restrict__ zout, float* __restrict__ log_s, int rows, int h, int mode) {
+  const long long total = (long long)rows * ldz;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldz), c = (int)(i - (long long)r * ldz);
+    float v = z[i];
+    if (c >= h && c < 2 * h) {
+      const float su = O[(long long)r * ldo + (c - h)], b = O[(long long)r * ldo + c];
+      float s, ls;
+      scale_fwd(su, mode, s, ls);
+      v = s * v + b;
+      log_s[(long long)r * h + (c - h)] = ls;
+    }
+    zout[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
+    const float* __restrict__ O, int ldo, const float* __restrict__ z, int ldz,
+    const float* __restrict__ gzout, const float* __restrict__ glog_s, float* __restrict__ gO,
+    float* __restrict__ gz, int rows, int h, int mode) {
+  const long long total = (long long)rows * ldz;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldz), c = (int)(i - (long long)r * ldz);
+    float gv = gzout[i];
+    if (c >= h && c < 2 * h) {
+      const float su = O[(long long)r * ldo + (c - h)];
+      const float z1 = z[i];
+      const float gl = glog_s ? glog_s[(long long)r * h + (c - h)] : 0.f;
+      float s, gsu;
+      switch (mode) {
+        case RADMMM_SCALE_TANH: {
+          const float th = tanhf(su);
+          s = th + 1.f + 1e-6f;
+          gsu = (gv * z1 + gl / s) * (1.f - th * th);
+        } break;
+        case RADMMM_SCALE_EXP: s = expf(su); gsu = gv * z1 * s + gl; break;
+        case RADMMM_SCALE_SIGMOID: {
+          const float sg = 1.f / (1.f + expf(-(su + 10.f)));
+          s = sg + 1e-6f;
+          gsu = (gv * z1 + gl / s) * sg * (1.f - sg);
+        } break;
+        default: s = 1.f; gsu = 0.f; break;
+      }
+      gO[(long long)r * ldo + (c - h)] = gsu;
+      gO[(long long)r * ldo + c] = gv;
+      gv = gv * s;
+    }
+    gz[i] = gv;
+  }
+}
+
+// ------------------------------------------------------------------ dact product
+__global__ __launch_bounds__(256) void dact_mul_kernel(
+    const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds,
+    float* __restrict__ y, int ldy, int rows, int cols, int dact) {
+  const int c4n = (cols + 3) / 4;
+  const long long total = (long long)rows * c4n;
+  const bool vec = (cols % 4 == 0) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldy % 4 == 0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n) * 4;
+    if (vec) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + (long long)r * ldg + c);
+      const float4 sv = *reinterpret_cast<const float4*>(saved + (long long)r * lds + c);
+      float4 o;
+      o.x = gv.x * radmmm::dact_from_out(sv.x, dact);
+      o.y = gv.y * radmmm::dact_from_out(sv.y, dact);
+      o.z = gv.z * radmmm::dact_from_out(sv.z, dact);
+      o.w = gv.w * radmmm::dact_from_out(sv.w, dact);
+      *reinterpret_cast<float4*>(y + (long long)r * ldy + c) = o;
+    } else {
+      for (int e = 0; e < 4 && c + e < cols; ++e)
+        y[(long long)r * ldy + c + e] =
+            g[(long long)r * ldg + c + e] * radmmm::dact_from_out(saved[(long long)r * lds + c + e], dact);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums
+constexpr int CS_ROWS_PER_BLOCK = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(
+    const float* __restrict__ X, int ldx, float* __restrict__ part, int rows, int cols,
+    int row_weight, int T, const int* __restrict__ lens, int taps, int dil) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * CS_ROWS_PER_BLOCK;
+  int r1 = r0 + CS_ROWS_PER_BLOCK;
+  if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  for (int r = r0 + rl; r < r1; r += 4) {
+    float w = 1.f;
+    if (row_weight) {
+      const int b = r / T, t = r - b * T;
+      const int len = lens ? lens[b] : T;
+      if (t >= len) w = 0.f;
+      else if (row_weight == 2) {
+        int cnt = 0;
+        for (int k = 0; k < taps; ++k) {
+          const int ts = t + (k - taps / 2) * dil;
+          cnt += (ts >= 0 && ts < len) ? 1 : 0;
+        }
+        w = ((float)cnt + 1e-6f) / (float)taps;
+      }
+    }
+    if (c < cols) acc = fmaf(w, X[(long long)r * ldx + c], acc);
+  }
+  sh[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    part[(long long)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ out, int nparts,
+                                                           int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long long)p * cols + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------ masked reductions
+constexpr int MR_BLOCKS = 512;
+__global__ __launch_bounds__(256) void masked_reduce_kernel(
+    const float* __restrict__ x, int B, int C, int T, long long sb, long long sc, long long st,
+    const int* __restrict__ lens, int mode, float* __restrict__ part) {
+  __shared__ float sh[17];
+  const long long total = (long long)B * C * T;
+  const bool c_inner = sc < st;  // iterate the stride-1 dim fastest
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int b, c, t;
+    if (c_inner) {
+      c = (int)(i % C);
+      const long long j = i / C;
+      t = (int)(j % T);
+      b = (int)(j / T);
+    } else {
+      t = (int)(i % T);
+      const long long j = i / T;
+      c = (int)(j % C);
+      b = (int)(j / C);
+    }
+    const int len = lens ? lens[b] : T;
+    if (t < len) {
+      const float v = x[b * sb + c * sc + t * st];
+      acc += mode ? v * v : v;
+    }
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ part, int n,
+                                                           float* __restrict__ out) {
+  __shared__ float sh[17];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void masked_reduce_bwd_kernel(
+    const float* __restrict__ x, int B, int C, int T, long long sb, long long sc, long long st,
+    const int* __restrict__ lens, int mode, const float* __restrict__ coef,
+    float* __restrict__ gx) {
+  // gx has the SAME strides as x (torch.empty_like of a dense, possibly permuted, view)
+  const long long total = (long long)B * C * T;
+  const bool c_inner = sc < st;
+  const float cf = coef[0];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int b, c, t;
+    if (c_inner) {
+      c = (int)(i % C);
+      const long long j = i / C;
+      t = (int)(j % T);
+      b = (int)(j / T);
+    } else {
+      t = (int)(i % T);
+      const long long j = i / T;
+      c = (int)(j % C);
+      b = (int)(j / C);
+    }
+    const int len = lens ? lens[b] : T;
+    const long long off = b * sb + c * sc + t * st;
+    float v = 0.f;
+    if (t < len) v = mode ? 2.f * cf * x[off] : cf;
+    gx[off] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void fatsm_kernel(const float* __restrict__ a,
+                                                    const float* __restrict__ b, int ld,
+                                                    float* __restrict__ y, int ldy, int rows, int n) {
+  const long long total = (long long)rows * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i - (long long)r * n);
+    const float t = a[(long long)r * ld + c] + b[(long long)r * ld + c];
+    const float s = a[(long long)r * ld + n + c] + b[(long long)r * ld + n + c];
+    y[(long long)r * ldy + c] = tanhf(t) * (1.f / (1.f + expf(-s)));
+  }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 256 * 8) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int radmmm_weightnorm_fwd(const float* v, const float* g, float* W, float* inv_norm,
+                                     int Cout, int Cin, int taps, int ldw, int perm_split,
+                                     int off_lo, int off_hi, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(v && g && W && inv_norm, "weightnorm_fwd: null pointer");
+  RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldw >= Cin, "weightnorm_fwd: bad dims");
+  hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, W, inv_norm,
+                     Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+  return radmmm::check_launch("weightnorm_fwd");
+}
+
+extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
+                                     const float* dW, int splits, int64_t split_stride, float* dv,
+                                     float* dg, int Cout, int Cin, int taps, int ldw,
+                                     int perm_split, int off_lo, int off_hi,
+                                     radmmm_stream_t stream) {
+  RADMMM_REQUIRE(v && g && inv_norm && dW && dv && dg, "weightnorm_bwd: null pointer");
+  RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldw >= Cin && splits >= 1, "weightnorm_bwd: bad dims");
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW,
+                     splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split,
+                     off_lo, off_hi);
+  return radmmm::check_launch("weightnorm_bwd");
+}
+
+extern "C" int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz, float* X0,
+                                   int ldx0, int rows, int D, int h, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(ctx && z && X0, "wn_input_fwd: null pointer");
+  RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_fwd: bad dims");
+  hipLaunchKernelGGL(wn_input_fwd_kernel, dim3(grid_for((long long)rows * ldx0)), dim3(256), 0,
+                     ST(stream), ctx, ldctx, z, ldz, X0, ldx0, rows, D, h);
+  return radmmm::check_launch("wn_input_fwd");
+}
+
+extern "C" int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int ctx_accum,
+                                   float* gz, int ldz, int rows, int D, int h,
+                                   radmmm_stream_t stream) {
+  RADMMM_REQUIRE(gX0 && gctx && gz, "wn_input_bwd: null pointer");
+  RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_bwd: bad dims");
+  hipLaunchKernelGGL(wn_input_bwd_kernel, dim3(grid_for((long long)rows * (D + h))), dim3(256), 0,
+                     ST(stream), gX0, ldx0, gctx, ldctx, ctx_accum, gz, ldz, rows, D, h);
+  return radmmm::check_launch("wn_input_bwd");
+}
+
+extern "C" int radmmm_affine_coupling_fwd(const float* O, int ldo, const float* z, int ldz,
+                                          float* zout, float* log_s, int rows, int h, int scaling,
+                                          radmmm_stream_t stream) {
+  RADMMM_REQUIRE(O && z && zout && log_s, "affine_coupling_fwd: null pointer");
+  RADMMM_REQUIRE(rows > 0 && h > 0 && ldo >= 2 * h && ldz >= 2 * h, "affine_coupling_fwd: bad dims");
+  hipLaunchKernelGGL(affine_coupling_fwd_kernel, dim3(grid_for((long long)rows * ldz)), dim3(256), 0,
+                     ST(stream), O, ldo, z, ldz, zout, log_s, rows, h, scaling);
+  return radmmm::check_launch("affine_coupling_fwd");
+}
+
+extern "C" int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* z, int ldz,
+                                          const float* gzout, const float* glog_s, float* gO,
+                                          float* gz, int rows, int h, int scaling,
+                                          radmmm_stream_t stream) {
+  RADMMM_REQUIRE(O && z && gzout && gO && gz, "affine_coupling_bwd: null pointer");
+  RADMMM_REQUIRE(rows > 0 && h > 0 && ldo >= 2 * h && ldz >= 2 * h, "affine_coupling_bwd: bad dims");
+  hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(grid_for((long long)rows * ldz)), dim3(256), 0,
+                     ST(stream), O, ldo, z, ldz, gzout, glog_s, gO, gz, rows, h, scaling);
+  return radmmm::check_launch("affine_coupling_bwd");
+}
+
+extern "C" int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y,
+                               int ldy, int rows, int cols, int dact, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(g && saved && y, "dact_mul: null pointer");
+  RADMMM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && lds >= cols && ldy >= cols, "dact_mul: bad dims");
+  hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for((long long)rows * ((cols + 3) / 4))), dim3(256), 0,
+                     ST(stream), g, ldg, saved, lds, y, ldy, rows, cols, dact);
+  return radmmm::check_launch("dact_mul");
+}
+
+extern "C" int64_t radmmm_colsum_scratch_floats(int rows, int cols) {
+  const int64_t nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  return nparts * cols;
+}
+
+extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch, int rows, int cols,
+                             int row_weight, int T, const int32_t* lens, int taps, int dil,
+                             radmmm_stream_t stream) {
+  RADMMM_REQUIRE(X && out && scratch, "colsum: null pointer");
+  RADMMM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, "colsum: bad dims");
+  RADMMM_REQUIRE(row_weight == 0 || (T > 0 && rows % T == 0), "colsum: rows must be a multiple of T");
+  RADMMM_REQUIRE(row_weight != 2 || (taps >= 1 && dil >= 1), "colsum: taps/dil");
+  const int nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts), dim3(256), 0, ST(stream),
+                     X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), scratch,
+                     out, nparts, cols);
+  return radmmm::check_launch("colsum");
+}
+
+extern "C" int64_t radmmm_masked_reduce_scratch_floats(int, int, int) { return MR_BLOCKS; }
+
+extern "C" int radmmm_masked_reduce(const float* x, int B, int C, int T, int64_t sb, int64_t sc,
+                                    int64_t st, const int32_t* lens, int mode, float* out,
+                                    float* scratch, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(x && out && scratch, "masked_reduce: null pointer");
+  RADMMM_REQUIRE(B > 0 && C > 0 && T > 0, "masked_reduce: bad dims");
+  const int nb = grid_for((long long)B * C * T, 256, MR_BLOCKS);
+  hipLaunchKernelGGL(masked_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), x, B, C, T,
+                     (long long)sb, (long long)sc, (long long)st, lens, mode, scratch);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, ST(stream), scratch, nb, out);
+  return radmmm::check_launch("masked_reduce");
+}
+
+extern "C" int radmmm_masked_reduce_bwd(const float* x, int B, int C, int T, int64_t sb, int64_t sc,
+                                        int64_t st, const int32_t* lens, int mode, const float* coef,
+                                        float* gx, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(coef && gx && (x || mode == 0), "masked_reduce_bwd: null pointer");
+  RADMMM_REQUIRE(B > 0 && C > 0 && T > 0, "masked_reduce_bwd: bad dims");
+  hipLaunchKernelGGL(masked_reduce_bwd_kernel, dim3(grid_for((long long)B * C * T)), dim3(256), 0,
+                     ST(stream), x, B, C, T, (long long)sb, (long long)sc, (long long)st, lens, mode,
+                     coef, gx);
+  return radmmm::check_launch("masked_reduce_bwd");
+}
+
+extern "C" int radmmm_fused_add_tanh_sigmoid_multiply(const float* a, const float* b, int ld, float* y,
+                                                      int ldy, int rows, int n,
+                                                      radmmm_stream_t stream) {
+  RADMMM_REQUIRE(a && b && y, "fused_add_tanh_sigmoid_multiply: null pointer");
+  RADMMM_REQUIRE(rows > 0 && n > 0 && ld >= 2 * n && ldy >= n, "fused_add_tanh_sigmoid_multiply: bad dims");
+  hipLaunchKernelGGL(fatsm_kernel, dim3(grid_for((long long)rows * n)), dim3(256), 0, ST(stream), a, b,
+                     ld, y, ldy, rows, n);
+  return radmmm::check_launch("fused_add_tanh_sigmoid_multiply");
+}

@@ -1,0 +1,241 @@
+"""MI355X-native drop-in for the reference's flow decoder (reference: decoders.py,
+models/radmmm.py).
+
+`RADMMMFlow` keeps the reference's constructor keywords, `forward` signature, output
+dictionary, attributes read by callers (`n_group_size`, `decoder_cond_dims`) and
+state_dict names/shapes, so a config selects it by changing
+`model.decoder.class_path: decoders.RADMMMFlow` to `rad_mmm_amd.decoders.RADMMMFlow`
+(configs/RADTTS_model_config.yaml:16-39).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .common import (AffineTransformationLayer, DataInitializedInvertible1x1Conv,
+                     Invertible1x1ConvLUS, SequenceLength)
+
+ZLD = ops.ZLD
+
+
+class FlowStep(nn.Module):
+    """One flow step = invertible 1x1 conv + coupling (reference decoders.py:36-80)."""
+
+    def __init__(self, n_mel_channels, n_context_dim, n_layers, affine_model="simple_conv",
+                 scaling_fn="exp", mode="LUS", affine_activation="softplus",
+                 use_partial_padding=False, cache_inverse=False, use_spline=False, use_bn=True):
+        super().__init__()
+        assert mode in {"LUS", "whiten"}
+        self.n_mel_channels = n_mel_channels
+        if mode == "LUS":
+            self.invtbl_conv = Invertible1x1ConvLUS(n_mel_channels, cache_inverse=cache_inverse)
+        else:
+            self.invtbl_conv = DataInitializedInvertible1x1Conv(n_mel_channels, cache_inverse=cache_inverse)
+        self.use_spline = use_spline
+        if use_spline:
+            from .spline_layers import SplineTransformationLayer
+            self.coupling_tfn = SplineTransformationLayer(
+                n_mel_channels, n_context_dim, n_layers, scaling_fn=scaling_fn, top=3, bottom=-3, left=-3,
+                right=3, n_bins=32, use_quadratic=True, use_bn=use_bn)
+        else:
+            self.coupling_tfn = AffineTransformationLayer(
+                n_mel_channels, n_context_dim, n_layers, affine_model=affine_model, scaling_fn=scaling_fn,
+                affine_activation=affine_activation, use_partial_padding=use_partial_padding)
+
+    def enable_inverse_cache(self):
+        self.invtbl_conv.cache_inverse = True
+
+    def effective_weight(self, col_offset: int):
+        """[ZLD, ZLD] zero-padded channel-mix matrix reading input columns
+        [col_offset, col_offset + C) (an early exit is a column offset, decoders.py:186-189),
+        and the bias -W mean of the whitening layer (common.py:613)."""
+        C = self.n_mel_channels
+        W = self.invtbl_conv.weight()
+        W_eff = F.pad(W, (col_offset, ZLD - col_offset - C, 0, ZLD - C))
+        mean = self.invtbl_conv.mean()
+        if mean is None:
+            b_eff = torch.zeros(ZLD, device=W.device, dtype=W.dtype)
+        else:
+            b_eff = F.pad(-(W @ mean).squeeze(1), (0, ZLD - C))
+        return W_eff.contiguous(), b_eff.contiguous()
+
+    def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset):
+        conv = self.invtbl_conv
+        if isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not bool(conv.initialized):
+            conv.initialize(z_cl[:, col_offset:], seq_lens, T)
+            print("initialized invertible conv")
+        W_eff, b_eff = self.effective_weight(col_offset)
+        log_det_W = conv.log_det()
+        z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T)
+        return z_out, log_det_W, log_s
+
+
+class RADMMMFlow(nn.Module):
+    """Reference decoders.py:82-248 (+ base class models/radmmm.py:29-167)."""
+
+    def __init__(self, n_speaker_dim=16, use_accent=True, n_accent_dim=1, n_text_dim=512, n_group_size=1,
+                 n_mel_channels=80, use_spk_emb_for_alignment=False, n_f0_dims=1, n_energy_avg_dims=1,
+                 context_w_f0_and_energy=True, use_context_lstm=True, context_lstm_norm: Optional[str] = None,
+                 n_flows=8, n_conv_layers_per_step=4, n_early_size=2, n_early_every=2,
+                 affine_model: str = "wavenet", scaling_fn: str = "tanh", affine_activation: str = "softplus",
+                 use_partial_padding=True, n_splines=0, use_bn=True, freeze_whitening_layer=False,
+                 use_accent_emb_for_decoder=False):
+        super().__init__()
+        assert n_speaker_dim % 2 == 0 and n_early_size % 2 == 0
+        if n_mel_channels * n_group_size != ZLD and n_mel_channels * n_group_size > ZLD:
+            raise ValueError(f"n_mel_channels*n_group_size must be <= {ZLD}")
+        # ---- models/radmmm.py:30-101
+        self.n_speaker_dim = n_speaker_dim
+        self.n_accent_dim = n_accent_dim
+        self.n_mel_channels = n_mel_channels
+        self.n_f0_dims = n_f0_dims
+        self.n_energy_avg_dims = n_energy_avg_dims
+        self.context_w_f0_and_energy = context_w_f0_and_energy
+        self.n_group_size = n_group_size
+        self.use_accent = bool(use_accent)
+        self.use_accent_emb_for_decoder = bool(use_accent_emb_for_decoder)
+        self.use_context_lstm = use_context_lstm
+        if self.use_accent:
+            assert n_accent_dim % 2 == 0
+        n_in = (n_f0_dims + n_energy_avg_dims + n_text_dim) * n_group_size + n_speaker_dim
+        n_hidden_src = n_speaker_dim + n_text_dim * n_group_size
+        if self.use_accent_emb_for_decoder:
+            n_in += n_accent_dim
+            n_hidden_src += n_accent_dim
+        if use_context_lstm:
+            n_hidden = int(n_hidden_src / 2)
+            self.context_lstm = nn.LSTM(input_size=n_in, hidden_size=n_hidden, num_layers=1, batch_first=True,
+                                        bidirectional=True)
+            if context_lstm_norm is not None:
+                fn = nn.utils.spectral_norm if "spectral" in context_lstm_norm else nn.utils.weight_norm
+                self.context_lstm = fn(self.context_lstm, "weight_hh_l0")
+                self.context_lstm = fn(self.context_lstm, "weight_hh_l0_reverse")
+            decoder_cond_dims = n_hidden * 2
+        else:
+            if not self.use_accent_emb_for_decoder:
+                raise ValueError("use_context_lstm=False needs use_accent_emb_for_decoder (as in the reference)")
+            decoder_cond_dims = n_speaker_dim + n_accent_dim + (n_text_dim + n_f0_dims + n_energy_avg_dims) * n_group_size
+        self.decoder_cond_dims = decoder_cond_dims
+        self.decoder_out_dims = n_mel_channels
+        # ---- decoders.py:105-143
+        self.matrix_decomposition = "LUS"
+        self.use_partial_padding = use_partial_padding
+        self.affine_activation = affine_activation
+        self.freeze_whitening_layer = freeze_whitening_layer
+        self.n_flows = n_flows
+        self.n_early_size = n_early_size
+        self.exit_steps = []
+        self.flows = nn.ModuleList()
+        c = n_mel_channels * n_group_size
+        for i in range(n_flows):
+            if i > 0 and i % n_early_every == 0:
+                c -= n_early_size
+                self.exit_steps.append(i)
+            self.flows.append(FlowStep(
+                c, decoder_cond_dims, n_conv_layers_per_step, affine_model, scaling_fn,
+                "whiten" if i == 0 else "LUS", affine_activation=affine_activation,
+                use_partial_padding=use_partial_padding, use_spline=i < n_splines, use_bn=use_bn))
+        if freeze_whitening_layer:
+            for p in self.flows[0].invtbl_conv.parameters():
+                p.requires_grad = False
+
+    # ------------------------------------------------------------------ helpers
+    def is_attribute_unconditional(self):
+        return self.n_f0_dims == 0 and self.n_energy_avg_dims == 0
+
+    def enable_inverse_cache(self):
+        for f in self.flows:
+            f.enable_inverse_cache()
+
+    def remove_norms(self):
+        raise NotImplementedError("inference-only helper; out of scope (SURVEY.md §8f4)")
+
+    def infer(self, *a, **k):
+        raise NotImplementedError("decoder.infer (inverse flows) is out of scope for this path (SURVEY.md §3.5)")
+
+    def _squeeze_cl(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, C, T] -> channels-last grouped [B, T//g, C*g] with channel c*g+k
+        (nn.Unfold order, decoders.py:118-122; models/radmmm.py:114-120)."""
+        g = self.n_group_size
+        B, C, T = x.shape
+        Tg = T // g
+        return x[:, :, : Tg * g].reshape(B, C, Tg, g).permute(0, 2, 1, 3).reshape(B, Tg, C * g)
+
+    def preprocess_context_cl(self, context, spk_vecs, seq_lens: SequenceLength, f0=None, energy_avg=None,
+                              accent_vecs=None):
+        """models/radmmm.py:103-148, producing channels-last [B, T', D]."""
+        g = self.n_group_size
+        ctx = self._squeeze_cl(context)
+        B, Tg, _ = ctx.shape
+        parts = [ctx, spk_vecs[:, None, :].expand(-1, Tg, -1)]
+        if self.use_accent_emb_for_decoder:
+            assert accent_vecs is not None
+            parts.append(accent_vecs[:, None, :].expand(-1, Tg, -1))
+        if self.context_w_f0_and_energy:
+            if f0 is not None:
+                parts.append(self._squeeze_cl(f0[:, None]))
+            if energy_avg is not None:
+                parts.append(self._squeeze_cl(energy_avg[:, None]))
+        x = torch.cat(parts, 2)
+        if not self.use_context_lstm:
+            return x.contiguous()
+        ul = torch.div(seq_lens.lengths_host, g, rounding_mode="floor")
+        self.context_lstm.flatten_parameters()
+        if int(ul.min()) == Tg:                       # fixed-length batch: packing is the identity
+            y, _ = self.context_lstm(x)
+        else:
+            packed = nn.utils.rnn.pack_padded_sequence(x, ul, batch_first=True, enforce_sorted=False)
+            out, _ = self.context_lstm(packed)
+            y, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=Tg)
+        return y.contiguous()
+
+    def preprocess_context(self, context, spk_vecs, out_lens=None, f0=None, energy_avg=None, accent_vecs=None):
+        """Reference-layout wrapper: returns [B, D, T']."""
+        sl = out_lens if isinstance(out_lens, SequenceLength) else SequenceLength(out_lens)
+        return self.preprocess_context_cl(context, spk_vecs, sl, f0, energy_avg, accent_vecs).transpose(1, 2)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, mel, spk_vecs, context, out_lens: SequenceLength, f0=None, energy_avg=None,
+                accent_vecs=None):
+        """mel [B, n_mel, T], spk_vecs [B, n_spk], context [B, n_text, T], out_lens SequenceLength,
+        f0/energy_avg [B, T], accent_vecs [B, n_accent]  ->  dict(z_mel [B, n_mel*g, T'],
+        log_det_W_list, log_s_list [B, C_i/2, T'], context_w_spkvec [B, D, T'])  (decoders.py:168-205)."""
+        if not mel.is_cuda:
+            raise RuntimeError("rad_mmm_amd.decoders.RADMMMFlow runs on an MI355X only (no CPU path)")
+        g = self.n_group_size
+        cond = self.preprocess_context_cl(context.float(), spk_vecs.float(), out_lens, f0, energy_avg, accent_vecs)
+        B, Tg, D = cond.shape
+        z3 = self._squeeze_cl(mel.float())                       # [B, T', C0]
+        C0 = z3.shape[2]
+        z = F.pad(z3, (0, ZLD - C0)).reshape(B * Tg, ZLD).contiguous() if C0 != ZLD else z3.reshape(B * Tg, ZLD).contiguous()
+        cond2 = cond.reshape(B * Tg, D)
+        lens32 = torch.div(out_lens.lengths, g, rounding_mode="floor").to(torch.int32)
+        unfolded = _UnfoldedLens(out_lens, g, Tg)
+
+        z_out, log_s_list, log_det_W_list = [], [], []
+        for i, flow in enumerate(self.flows):
+            off = 0
+            if i in self.exit_steps:
+                z_out.append(z[:, : self.n_early_size])
+                off = self.n_early_size
+            z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off)
+            log_s_list.append(log_s.view(B, Tg, -1).transpose(1, 2))
+            log_det_W_list.append(log_det_W)
+        z_out.append(z[:, : self.flows[-1].n_mel_channels])
+        z_mel = torch.cat([t.reshape(B, Tg, -1) for t in z_out], 2).transpose(1, 2).contiguous()
+        return {"z_mel": z_mel, "log_det_W_list": log_det_W_list, "log_s_list": log_s_list,
+                "context_w_spkvec": cond.transpose(1, 2)}
+
+
+class _UnfoldedLens:
+    """SequenceLength(lengths // g) without another host sync (decoders.py:182)."""
+
+    def __init__(self, sl: SequenceLength, g: int, Tg: int):
+        self.lengths = torch.div(sl.lengths, g, rounding_mode="floor")
+        self.lengths_host = torch.div(sl.lengths_host, g, rounding_mode="floor")
+        ids = torch.arange(0, Tg, device=self.lengths.device)
+        self.mask = ids < self.lengths.unsqueeze(1)

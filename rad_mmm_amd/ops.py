@@ -1,0 +1,283 @@
+"""Host-side operators over the C-ABI: allocation + launch sequencing + autograd wiring.
+
+Every numeric step is a kernel of libradmmm_hip.so; torch supplies memory, streams and
+the autograd graph.  Internal activation layout is channels-last ([B*T, ld] fp32), see
+DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad
+
+ZLD = 160            # row pitch of every flow-variable matrix (n_mel*group padded, see decoders.py)
+
+
+def _empty(*shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pick_splits(tiles: int, rows: int) -> int:
+    """split-K factor for the weight-gradient GEMM: aim for >= 2 workgroups per CU."""
+    s = max(1, min(64, -(-512 // max(tiles, 1))))
+    return max(1, min(s, rows // 32 if rows >= 32 else 1))
+
+
+# ---------------------------------------------------------------------------------------
+# thin launch helpers
+# ---------------------------------------------------------------------------------------
+def weightnorm_fwd(v: torch.Tensor, g: torch.Tensor, ldw: Optional[int] = None,
+                   perm: Tuple[int, int, int] = (0, 0, 0)) -> Tuple[torch.Tensor, torch.Tensor]:
+    """v [Cout, Cin, taps] (checkpoint layout) -> W [taps, Cout, ldw], inv_norm [Cout]."""
+    Cout, Cin, taps = v.shape
+    ldw = ldw or round_up(Cin, 4)
+    W = (torch.zeros if ldw != Cin else torch.empty)(taps, Cout, ldw, device=v.device, dtype=torch.float32)
+    inv = _empty(Cout, like=v)
+    check(lib.radmmm_weightnorm_fwd(ptr(v), ptr(g), ptr(W), ptr(inv), Cout, Cin, taps, ldw,
+                                    perm[0], perm[1], perm[2], stream()), "weightnorm_fwd")
+    return W, inv
+
+
+def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0)):
+    """dW_slabs [S, taps, Cout, ldw] -> (dv like v, dg like g)."""
+    Cout, Cin, taps = v.shape
+    S = dW_slabs.shape[0]
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g)
+    check(lib.radmmm_weightnorm_bwd(ptr(v), ptr(g), ptr(inv), ptr(dW_slabs), S,
+                                    dW_slabs.stride(0), ptr(dv), ptr(dg), Cout, Cin, taps, ldw,
+                                    perm[0], perm[1], perm[2], stream()), "weightnorm_bwd")
+    return dv, dg
+
+
+def colsum(X: torch.Tensor, cols: int, row_weight: int = 0, T: int = 1,
+           lens: Optional[torch.Tensor] = None, taps: int = 1, dil: int = 1) -> torch.Tensor:
+    rows, ld = X.shape
+    out = _empty(cols, like=X)
+    scratch = _empty(int(lib.radmmm_colsum_scratch_floats(rows, cols)), like=X)
+    check(lib.radmmm_colsum(ptr(X), ld, ptr(out), ptr(scratch), rows, cols, row_weight, T,
+                            ptr(lens), taps, dil, stream()), "colsum")
+    return out
+
+
+def wgrad_slabs(GY: torch.Tensor, Mc: int, X: torch.Tensor, Nc: int, ldp: int, T: int,
+                lens: Optional[torch.Tensor], taps: int = 1, dil: int = 1,
+                x_mask_mode: int = 0) -> torch.Tensor:
+    R = GY.shape[0]
+    tiles = -(-Mc // 128) * -(-Nc // 128) * taps
+    S = pick_splits(tiles, R)
+    P = torch.empty(S, taps, Mc, ldp, device=GY.device, dtype=torch.float32)
+    if ldp != Nc:
+        P.zero_()
+    wgrad(GY=GY, ldgy=GY.shape[1], X=X, ldx=X.shape[1], P=P, ldp=ldp, split_stride=P.stride(0),
+          R=R, Mc=Mc, Nc=Nc, taps=taps, dil=dil, T=T, lens=lens, x_mask_mode=x_mask_mode, splits=S)
+    return P
+
+
+# ---------------------------------------------------------------------------------------
+# affine flow step: invertible 1x1 channel mix + WN + affine coupling, one autograd node
+# ---------------------------------------------------------------------------------------
+class AffineFlowStepFn(torch.autograd.Function):
+    """FlowStep.forward of the reference (decoders.py:72-80) for the affine/WN coupling.
+
+    inputs : z_in [N, ZLD], ctx [N, D], lens (int32 [B]) , W_eff [ZLD, ZLD], b_eff [ZLD],
+             start_v/g/b, end_w/b, then L x (in_v, in_g, in_b), L x (res_v, res_g, res_b)
+    outputs: z_out [N, ZLD], log_s [N, h]
+    """
+
+    @staticmethod
+    def forward(ctx, meta, z_in, cond, lens, W_eff, b_eff, start_v, start_g, start_b, end_w, end_b,
+                *layer_params):
+        B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
+        act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
+        h = C // 2
+        N = B * T
+        Wc = start_v.shape[0]                       # WN width (1024)
+        Kp = round_up(D + h, 32)
+        in_p = layer_params[: 3 * nl]
+        res_p = layer_params[3 * nl:]
+        assert z_in.shape == (N, ZLD) and cond.shape == (N, D) and z_in.is_contiguous() and cond.is_contiguous()
+
+        # 1. invertible 1x1 (common.py:546 / :613-615): z1 = z_in @ W_eff^T + b_eff
+        z1 = _empty(N, ZLD, like=z_in)
+        rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T,
+                bias=b_eff)
+        # 2. WN input cat((z0, context)) (common.py:819), K-padded
+        X0 = _empty(N, Kp, like=z_in)
+        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, stream()), "wn_input_fwd")
+        # 3. weight-norm fold (common.py:791,813,174)
+        perm = (h, D, 0)                             # ref cols [z0 | ctx] -> packed [ctx | z0 | 0]
+        Ws, inv_s = weightnorm_fwd(start_v, start_g, Kp, perm)
+        Wi, inv_i, Wr, inv_r = [], [], [], []
+        for j in range(nl):
+            w, iv = weightnorm_fwd(in_p[3 * j], in_p[3 * j + 1])
+            Wi.append(w); inv_i.append(iv)
+            w, iv = weightnorm_fwd(res_p[3 * j], res_p[3 * j + 1])
+            Wr.append(w); inv_r.append(iv)
+        # 4. start conv
+        H = [_empty(N, Wc, like=z_in)]
+        rowgemm(A=X0, lda=Kp, B=Ws, ldb=Kp, b_layout=0, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp, T=T, bias=start_b)
+        # 5. dilated partial convs + res/skip 1x1 (common.py:829-832)
+        OUT = _empty(N, Wc, like=z_in)
+        R = []
+        for j in range(nl):
+            d = 2 ** j
+            Hn = _empty(N, Wc, like=z_in)
+            kt = in_p[3 * j].shape[2]
+            rowgemm(A=H[j], lda=Wc, B=Wi[j], ldb=Wc, b_tap_stride=Wi[j].stride(0), b_layout=0, C=Hn, ldc=Wc,
+                    M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, T=T, lens=lens,
+                    a_mask_mode=1 if partial else 0, bias=in_p[3 * j + 2], pconv=1 if partial else 0,
+                    ratio_taps=kt, ratio_dil=d, postmask=1, act=act)
+            H.append(Hn)
+            Rj = _empty(N, Wc, like=z_in)
+            rowgemm(A=Hn, lda=Wc, B=Wr[j], ldb=Wc, b_layout=0, C=Rj, ldc=Wc, M=N, N=Wc, K=Wc, T=T,
+                    bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0)
+            R.append(Rj)
+        # 6. end conv (plain, zero-init in the reference: common.py:799-802)
+        O = _empty(N, ZLD, like=z_in)
+        end_w2 = end_w.view(C, Wc)
+        rowgemm(A=OUT, lda=Wc, B=end_w2, ldb=Wc, b_layout=0, C=O, ldc=ZLD, M=N, N=C, K=Wc, T=T, bias=end_b)
+        # 7. affine coupling (common.py:1174-1185)
+        z_out = _empty(N, ZLD, like=z_in)
+        log_s = _empty(N, h, like=z_in)
+        check(lib.radmmm_affine_coupling_fwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(z_out), ptr(log_s), N, h, scaling,
+                                             stream()), "affine_coupling_fwd")
+        ctx.meta = meta
+        ctx.nl = nl
+        ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Ws, inv_s,
+                              *H, *R, *Wi, *inv_i, *Wr, *inv_r, *layer_params)
+        return z_out, log_s
+
+    @staticmethod
+    def backward(ctx, g_zout, g_logs):
+        meta, nl = ctx.meta, ctx.nl
+        B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
+        act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
+        sv = ctx.saved_tensors
+        z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Ws, inv_s = sv[:12]
+        p = 12
+        H = sv[p: p + nl + 1]; p += nl + 1
+        R = sv[p: p + nl]; p += nl
+        Wi = sv[p: p + nl]; p += nl
+        inv_i = sv[p: p + nl]; p += nl
+        Wr = sv[p: p + nl]; p += nl
+        inv_r = sv[p: p + nl]; p += nl
+        layer_params = sv[p:]
+        in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
+        h = C // 2
+        N = B * T
+        Wc = start_v.shape[0]
+        Kp = X0.shape[1]
+        g_zout = g_zout.contiguous()
+        if g_logs is not None:
+            g_logs = g_logs.contiguous()
+
+        # coupling
+        gO = _empty(N, ZLD, like=z_in)
+        gz1 = _empty(N, ZLD, like=z_in)
+        check(lib.radmmm_affine_coupling_bwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(g_zout), ptr(g_logs), ptr(gO), ptr(gz1),
+                                             N, h, scaling, stream()), "affine_coupling_bwd")
+        # end conv
+        g_end_b = colsum(gO, C)
+        g_end_w = wgrad_slabs(gO, C, OUT, Wc, Wc, T, None).sum(0).view(C, Wc, 1)
+        gOUT = _empty(N, Wc, like=z_in)
+        rowgemm(A=gO, lda=ZLD, B=end_w.view(C, Wc), ldb=Wc, b_layout=1, C=gOUT, ldc=Wc, M=N, N=Wc, K=C, T=T)
+        g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
+        g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
+        G = None
+        gQ = _empty(N, Wc, like=z_in)
+        for j in range(nl - 1, -1, -1):
+            d = 2 ** j
+            kt = in_p[3 * j].shape[2]
+            # through softplus of the res/skip branch
+            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, stream()), "dact_mul")
+            g_res[3 * j + 2] = colsum(gQ, Wc)
+            slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
+            g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
+            # dL/dconv_j = (gQ @ Wres + dL/dH_{j+1} via in_layer j+1) * softplus'(H_{j+1}) * mask * ratio_j
+            g_conv = _empty(N, Wc, like=z_in)
+            rowgemm(A=gQ, lda=Wc, B=Wr[j], ldb=Wc, b_layout=1, C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, T=T,
+                    lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
+                    rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d)
+            g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
+            slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d,
+                                x_mask_mode=1 if partial else 0)
+            g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
+            G = _empty(N, Wc, like=z_in)
+            rowgemm(A=g_conv, lda=Wc, B=Wi[j], ldb=Wc, b_tap_stride=Wi[j].stride(0), b_layout=1, C=G, ldc=Wc,
+                    M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens, a_mask_mode=0,
+                    premask=1 if partial else 0)
+        # start conv: G is dL/dH_0
+        g_start_b = colsum(G, Wc)
+        perm = (h, D, 0)
+        slabs = wgrad_slabs(G, Wc, X0, Kp, Kp, T, None)
+        g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
+        gX0 = _empty(N, Kp, like=z_in)
+        rowgemm(A=G, lda=Wc, B=Ws, ldb=Kp, b_layout=1, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc, T=T)
+        g_cond = _empty(N, D, like=z_in)
+        check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
+        # invertible 1x1
+        g_b_eff = colsum(gz1, ZLD)
+        g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
+        g_zin = _empty(N, ZLD, like=z_in)
+        rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
+        return (None, g_zin, g_cond, None, g_W_eff, g_b_eff, g_start_v, g_start_g, g_start_b, g_end_w, g_end_b,
+                *g_in, *g_res)
+
+
+# ---------------------------------------------------------------------------------------
+# masked reductions for the flow NLL (loss.py:85-110)
+# ---------------------------------------------------------------------------------------
+class MaskedReduceFn(torch.autograd.Function):
+    """sum over [B,C,T] of x*m (mode 0) or (x*m)^2 (mode 1), m = [t < lens[b]]; x may be any
+    dense (permuted) view."""
+
+    @staticmethod
+    def forward(ctx, x, lens, mode):
+        assert x.dim() == 3 and x.dtype == torch.float32
+        B, C, T = x.shape
+        out = _empty(1, like=x)
+        scratch = _empty(int(lib.radmmm_masked_reduce_scratch_floats(B, C, T)), like=x)
+        sb, sc, st = x.stride()
+        check(lib.radmmm_masked_reduce(ptr(x), B, C, T, sb, sc, st, ptr(lens), mode, ptr(out), ptr(scratch),
+                                       stream()), "masked_reduce")
+        ctx.save_for_backward(x, lens)
+        ctx.mode = mode
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lens = ctx.saved_tensors
+        B, C, T = x.shape
+        gx = torch.empty_like(x)          # preserves x's (dense) strides
+        assert gx.stride() == x.stride()
+        coef = g.reshape(1).contiguous().float()
+        sb, sc, st = x.stride()
+        check(lib.radmmm_masked_reduce_bwd(ptr(x), B, C, T, sb, sc, st, ptr(lens), ctx.mode, ptr(coef), ptr(gx),
+                                           stream()), "masked_reduce_bwd")
+        return gx, None, None
+
+
+def masked_sum(x, lens):
+    return MaskedReduceFn.apply(x, lens, 0)
+
+
+def masked_sumsq(x, lens):
+    return MaskedReduceFn.apply(x, lens, 1)
+
+
+def fused_add_tanh_sigmoid_multiply(a: torch.Tensor, b: torch.Tensor, n_channels: int) -> torch.Tensor:
+    """common.py:66-73 on channels-last [rows, 2n] operands (forward only; no config uses it)."""
+    rows, ld = a.shape
+    y = _empty(rows, n_channels, like=a)
+    check(lib.radmmm_fused_add_tanh_sigmoid_multiply(ptr(a), ptr(b), ld, ptr(y), n_channels, rows, n_channels,
+                                                     stream()), "fused_add_tanh_sigmoid_multiply")
+    return y

@@ -1,0 +1,303 @@
+"""GPU parity tests: HIP kernels (through the C-ABI) vs the CPU oracle and the golden
+fixtures.  Run on an MI355X with `pytest -m gpu`.
+
+Tolerances: fp32 path -> 1e-4 relative (BASELINE.json north_star) on flow z / log-det /
+NLL; kernels in isolation are held to 2e-5.  Index work (MAS) is bit-exact
+(tests/test_hip_aux.py).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(d):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def R():
+    import rad_mmm_amd
+    from rad_mmm_amd import _lib, ops
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return ops
+
+
+def _lens_dev(lens):
+    return torch.tensor(lens, dtype=torch.int32, device=DEV)
+
+
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,layout", [(111, 50, 70, 0), (111, 50, 70, 1), (256, 128, 32, 0),
+                                          (37 * 8, 160, 158, 1), (640, 300, 1030, 0)])
+def test_rowgemm_plain(R, M, N, K, layout):
+    from rad_mmm_amd._lib import rowgemm
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = (K + 3) // 4 * 4 + 4
+    A = torch.randn(M, lda, generator=g)
+    if layout == 0:
+        ldb = (K + 3) // 4 * 4
+        Bm = torch.randn(N, ldb, generator=g)
+        ref = A[:, :K].double() @ Bm[:, :K].double().t()
+    else:
+        ldb = (N + 3) // 4 * 4 + 8
+        Bm = torch.randn(K, ldb, generator=g)
+        ref = A[:, :K].double() @ Bm[:, :N].double()
+    bias = torch.randn(N, generator=g)
+    ldc = (N + 3) // 4 * 4
+    C = torch.full((M, ldc), float("nan"), device=DEV)
+    rowgemm(A=A.to(DEV), lda=lda, B=Bm.to(DEV), ldb=ldb, b_layout=layout, C=C, ldc=ldc, M=M, N=N, K=K, T=M,
+            bias=bias.to(DEV))
+    out = C[:, :N].cpu().double()
+    assert rel_err(out, ref + bias.double()) < 2e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,dil", [(16, 16, 1), (40, 24, 2), (128, 130, 4), (64, 64, 8)])
+def test_conv_fwd_partial_softplus(R, Cin, Cout, dil):
+    """in_layer forward: softplus(ConvNorm(PartialConv1d)) (common.py:179-191,830)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd._lib import rowgemm
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(Cin * 7 + dil)
+    B, Tn = 3, 45
+    lens = [45, 31, 9]
+    x = torch.randn(B, Cin, Tn, generator=g)
+    v = torch.randn(Cout, Cin, 5, generator=g) * 0.2
+    gg = torch.rand(Cout, 1, 1, generator=g) + 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    mask = O.lengths_to_mask(torch.tensor(lens), Tn)[:, None].float()
+    w = O.weight_norm_fold(v, gg)
+    ref = F.softplus(O.partial_conv1d(x, mask, w, b, dil) * mask)
+    W, inv = ops.weightnorm_fwd(v.to(DEV), gg.to(DEV))
+    assert rel_err(W.cpu().permute(1, 2, 0)[:, :Cin], w) < 1e-6
+    ld = (Cin + 3) // 4 * 4
+    xcl = F.pad(x.permute(0, 2, 1).reshape(B * Tn, Cin), (0, ld - Cin)).contiguous().to(DEV)
+    ldc = (Cout + 3) // 4 * 4
+    y = torch.empty(B * Tn, ldc, device=DEV)
+    rowgemm(A=xcl, lda=ld, B=W, ldb=W.shape[2], b_tap_stride=W.stride(0), b_layout=0, C=y, ldc=ldc, M=B * Tn,
+            N=Cout, K=Cin, taps=5, dil=dil, sign=1, T=Tn, lens=_lens_dev(lens), a_mask_mode=1, bias=b.to(DEV),
+            pconv=1, ratio_taps=5, ratio_dil=dil, postmask=1, act=1)
+    out = y[:, :Cout].cpu().reshape(B, Tn, Cout).permute(0, 2, 1)
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,dil", [(16, 16, 1), (40, 24, 4), (130, 64, 2)])
+def test_conv_dgrad_wgrad(R, Cin, Cout, dil):
+    """data- and weight-gradient of the masked dilated conv vs autograd on the oracle."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd._lib import rowgemm
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(Cin + 13 * dil)
+    B, Tn = 3, 40
+    lens = [40, 26, 7]
+    x = torch.randn(B, Cin, Tn, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 5, generator=g) * 0.2).requires_grad_(True)
+    mask = O.lengths_to_mask(torch.tensor(lens), Tn)[:, None].float()
+    y = F.conv1d(x * mask, w, None, padding=2 * dil, dilation=dil)
+    gy = torch.randn(B, Cout, Tn, generator=g)
+    (y * gy).sum().backward()
+    ldi, ldo = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    cl = lambda t, ld: F.pad(t.detach().permute(0, 2, 1).reshape(B * Tn, -1), (0, ld - t.shape[1])).contiguous().to(DEV)
+    Wp = F.pad(w.detach().permute(2, 0, 1), (0, ldi - Cin)).contiguous().to(DEV)      # [5][Cout][ldi]
+    gx = torch.empty(B * Tn, ldi, device=DEV)
+    rowgemm(A=cl(gy, ldo), lda=ldo, B=Wp, ldb=ldi, b_tap_stride=Wp.stride(0), b_layout=1, C=gx, ldc=ldi,
+            M=B * Tn, N=Cin, K=Cout, taps=5, dil=dil, sign=-1, T=Tn, lens=_lens_dev(lens), a_mask_mode=0, premask=1)
+    out = gx[:, :Cin].cpu().reshape(B, Tn, Cin).permute(0, 2, 1)
+    assert rel_err(out, x.grad) < 2e-5
+    P = ops.wgrad_slabs(cl(gy, ldo), Cout, cl(x, ldi), Cin, ldi, Tn, _lens_dev(lens), taps=5, dil=dil, x_mask_mode=1)
+    gw = P.sum(0)[:, :, :Cin].cpu().permute(1, 2, 0)
+    assert rel_err(gw, w.grad) < 2e-5
+
+
+def test_weightnorm_bwd(R):
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(24, 10, 5, generator=g, requires_grad=True)
+    gg = (torch.rand(24, 1, 1, generator=g) + 0.5).requires_grad_(True)
+    w = O.weight_norm_fold(v, gg)
+    gw = torch.randn(24, 10, 5, generator=g)
+    (w * gw).sum().backward()
+    W, inv = ops.weightnorm_fwd(v.detach().to(DEV), gg.detach().to(DEV))
+    ldw = W.shape[2]
+    slabs = torch.zeros(2, 5, 24, ldw, device=DEV)
+    gwp = F.pad(gw.permute(2, 0, 1), (0, ldw - 10)).to(DEV)
+    slabs[0] = 0.25 * gwp
+    slabs[1] = 0.75 * gwp
+    dv, dg = ops.weightnorm_bwd(v.detach().to(DEV), gg.detach().to(DEV), inv, slabs, ldw)
+    assert rel_err(dv.cpu(), v.grad) < 1e-5
+    assert rel_err(dg.cpu(), gg.grad) < 1e-5
+
+
+# --------------------------------------------------------------------------------------
+def test_affine_layer_golden(R, golden):
+    """AffineTransformationLayer (WN width 16) fwd+bwd vs the reference-generated fixture."""
+    from rad_mmm_amd.common import AffineTransformationLayer
+    from rad_mmm_amd.ops import ZLD
+    g = golden("affine_tiny.npz")
+    layer = AffineTransformationLayer(8, 12, 4, affine_model="wavenet", scaling_fn="tanh",
+                                      affine_activation="softplus", n_channels=16, use_partial_padding=True)
+    layer.load_state_dict(T(sub(g, "sd.")))
+    layer = layer.to(DEV)
+    B, C, Tn = g["in.z"].shape
+    z = torch.from_numpy(g["in.z"])
+    zcl = F.pad(z.permute(0, 2, 1).reshape(B * Tn, C), (0, ZLD - C)).contiguous().to(DEV).requires_grad_(True)
+    ctx = torch.from_numpy(g["in.ctx"]).permute(0, 2, 1).reshape(B * Tn, -1).contiguous().to(DEV).requires_grad_(True)
+    lens = torch.from_numpy(g["in.lens"])
+    W_eff = torch.eye(ZLD, device=DEV)
+    b_eff = torch.zeros(ZLD, device=DEV)
+    zo, log_s = layer.run(zcl, ctx, lens.to(torch.int32).to(DEV), W_eff, b_eff, B, Tn)
+    zo_ref = torch.from_numpy(g["out.z"])
+    out = zo[:, :C].detach().cpu().reshape(B, Tn, C).permute(0, 2, 1)
+    assert rel_err(out, zo_ref) < 2e-5
+    ls = log_s.detach().cpu().reshape(B, Tn, C // 2).permute(0, 2, 1)
+    assert rel_err(ls, g["out.log_s"]) < 2e-5
+    mask = (torch.arange(Tn)[None] < lens[:, None]).float().reshape(B * Tn, 1).to(DEV)
+    scalar = 0.5 * ((zo[:, :C] * mask) ** 2).sum() - (log_s * mask).sum()
+    assert abs(float(scalar) - float(g["out.scalar"])) < 1e-4 * abs(float(g["out.scalar"]))
+    scalar.backward()
+    gz = zcl.grad[:, :C].cpu().reshape(B, Tn, C).permute(0, 2, 1)
+    assert rel_err(gz, g["grad.z"]) < 1e-4
+    gc = ctx.grad.cpu().reshape(B, Tn, -1).permute(0, 2, 1)
+    assert rel_err(gc, g["grad.ctx"]) < 1e-4
+    for n, p in layer.named_parameters():
+        assert rel_err(p.grad.cpu(), g["gradp." + n]) < 1e-4, n
+
+
+def test_flow_loss_golden(R, golden):
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.loss import RADMMMLoss
+    g = golden("flow_loss.npz")
+    z = torch.from_numpy(g["z"]).to(DEV).requires_grad_(True)
+    log_s = [torch.from_numpy(g[f"log_s{i}"]).permute(0, 2, 1).contiguous().to(DEV).permute(0, 2, 1).requires_grad_(True)
+             for i in range(3)]
+    out = {"z_mel": z, "log_s_list": log_s, "log_det_W_list": list(torch.from_numpy(g["ldw"]).to(DEV))}
+    crit = RADMMMLoss(sigma=0.9, n_group_size=2)
+    ld = crit(out, None, SequenceLength(torch.from_numpy(g["lens"]).to(DEV)), 0)
+    assert abs(float(ld["loss_mel"][0]) - float(g["loss_mel"])) < 1e-5 * abs(float(g["loss_mel"]))
+    assert abs(float(ld["loss_prior_mel"][0]) - float(g["loss_prior"])) < 1e-5 * abs(float(g["loss_prior"]))
+    assert ld["loss_mel"][1] == 1.0 and ld["loss_prior_mel"][1] == 0.0
+    ld["loss_mel"][0].backward()
+    # closed form: d/dz = z*m/(sigma^2*denom), d/dlog_s = -m/denom
+    lens = torch.from_numpy(g["lens"]) // 2
+    m = (torch.arange(z.shape[2])[None] < lens[:, None]).float()[:, None]
+    denom = float(lens.sum()) * z.shape[1]
+    assert rel_err(z.grad.cpu(), torch.from_numpy(g["z"]) * m / (0.81 * denom)) < 1e-5
+    for t in log_s:
+        assert rel_err(t.grad.cpu(), (-m / denom).expand_as(t)) < 1e-6
+
+
+def _build_decoder(g):
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.decoders import RADMMMFlow
+    kw = {k: (v.item() if v.shape == () else v) for k, v in sub(g, "cfg.").items()}
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    return dec.to(DEV).train(), cfg, sd
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small"])
+def test_decoder_golden(R, golden, tag):
+    """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
+    cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.loss import RADMMMLoss
+    g = golden(f"decoder_{tag}.npz")
+    dec, cfg, sd = _build_decoder(g)
+    b = T(O.synthetic_batch(int(g["B"]), int(g["T"]), cfg, 1234, bool(g["ragged"])))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    mel = gb["mel"].clone().requires_grad_(True)
+    ctx = gb["context"].clone().requires_grad_(True)
+    sl = SequenceLength(gb["lengths"])
+    out = dec(mel, gb["spk"], ctx, sl, gb["f0"], gb["energy"], gb["accent"])
+    zm = out["z_mel"].detach().cpu().numpy()
+    assert zm.shape == g["z_mel"].shape
+    assert rel_err(zm, g["z_mel"]) < 1e-4                       # includes padded frames
+    ld = torch.stack(out["log_det_W_list"]).detach().cpu().numpy()
+    assert np.abs(ld - g["log_det_W"]).max() < 1e-4
+    ul = b["lengths"] // cfg.n_group_size
+    mask = (torch.arange(zm.shape[2])[None] < ul[:, None]).float()[:, None]
+    for i, ls in enumerate(out["log_s_list"]):
+        assert ls.shape == (zm.shape[0], cfg.flow_channels()[i] // 2, zm.shape[2])
+        s = float((ls.detach().cpu() * mask).sum())
+        assert abs(s - float(g[f"log_s.{i}.masked_sum"])) < 1e-4 * max(1.0, abs(s)), i
+        assert rel_err(ls[:, :4, :32].detach().cpu(), g[f"log_s.{i}.slice"]) < 1e-4, i
+    assert rel_err(out["context_w_spkvec"][:, :8, :16].detach().cpu(), g["ctx_w_spkvec.slice"]) < 1e-4
+    crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)
+    losses = crit(out, None, sl, 0)
+    lm = losses["loss_mel"][0]
+    assert abs(float(lm) - float(g["loss_mel"])) < 1e-4 * abs(float(g["loss_mel"]))
+    assert abs(float(losses["loss_prior_mel"][0]) - float(g["loss_prior"])) < 1e-4 * abs(float(g["loss_prior"]))
+    lm.backward()
+    assert rel_err(mel.grad.cpu(), g["grad.mel"]) < 5e-4
+    assert rel_err(ctx.grad[:, :8, :32].cpu(), g["grad.context.slice"]) < 5e-4
+    worst = 0.0
+    for n, p in dec.named_parameters():
+        gn = float(g["gradnorm." + n])
+        mine = float(p.grad.norm())
+        assert abs(mine - gn) < 5e-4 * gn + 1e-8, (n, mine, gn)
+        worst = max(worst, abs(mine - gn) / (gn + 1e-12))
+    for n, gr in sub(g, "gradp.").items():
+        p = dict(dec.named_parameters())[n]
+        assert np.abs(p.grad.cpu().numpy() - gr).max() < 5e-4 * np.abs(gr).max() + 1e-8, n
+    for n, gr in sub(g, "gradslice.").items():
+        p = dict(dec.named_parameters())[n]
+        assert np.abs(p.grad[:4, :8].cpu().numpy() - gr).max() < 5e-4 * np.abs(gr).max() + 1e-8, n
+    print(f"{tag}: worst grad-norm rel err {worst:.2e}")
+
+
+def test_decoder_full_size_item_independence(R):
+    """BASELINE config 2 shape (8 flows, B=32, T=800): item 0 of the full batch must equal the
+    CPU oracle run on that item alone (items are independent given initialised weights), and
+    the NLL of the batch must equal the frame-weighted mean of per-item NLLs."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+              scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+              n_conv_layers_per_step=4, n_flows=8)
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    b = T(O.synthetic_batch(32, 800, cfg, 99, ragged=True))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+    crit = RADMMMLoss(n_group_size=2)
+    lm = crit(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["z_mel"]).all() and torch.isfinite(lm)
+    for p in dec.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    # oracle on the shortest item alone (cheapest), cut to its own length
+    i = 31
+    L = int(b["lengths"][i])
+    Lc = L + (L % 2)
+    one = {k: (v[i:i + 1, ..., :Lc] if v.dim() > 1 and v.shape[-1] == 800 else v[i:i + 1]) for k, v in b.items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ro = O.decoder_forward(sd, cfg, one["mel"], one["spk"], one["context"], one["lengths"], one["f0"],
+                           one["energy"], one["accent"])
+    Tv = L // 2
+    z_hip = out["z_mel"][i, :, :Tv].detach().cpu()
+    assert rel_err(z_hip, ro["z_mel"][0, :, :Tv]) < 1e-4
+    lo, _ = O.decoder_loss(ro, one["lengths"], 2)
+    # per-item NLL from the HIP outputs (closed form) vs oracle
+    zsq = float((z_hip ** 2).sum()) / 2
+    lss = sum(float(ls[i, :, :Tv].sum()) for ls in out["log_s_list"])
+    ldw = float(torch.stack(out["log_det_W_list"]).sum()) * Tv
+    nll_i = (zsq - lss - ldw) / (Tv * 160)
+    assert abs(nll_i - float(lo)) < 1e-4 * abs(float(lo))
