@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the RADTTS flow-decoder training step
+(decoder forward + flow NLL + backward; no optimizer, no data loading) on synthetic
+fixed-length batches, B=32 per GPU, 80 mel, T=800 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One process per GPU; N > 1 adds the bucketed RCCL gradient all-reduce overlapped with
+backward (rad_mmm_amd/ddp.py).  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel (dilated k=5 1024->1024 conv GEMM, fp32 MFMA) timed live with
+               HIP events on the launch stream: algorithmic FLOP per launch / avg duration
+  wn_stack     the north_star's derived view: algorithmic fp32 bytes of the WN stack / step time
+  cpu_baseline the CPU oracle (a port of the reference's arithmetic) timed on the host cores
+               on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RADTTS = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+              scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+              n_conv_layers_per_step=4, n_flows=8)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def procedural_state(cfg_kwargs):
+    """Random-init weights of the named architecture (no checkpoints exist offline): the same
+    closed-form generator the golden fixtures use, so every rank builds identical weights."""
+    from rad_mmm_amd import synthetic as O
+    cfg = O.DecoderConfig(**cfg_kwargs)
+    sd = O.procedural_decoder_state(O.decoder_state_shapes(cfg))
+    return cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def algorithmic_flops_per_frame(cfg) -> float:
+    """fwd+bwd FLOPs per MEL frame of the conv/1x1 stack (bwd = 2x fwd)."""
+    D, W, L = cfg.cond_dims, 1024, cfg.n_conv_layers_per_step
+    fwd = 0.0
+    for C in cfg.flow_channels():
+        h = C // 2
+        fwd += 2 * (C * C + (h + D) * W + L * (5 * W * W + W * W) + W * C)
+    return 3.0 * fwd / cfg.n_group_size
+
+
+def algorithmic_bytes_per_frame(cfg) -> float:
+    """fp32 HBM bytes per mel frame fwd+bwd under one-kernel-per-conv fusion."""
+    D, W, L = cfg.cond_dims, 1024, cfg.n_conv_layers_per_step
+    fl = 0.0
+    for C in cfg.flow_channels():
+        h = C // 2
+        fl += 2 * C + (h + D + W) + L * 2 * W * 2 + (3 * L * W - W) + (W + 3 * C // 2)
+    return 3.0 * 4.0 * fl / cfg.n_group_size
+
+
+def time_dominant_kernel(N, T, reps=20):
+    """Average duration (s) of ONE launch of the dominant kernel: rowgemm_f32 as the WN in_layer
+    forward conv (M=B*T', N=1024, K=5x1024, dilation 2, partial-conv epilogue + softplus),
+    bracketed by HIP events on the stream the kernel is launched on (torch's current stream)."""
+    from rad_mmm_amd._lib import rowgemm
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(N, 1024, generator=g).to(dev)
+    w = (torch.randn(5, 1024, 1024, generator=g) * 0.02).to(dev)
+    b = torch.zeros(1024, device=dev)
+    y = torch.empty(N, 1024, device=dev)
+    lens = torch.full((N // T,), T, dtype=torch.int32, device=dev)
+
+    def launch():
+        rowgemm(A=x, lda=1024, B=w, ldb=1024, b_tap_stride=1024 * 1024, b_layout=0, C=y, ldc=1024, M=N, N=1024,
+                K=1024, taps=5, dil=2, sign=1, T=T, lens=lens, a_mask_mode=1, bias=b, pconv=1, ratio_taps=5,
+                ratio_dil=2, postmask=1, act=1)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
+
+
+def cpu_baseline(cfg, sd, B=2, T=800):
+    """The CPU oracle (fp32 restatement of the reference) on a bounded sample: decoder fwd +
+    NLL + bwd at the config-2 architecture, B=2, T=800, all host cores."""
+    from oracle import radmmm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0
+             and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
+    b = {k: torch.from_numpy(v) for k, v in O.synthetic_batch(B, T, cfg, 4321, False).items()}
+    t0 = time.perf_counter()
+    out = O.decoder_forward(p, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
+    lm, _ = O.decoder_loss(out, b["lengths"], cfg.n_group_size)
+    lm.backward()
+    dt = time.perf_counter() - t0
+    return {"value": B * T / dt, "unit": "mel-frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"oracle decoder fwd+NLL+bwd, 8 flows, B={B}, T={T}, fp32, 1 step = {dt:.1f} s",
+            "loss_mel": float(lm)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import rad_mmm_amd  # noqa: F401  (loads libradmmm_hip.so; no fallback)
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd import synthetic as O
+
+    cfg, sd = procedural_state(RADTTS)
+    dec = RADMMMFlow(use_accent=True, **RADTTS)
+    dec.load_state_dict(sd)
+    dec = dec.to(dev).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)
+    B, T = args.batch, args.frames
+    batch = O.synthetic_batch(B, T, cfg, seed=1234 + rank, ragged=False)      # rank r: its own utterances
+    gb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    sl = SequenceLength(gb["lengths"])
+    reducer = BucketedGradReducer(dec)
+
+    def step():
+        reducer.prepare()
+        out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+        losses = crit(out, None, sl, 0)
+        loss = losses["loss_mel"][0]
+        loss.backward()
+        reducer.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    frames_per_s = world * B * T * args.steps / dt
+    loss_val = float(loss)
+
+    if rank == 0:
+        N = B * (T // cfg.n_group_size)
+        kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)
+        achieved = kflop / kdur / 1e12
+        fl = algorithmic_flops_per_frame(cfg)
+        by = algorithmic_bytes_per_frame(cfg) + 3 * 4 * sum(p.numel() for p in dec.parameters()) / (B * T)
+        res = {
+            "metric": "mel-frames/sec training step (fwd+bwd)", "value": frames_per_s, "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (procedural random-init weights, N(2.5,0.5) mel, fixed length)",
+            "config": {"workload": "RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
+                                   "D=1048) fwd+NLL+bwd", "batch_per_gpu": B, "n_mel": 80, "frames": T,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "precision": "fp32 MFMA (exact)"},
+            "loss_mel": loss_val,
+            "roofline": {"bound": "mfma", "kernel": "rowgemm_f32_kernel<0> (WN in_layer conv fwd, M=%d N=1024 K=5x1024)" % N,
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": kdur * 1e3,
+                         "flop_per_launch": kflop, "traffic": None},
+            "step_flops": {"algorithmic_tflop_per_step": fl * B * T / 1e12,
+                           "achieved_tflops_per_gpu": fl * B * T / (ms_per_step * 1e-3) / 1e12,
+                           "frac_of_fp32_mfma_peak": fl * B * T / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+            "wn_stack": {"bound": "hbm (derived, north_star)", "algorithmic_gb_per_step": by * B * T / 1e9,
+                         "achieved": by * B * T / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": by * B * T / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library is a build artefact (git-ignored): cross-compile it if this is a fresh tree
+    if not os.path.exists(os.path.join(ROOT, "rad_mmm_amd", "libradmmm_hip.so")):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "rad_mmm_amd", "csrc", "build.sh")])
 
 
 def load_golden(name):

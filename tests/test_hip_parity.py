@@ -160,7 +160,7 @@ def test_affine_layer_golden(R, golden):
     assert rel_err(ls, g["out.log_s"]) < 2e-5
     mask = (torch.arange(Tn)[None] < lens[:, None]).float().reshape(B * Tn, 1).to(DEV)
     scalar = 0.5 * ((zo[:, :C] * mask) ** 2).sum() - (log_s * mask).sum()
-    assert abs(float(scalar) - float(g["out.scalar"])) < 1e-4 * abs(float(g["out.scalar"]))
+    assert abs(float(scalar.detach()) - float(g["out.scalar"])) < 1e-4 * abs(float(g["out.scalar"]))
     scalar.backward()
     gz = zcl.grad[:, :C].cpu().reshape(B, Tn, C).permute(0, 2, 1)
     assert rel_err(gz, g["grad.z"]) < 1e-4
@@ -286,8 +286,9 @@ def test_decoder_full_size_item_independence(R):
     # oracle on the shortest item alone (cheapest), cut to its own length
     i = 31
     L = int(b["lengths"][i])
-    Lc = L + (L % 2)
+    Lc = L - (L % 2)                 # frames beyond 2*(L//2) are dropped by the squeeze anyway
     one = {k: (v[i:i + 1, ..., :Lc] if v.dim() > 1 and v.shape[-1] == 800 else v[i:i + 1]) for k, v in b.items()}
+    one["lengths"] = torch.tensor([Lc])
     torch.set_num_threads(max(1, torch.get_num_threads()))
     ro = O.decoder_forward(sd, cfg, one["mel"], one["spk"], one["context"], one["lengths"], one["f0"],
                            one["energy"], one["accent"])
