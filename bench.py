@@ -94,23 +94,55 @@ def time_dominant_kernel(N, T, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
 
 
-def cpu_baseline(cfg, sd, B=2, T=800):
-    """The CPU oracle (fp32 restatement of the reference) on a bounded sample: decoder fwd +
-    NLL + bwd at the config-2 architecture, B=2, T=800, all host cores."""
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribing it is catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cfg, sd, budget_s=25.0):
+    """The CPU oracle (fp32 restatement of the reference, kind="port") timed on the host cores
+    on a bounded sample of the same workload: the config-2 architecture (8 flows) at the
+    largest of (B,T) in {(2,800),(1,800),(1,400),(1,200)} whose predicted time fits the
+    budget (prediction from a B=1,T=100 probe step; cost is linear in frames)."""
     from oracle import radmmm_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = host_threads()
+    torch.set_num_threads(threads)
     p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0
              and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
-    b = {k: torch.from_numpy(v) for k, v in O.synthetic_batch(B, T, cfg, 4321, False).items()}
-    t0 = time.perf_counter()
-    out = O.decoder_forward(p, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
-    lm, _ = O.decoder_loss(out, b["lengths"], cfg.n_group_size)
-    lm.backward()
-    dt = time.perf_counter() - t0
-    return {"value": B * T / dt, "unit": "mel-frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"oracle decoder fwd+NLL+bwd, 8 flows, B={B}, T={T}, fp32, 1 step = {dt:.1f} s",
-            "loss_mel": float(lm)}
+
+    def one(B, T):
+        for v in p.values():
+            if v.requires_grad:
+                v.grad = None
+        b = {k: torch.from_numpy(v) for k, v in O.synthetic_batch(B, T, cfg, 4321, False).items()}
+        t0 = time.perf_counter()
+        out = O.decoder_forward(p, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"],
+                                b["accent"])
+        lm, _ = O.decoder_loss(out, b["lengths"], cfg.n_group_size)
+        lm.backward()
+        return time.perf_counter() - t0, float(lm.detach())
+
+    one(1, 100)                                   # warm-up (thread pools, oneDNN primitives)
+    probe, _ = one(1, 100)
+    per_frame = probe / 100.0
+    B, T = 1, 100
+    dt = probe
+    for cand in ((2, 800), (1, 800), (1, 400), (1, 200)):
+        if per_frame * cand[0] * cand[1] <= budget_s:
+            B, T = cand
+            dt, _ = one(B, T)
+            break
+    return {"value": B * T / dt, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle decoder fwd+NLL+bwd, 8 flows WN-1024, B={B}, T={T}, fp32, 1 step = {dt:.1f} s "
+                      f"(probe B=1,T=100: {probe:.2f} s)"}
 
 
 def main():
@@ -182,7 +214,7 @@ def main():
         dt = float(tt)
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * B * T * args.steps / dt
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     if rank == 0:
         N = B * (T // cfg.n_group_size)

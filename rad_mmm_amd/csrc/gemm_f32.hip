@@ -42,15 +42,24 @@ __device__ __forceinline__ float4 sel4(float4 v, bool ok, int k, int K) {
 }
 
 __device__ __forceinline__ void mfma_step(const float* as, const float* bs, f32x16 (&acc)[2][2]) {
-  // as/bs already offset by wave sub-tile + (lane&31) + (lane>>5)*LDT
+  // as/bs already offset by wave sub-tile + (lane&31) + (lane>>5)*LDT.  Fragments of k-pair
+  // kk+1 are read from LDS before the MFMAs of k-pair kk issue, so the LDS latency sits
+  // under 4 MFMAs (256 cycles) instead of in front of them.
+  float a[2][2], b[2][2];
+  a[0][0] = as[0]; a[0][1] = as[32];
+  b[0][0] = bs[0]; b[0][1] = bs[32];
 #pragma unroll
   for (int kk = 0; kk < BK / 2; ++kk) {
-    const float a0 = as[kk * 2 * LDT], a1 = as[kk * 2 * LDT + 32];
-    const float b0 = bs[kk * 2 * LDT], b1 = bs[kk * 2 * LDT + 32];
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < BK / 2) {
+      a[nxt][0] = as[(kk + 1) * 2 * LDT]; a[nxt][1] = as[(kk + 1) * 2 * LDT + 32];
+      b[nxt][0] = bs[(kk + 1) * 2 * LDT]; b[nxt][1] = bs[(kk + 1) * 2 * LDT + 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this k-pair's MFMAs
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][1], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], b[cur][0], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], b[cur][1], acc[1][1], 0, 0, 0);
   }
 }
 
@@ -92,12 +101,13 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
   const int a_row = tid & 127, a_kc = tid >> 7;
   const int r = m0 + a_row;
   const bool r_ok = r < p.M;
-  int t_in = 0, lim = 0, a_item = 0;
+  int t_in = 0, lim = 0;
+  const float* a_item_ptr = p.A;   // frame 0 of this thread's item (always valid memory)
   if (r_ok) {
     const int b = r / p.T;
-    a_item = b;
     t_in = r - b * p.T;
     lim = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
+    a_item_ptr = p.A + (p.a_item_stride ? (long long)b * p.a_item_stride : (long long)b * p.T * p.lda);
   }
   // B layout 0 ([n][k]): same shape as A.  B layout 1 ([k][n]): thread owns 4 n at b_n4*4,
   // k rows b_k0 + 8*i.
@@ -107,20 +117,19 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
 
   float4 ra[4], rb[4];
 
+  // Loads only ISSUE here (addresses clamped to valid memory); the validity selects are
+  // applied in store_tiles, i.e. after the MFMA loop of the current tile, so that the
+  // s_waitcnt for these loads lands behind the MFMAs and not in front of them.
   auto load_tiles = [&](int step) {
     const int tap = step / kpt, kb = step - tap * kpt;
     const int s = p.sign * (tap - p.taps / 2) * p.dil;
     const int ts = t_in + s;
     const bool av = r_ok && ts >= 0 && ts < lim;
-    const float* arow = p.a_item_stride
-                            ? p.A + (av ? (long long)a_item * p.a_item_stride + (long long)ts * p.lda : 0)
-                            : p.A + (long long)(av ? r + s : 0) * p.lda;
+    const float* arow = a_item_ptr + (long long)(av ? ts : 0) * p.lda;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = kb * BK + (a_kc + 2 * i) * 4;
-      const bool kv = av && k < p.K;
-      const float4 v = *reinterpret_cast<const float4*>(arow + (kv ? k : 0));
-      ra[i] = sel4(v, kv, k, p.K);
+      ra[i] = *reinterpret_cast<const float4*>(arow + ((av && k < p.K) ? k : 0));
     }
     const float* bbase = p.B + (long long)tap * p.b_tap_stride;
     if (B_LAYOUT == 0) {
@@ -128,9 +137,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = kb * BK + (a_kc + 2 * i) * 4;
-        const bool kv = bn_ok && k < p.K;
-        const float4 v = *reinterpret_cast<const float4*>(brow + (kv ? k : 0));
-        rb[i] = sel4(v, kv, k, p.K);
+        rb[i] = *reinterpret_cast<const float4*>(brow + ((bn_ok && k < p.K) ? k : 0));
       }
     } else {
       const int n = n0 + b_n4 * 4;
@@ -138,35 +145,44 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
       for (int i = 0; i < 4; ++i) {
         const int k = kb * BK + b_k0 + 8 * i;
         const bool kv = k < p.K && n < p.N;
-        const float4 v = *reinterpret_cast<const float4*>(bbase + (long long)(kv ? k : 0) * p.ldb + (kv ? n : 0));
-        rb[i] = sel4(v, kv, n, p.N);
+        rb[i] = *reinterpret_cast<const float4*>(bbase + (long long)(kv ? k : 0) * p.ldb + (kv ? n : 0));
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int step, int buf) {
+    const int tap = step / kpt, kb = step - tap * kpt;
+    const int ts = t_in + p.sign * (tap - p.taps / 2) * p.dil;
+    const bool av = r_ok && ts >= 0 && ts < lim;
     float* as = As + buf * TILE;
     float* bs = Bs + buf * TILE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kc = (a_kc + 2 * i) * 4;
-      as[(kc + 0) * LDT + a_row] = ra[i].x;
-      as[(kc + 1) * LDT + a_row] = ra[i].y;
-      as[(kc + 2) * LDT + a_row] = ra[i].z;
-      as[(kc + 3) * LDT + a_row] = ra[i].w;
+      const int k = kb * BK + kc;
+      const float4 v = sel4(ra[i], av && k < p.K, k, p.K);
+      as[(kc + 0) * LDT + a_row] = v.x;
+      as[(kc + 1) * LDT + a_row] = v.y;
+      as[(kc + 2) * LDT + a_row] = v.z;
+      as[(kc + 3) * LDT + a_row] = v.w;
     }
     if (B_LAYOUT == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kc = (a_kc + 2 * i) * 4;
-        bs[(kc + 0) * LDT + a_row] = rb[i].x;
-        bs[(kc + 1) * LDT + a_row] = rb[i].y;
-        bs[(kc + 2) * LDT + a_row] = rb[i].z;
-        bs[(kc + 3) * LDT + a_row] = rb[i].w;
+        const int k = kb * BK + kc;
+        const float4 v = sel4(rb[i], bn_ok && k < p.K, k, p.K);
+        bs[(kc + 0) * LDT + a_row] = v.x;
+        bs[(kc + 1) * LDT + a_row] = v.y;
+        bs[(kc + 2) * LDT + a_row] = v.z;
+        bs[(kc + 3) * LDT + a_row] = v.w;
       }
     } else {
+      const int n = n0 + b_n4 * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(bs + (b_k0 + 8 * i) * LDT + b_n4 * 4) = rb[i];
+      for (int i = 0; i < 4; ++i) {
+        const int k = kb * BK + b_k0 + 8 * i;
+        *reinterpret_cast<float4*>(bs + (b_k0 + 8 * i) * LDT + b_n4 * 4) = sel4(rb[i], k < p.K && n < p.N, n, p.N);
+      }
     }
   };
 
@@ -179,15 +195,17 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   load_tiles(0);
-  store_tiles(0);
+  store_tiles(0, 0);
   __syncthreads();
   const int frag_off = (lane >> 5) * LDT + (lane & 31);
   for (int step = 0; step < nsteps; ++step) {
+    // single basic block: the last iteration re-stages the final tile into the idle buffer
+    // instead of branching, so the loads' wait sits behind the MFMAs in every iteration
     const int buf = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) load_tiles(step + 1);
+    const int nxt = step + 1 < nsteps ? step + 1 : step;
+    load_tiles(nxt);
     mfma_step(As + buf * TILE + wm * 64 + frag_off, Bs + buf * TILE + wn * 64 + frag_off, acc);
-    if (more) store_tiles(buf ^ 1);
+    store_tiles(nxt, buf ^ 1);
     __syncthreads();
   }
 
@@ -295,36 +313,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const radmmm_wgrad_de
   const int am = m0 + c4 * 4, bn = n0 + c4 * 4;
 
   float4 ra[4], rb[4];
-  auto load_tiles = [&](int step) {
+  auto x_row = [&](int rr, bool& ok) {   // source row of the (shifted, masked) activation operand
+    ok = rr < p.R && bn < p.Nc;
+    int src = 0;
+    if (ok) {
+      const int b = rr / p.T;
+      const int t = rr - b * p.T + shift;
+      const int lim = (p.x_mask_mode && p.lens) ? p.lens[b] : p.T;
+      ok = t >= 0 && t < lim;
+      src = rr + shift;
+    }
+    return ok ? src : 0;
+  };
+  auto load_tiles = [&](int step) {     // issue only; selects happen in store_tiles
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = step * BK + k0 + 8 * i;
-      const bool rv = rr < p.R;
-      {
-        const bool ok = rv && am < p.Mc;
-        const float4 v = *reinterpret_cast<const float4*>(p.GY + (long long)(ok ? rr : 0) * p.ldgy + (ok ? am : 0));
-        ra[i] = sel4(v, ok, am, p.Mc);
-      }
-      {
-        bool ok = rv && bn < p.Nc;
-        int src = 0;
-        if (ok) {
-          const int b = rr / p.T;
-          const int t = rr - b * p.T + shift;
-          const int lim = (p.x_mask_mode && p.lens) ? p.lens[b] : p.T;
-          ok = t >= 0 && t < lim;
-          src = rr + shift;
-        }
-        const float4 v = *reinterpret_cast<const float4*>(p.X + (long long)(ok ? src : 0) * p.ldx + (ok ? bn : 0));
-        rb[i] = sel4(v, ok, bn, p.Nc);
-      }
+      const bool aok = rr < p.R && am < p.Mc;
+      ra[i] = *reinterpret_cast<const float4*>(p.GY + (long long)(aok ? rr : 0) * p.ldgy + (aok ? am : 0));
+      bool bok;
+      const int src = x_row(rr, bok);
+      rb[i] = *reinterpret_cast<const float4*>(p.X + (long long)src * p.ldx + (bok ? bn : 0));
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int step, int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(As + buf * TILE + (k0 + 8 * i) * LDT + c4 * 4) = ra[i];
-      *reinterpret_cast<float4*>(Bs + buf * TILE + (k0 + 8 * i) * LDT + c4 * 4) = rb[i];
+      const int rr = step * BK + k0 + 8 * i;
+      const bool aok = rr < p.R && am < p.Mc;
+      bool bok;
+      (void)x_row(rr, bok);
+      *reinterpret_cast<float4*>(As + buf * TILE + (k0 + 8 * i) * LDT + c4 * 4) = sel4(ra[i], aok, am, p.Mc);
+      *reinterpret_cast<float4*>(Bs + buf * TILE + (k0 + 8 * i) * LDT + c4 * 4) = sel4(rb[i], bok, bn, p.Nc);
     }
   };
 
@@ -339,14 +359,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const radmmm_wgrad_de
   const int frag_off = (lane >> 5) * LDT + (lane & 31);
   if (step_lo < step_hi) {
     load_tiles(step_lo);
-    store_tiles(0);
+    store_tiles(step_lo, 0);
     __syncthreads();
     for (int step = step_lo; step < step_hi; ++step) {
       const int buf = (step - step_lo) & 1;
-      const bool more = step + 1 < step_hi;
-      if (more) load_tiles(step + 1);
+      const int nxt = step + 1 < step_hi ? step + 1 : step;
+      load_tiles(nxt);
       mfma_step(As + buf * TILE + wm * 64 + frag_off, Bs + buf * TILE + wn * 64 + frag_off, acc);
-      if (more) store_tiles(buf ^ 1);
+      store_tiles(nxt, buf ^ 1);
       __syncthreads();
     }
   }
