@@ -153,7 +153,16 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     args = ap.parse_args()
+    if args.kernel_only:
+        import rad_mmm_amd  # noqa: F401
+        torch.cuda.set_device(0)
+        N, Tg = args.batch * (args.frames // 2), args.frames // 2
+        kdur, kflop = time_dominant_kernel(N, Tg)
+        print(json.dumps({"kernel": "rowgemm_f32 in_layer fwd", "M": N, "avg_launch_ms": kdur * 1e3,
+                          "tflops": kflop / kdur / 1e12, "tile_env": os.environ.get("RADMMM_ROWGEMM_TILE", "16")}))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

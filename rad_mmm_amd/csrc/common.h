@@ -10,6 +10,9 @@ namespace radmmm {
 
 void set_error(const char* fmt, ...);
 
+// rowgemm16_f32.hip: 16-row-granular tiling of radmmm_rowgemm_f32 (descriptor already validated)
+int launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream);
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -14,7 +14,10 @@
 // i+1 are issued before the MFMA loop of tile i and written to the other buffer after it,
 // one barrier per K step.  fp32 MFMA issues once per 64 cycles per SIMD, which leaves
 // ample issue room for the staging traffic (see DESIGN.md for the cycle budget).
+#include <stdlib.h>
+
 #include "common.h"
+#include "rowgemm_epilogue.h"
 
 namespace {
 
@@ -215,70 +218,12 @@ __global__ __launch_bounds__(256, 2) void rowgemm_f32_kernel(const radmmm_rowgem
   // mask/ratio is computed once per 4 outputs.
   stage_acc_to_lds(smem, acc, wm, wn, lane);
   __syncthreads();
-  const bool need_row = p.pconv || p.premask || p.postmask || p.rowscale;
-  const bool vec_ok = (p.ldc % 4 == 0) && radmmm::aligned16(p.C) &&
-                      (!p.add || (p.ldadd % 4 == 0 && radmmm::aligned16(p.add))) &&
-                      (!p.dact || (p.lddact % 4 == 0 && radmmm::aligned16(p.dact_src))) &&
-                      (!p.C2 || (p.ldc2 % 4 == 0 && radmmm::aligned16(p.C2)));
+  const radmmm::EpilogueCtx ec(p);
   const int c4 = (tid & 31) * 4;
-  const int col = n0 + c4;
   for (int i = 0; i < 16; ++i) {
     const int rl = i * 8 + (tid >> 5);
-    const int row = m0 + rl;
-    if (row >= p.M || col >= p.N) continue;
-    float maskv = 1.f, ratio = 1.f;
-    if (need_row) {
-      const int b = row / p.T;
-      const int t = row - b * p.T;
-      const int len = p.lens ? p.lens[b] : p.T;
-      maskv = t < len ? 1.f : 0.f;
-      if (p.pconv || p.rowscale == 2) ratio = radmmm::pconv_ratio(t, len, p.ratio_taps, p.ratio_dil);
-    }
     const float4 a4 = *reinterpret_cast<const float4*>(smem + rl * BN + c4);
-    float v[4] = {a4.x, a4.y, a4.z, a4.w};
-    const bool full = vec_ok && col + 3 < p.N;
-    float addv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f}, c2v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (full) {
-      if (p.add) { const float4 t4 = *reinterpret_cast<const float4*>(p.add + (long long)row * p.ldadd + col); addv[0] = t4.x; addv[1] = t4.y; addv[2] = t4.z; addv[3] = t4.w; }
-      if (p.dact) { const float4 t4 = *reinterpret_cast<const float4*>(p.dact_src + (long long)row * p.lddact + col); dsv[0] = t4.x; dsv[1] = t4.y; dsv[2] = t4.z; dsv[3] = t4.w; }
-      if (p.C2 && p.c2_accum) { const float4 t4 = *reinterpret_cast<const float4*>(p.C2 + (long long)row * p.ldc2 + col); c2v[0] = t4.x; c2v[1] = t4.y; c2v[2] = t4.z; c2v[3] = t4.w; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (col + e < p.N) {
-          if (p.add) addv[e] = p.add[(long long)row * p.ldadd + col + e];
-          if (p.dact) dsv[e] = p.dact_src[(long long)row * p.lddact + col + e];
-          if (p.C2 && p.c2_accum) c2v[e] = p.C2[(long long)row * p.ldc2 + col + e];
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = v[e];
-      if (p.pconv) x *= ratio;
-      if (p.premask) x *= maskv;
-      if (p.bias) x += (col + e < p.N) ? p.bias[col + e] : 0.f;
-      x += addv[e];
-      if (p.postmask) x *= maskv;
-      if (p.dact) x *= radmmm::dact_from_out(dsv[e], p.dact);
-      if (p.rowscale == 1) x *= maskv;
-      if (p.rowscale == 2) x *= maskv * ratio;
-      x = radmmm::act_apply(x, p.act);
-      v[e] = x;
-      c2v[e] += x;
-    }
-    if (full) {
-      *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-      if (p.C2) *reinterpret_cast<float4*>(p.C2 + (long long)row * p.ldc2 + col) = make_float4(c2v[0], c2v[1], c2v[2], c2v[3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (col + e < p.N) {
-          p.C[(long long)row * p.ldc + col + e] = v[e];
-          if (p.C2) p.C2[(long long)row * p.ldc2 + col + e] = c2v[e];
-        }
-      }
-    }
+    radmmm::epilogue_store4(p, ec, m0 + rl, n0 + c4, a4);
   }
 }
 
@@ -422,6 +367,11 @@ extern "C" int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t 
   RADMMM_REQUIRE(d->sign == 1 || d->sign == -1, "rowgemm: sign must be +-1");
   RADMMM_REQUIRE(!(d->pconv || d->rowscale == 2) || (d->ratio_taps >= 1 && d->ratio_dil >= 1), "rowgemm: ratio_taps/ratio_dil required with pconv/rowscale=2");
   RADMMM_REQUIRE(!d->dact || d->dact_src, "rowgemm: dact needs dact_src");
+  static const bool use32 = [] {
+    const char* e = getenv("RADMMM_ROWGEMM_TILE");
+    return e && atoi(e) == 32;
+  }();
+  if (!use32) return radmmm::launch_rowgemm16(*d, static_cast<hipStream_t>(stream));
   const int ntm = (d->M + BM - 1) / BM, ntn = (d->N + BN - 1) / BN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->b_layout == 0) {

@@ -1,0 +1,85 @@
+// Fused epilogue of radmmm_rowgemm_f32 (see include/radmmm_hip.h for the order of operations),
+// applied to 4 consecutive output columns of one row.  Shared by both tilings of the kernel.
+#pragma once
+#include "common.h"
+
+namespace radmmm {
+
+struct EpilogueCtx {
+  bool need_row, vec_ok;
+  __device__ explicit EpilogueCtx(const radmmm_rowgemm_desc& p) {
+    need_row = p.pconv || p.premask || p.postmask || p.rowscale;
+    vec_ok = (p.ldc % 4 == 0) && aligned16(p.C) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) &&
+             (!p.dact || (p.lddact % 4 == 0 && aligned16(p.dact_src))) &&
+             (!p.C2 || (p.ldc2 % 4 == 0 && aligned16(p.C2)));
+  }
+};
+
+__device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
+                                                int col, float4 a4) {
+  if (row >= p.M || col >= p.N) return;
+  float maskv = 1.f, ratio = 1.f;
+  if (ec.need_row) {
+    const int b = row / p.T;
+    const int t = row - b * p.T;
+    const int len = p.lens ? p.lens[b] : p.T;
+    maskv = t < len ? 1.f : 0.f;
+    if (p.pconv || p.rowscale == 2) ratio = pconv_ratio(t, len, p.ratio_taps, p.ratio_dil);
+  }
+  float v[4] = {a4.x, a4.y, a4.z, a4.w};
+  const bool full = ec.vec_ok && col + 3 < p.N;
+  float addv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f}, c2v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (full) {
+    if (p.add) {
+      const float4 t4 = *reinterpret_cast<const float4*>(p.add + (long long)row * p.ldadd + col);
+      addv[0] = t4.x; addv[1] = t4.y; addv[2] = t4.z; addv[3] = t4.w;
+    }
+    if (p.dact) {
+      const float4 t4 = *reinterpret_cast<const float4*>(p.dact_src + (long long)row * p.lddact + col);
+      dsv[0] = t4.x; dsv[1] = t4.y; dsv[2] = t4.z; dsv[3] = t4.w;
+    }
+    if (p.C2 && p.c2_accum) {
+      const float4 t4 = *reinterpret_cast<const float4*>(p.C2 + (long long)row * p.ldc2 + col);
+      c2v[0] = t4.x; c2v[1] = t4.y; c2v[2] = t4.z; c2v[3] = t4.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (col + e < p.N) {
+        if (p.add) addv[e] = p.add[(long long)row * p.ldadd + col + e];
+        if (p.dact) dsv[e] = p.dact_src[(long long)row * p.lddact + col + e];
+        if (p.C2 && p.c2_accum) c2v[e] = p.C2[(long long)row * p.ldc2 + col + e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    if (p.pconv) x *= ratio;
+    if (p.premask) x *= maskv;
+    if (p.bias) x += (col + e < p.N) ? p.bias[col + e] : 0.f;
+    x += addv[e];
+    if (p.postmask) x *= maskv;
+    if (p.dact) x *= dact_from_out(dsv[e], p.dact);
+    if (p.rowscale == 1) x *= maskv;
+    if (p.rowscale == 2) x *= maskv * ratio;
+    x = act_apply(x, p.act);
+    v[e] = x;
+    c2v[e] += x;
+  }
+  if (full) {
+    *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.C2)
+      *reinterpret_cast<float4*>(p.C2 + (long long)row * p.ldc2 + col) = make_float4(c2v[0], c2v[1], c2v[2], c2v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (col + e < p.N) {
+        p.C[(long long)row * p.ldc + col + e] = v[e];
+        if (p.C2) p.C2[(long long)row * p.ldc2 + col + e] = c2v[e];
+      }
+    }
+  }
+}
+
+}  // namespace radmmm
