@@ -112,9 +112,14 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
   const bool bn_ok = bn < p.N;
   const int b_n4 = tid & 31, b_k0 = tid >> 5;        // layout 1: 4 n at b_n4*4, k rows b_k0 + 8*i
 
-  float4 ra[G::NI], rb[2];
+  struct Regs {
+    float4 a[G::NI];
+    float4 b[2];
+  };
 
-  auto load_tiles = [&](int step) {          // issue only; selects happen in store_tiles
+  // Issue the global loads of one K-step tile into a register set (addresses clamped to valid
+  // memory; the validity selects are applied when the set is written to LDS).
+  auto load_tiles = [&](int step, Regs& R) __attribute__((always_inline)) {
     const int tap = step / kpt, kb = step - tap * kpt;
     const int s = p.sign * (tap - p.taps / 2) * p.dil;
 #pragma unroll
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
       const int ts = a_t[i] + s;
       const int k = kb * BK + a_chunk[i] * 4;
       const bool av = ts >= 0 && ts < a_lim[i] && k < p.K;
-      ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (long long)(av ? ts : 0) * p.lda + (av ? k : 0));
+      R.a[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (long long)(av ? ts : 0) * p.lda + (av ? k : 0));
     }
     const float* bbase = p.B + (long long)tap * p.b_tap_stride;
     if (B_LAYOUT == 0) {
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int k = kb * BK + (b_kc + 2 * i) * 4;
-        rb[i] = *reinterpret_cast<const float4*>(brow + ((bn_ok && k < p.K) ? k : 0));
+        R.b[i] = *reinterpret_cast<const float4*>(brow + ((bn_ok && k < p.K) ? k : 0));
       }
     } else {
       const int n = n0 + b_n4 * 4;
@@ -138,21 +143,23 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
       for (int i = 0; i < 2; ++i) {
         const int k = kb * BK + b_k0 + 8 * i;
         const bool kv = k < p.K && n < p.N;
-        rb[i] = *reinterpret_cast<const float4*>(bbase + (long long)(kv ? k : 0) * p.ldb + (kv ? n : 0));
+        R.b[i] = *reinterpret_cast<const float4*>(bbase + (long long)(kv ? k : 0) * p.ldb + (kv ? n : 0));
       }
     }
   };
-  auto store_tiles = [&](int step, int buf) {
+  // Write part `part` (of 4) of a register set into LDS buffer `buf`: the part-th float4 of the
+  // A operand and (parts 0,1) of the B operand.
+  auto store_part = [&](int step, int buf, const Regs& R, const int part) __attribute__((always_inline)) {
     const int tap = step / kpt, kb = step - tap * kpt;
     const int s = p.sign * (tap - p.taps / 2) * p.dil;
     float* as = As + buf * G::A_TILE;
     float* bs = Bs + buf * G::B_TILE;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
-      if (a_chunk[i] < 4) {
+      if (i == part && a_chunk[i] < 4) {
         const int ts = a_t[i] + s;
         const int k = kb * BK + a_chunk[i] * 4;
-        const float4 v = sel4(ra[i], ts >= 0 && ts < a_lim[i] && k < p.K, k, p.K);
+        const float4 v = sel4(R.a[i], ts >= 0 && ts < a_lim[i] && k < p.K, k, p.K);
         float* d = as + (a_chunk[i] * 4) * G::LDA + a_row[i];
         d[0] = v.x;
         d[G::LDA] = v.y;
@@ -160,24 +167,23 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
         d[3 * G::LDA] = v.w;
       }
     }
-    if (B_LAYOUT == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int kc = (b_kc + 2 * i) * 4;
-        const int k = kb * BK + kc;
-        const float4 v = sel4(rb[i], bn_ok && k < p.K, k, p.K);
-        float* d = bs + kc * LDB + b_row;
-        d[0] = v.x;
-        d[LDB] = v.y;
-        d[2 * LDB] = v.z;
-        d[3 * LDB] = v.w;
-      }
-    } else {
-      const int n = n0 + b_n4 * 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int k = kb * BK + b_k0 + 8 * i;
-        *reinterpret_cast<float4*>(bs + (b_k0 + 8 * i) * LDB + b_n4 * 4) = sel4(rb[i], k < p.K && n < p.N, n, p.N);
+    for (int i = 0; i < 2; ++i) {
+      if (i == part) {
+        if (B_LAYOUT == 0) {
+          const int kc = (b_kc + 2 * i) * 4;
+          const int k = kb * BK + kc;
+          const float4 v = sel4(R.b[i], bn_ok && k < p.K, k, p.K);
+          float* d = bs + kc * LDB + b_row;
+          d[0] = v.x;
+          d[LDB] = v.y;
+          d[2 * LDB] = v.z;
+          d[3 * LDB] = v.w;
+        } else {
+          const int n = n0 + b_n4 * 4;
+          const int k = kb * BK + b_k0 + 8 * i;
+          *reinterpret_cast<float4*>(bs + (b_k0 + 8 * i) * LDB + b_n4 * 4) = sel4(R.b[i], k < p.K && n < p.N, n, p.N);
+        }
       }
     }
   };
@@ -188,42 +194,56 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0, 0);
-  __syncthreads();
   // fragment addressing: lane l reads element [k = l>>4][i = l&15]
   const int fa = (lane >> 4) * G::LDA + (lane & 15);
   const int fb = (lane >> 4) * LDB + wave * 32 + (lane & 15);
-  for (int step = 0; step < nsteps; ++step) {
+
+  // One K step.  Software pipeline, prefetch distance 2: while the MFMAs of tile `step` run from
+  // LDS buffer step&1, the loads of tile step+2 are in flight into Rload and tile step+1 (loaded
+  // during the previous step, register set Rstore) is written to the other LDS buffer in four
+  // parts slotted between the four k-quads of MFMAs.  The only work left outside the MFMA
+  // stream is the address arithmetic, one barrier and the first fragment read of the next step.
+  auto kstep = [&](int step, Regs& Rload, const Regs& Rstore) __attribute__((always_inline)) {
     const int buf = step & 1;
-    const int nxt = step + 1 < nsteps ? step + 1 : step;   // straight-line loop (see gemm_f32.hip)
-    load_tiles(nxt);
+    const int t1 = step + 1 < nsteps ? step + 1 : nsteps - 1;
+    const int t2 = step + 2 < nsteps ? step + 2 : nsteps - 1;
+    load_tiles(t2, Rload);
     const float* as = As + buf * G::A_TILE + fa;
     const float* bs = Bs + buf * G::B_TILE + fb;
-    // fragments of k-quad kq+1 are read while the MFMAs of k-quad kq run
-    float a[2][MT], bq[2][2];
+    float a[MT], bq[2][2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = as[mt * 16];
+    for (int mt = 0; mt < MT; ++mt) a[mt] = as[mt * 16];
     bq[0][0] = bs[0];
     bq[0][1] = bs[16];
 #pragma unroll
     for (int kq = 0; kq < BK / 4; ++kq) {
       const int cur = kq & 1, nx = cur ^ 1;
       if (kq + 1 < BK / 4) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[nx][mt] = as[(kq + 1) * 4 * G::LDA + mt * 16];
         bq[nx][0] = bs[(kq + 1) * 4 * LDB];
         bq[nx][1] = bs[(kq + 1) * 4 * LDB + 16];
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mt], bq[cur][0], acc[mt][0], 0, 0, 0);
-        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mt], bq[cur][1], acc[mt][1], 0, 0, 0);
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bq[cur][0], acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bq[cur][1], acc[mt][1], 0, 0, 0);
+        // rolling refill: a[mt] is dead once its two MFMAs have issued
+        if (kq + 1 < BK / 4) a[mt] = as[(kq + 1) * 4 * G::LDA + mt * 16];
       }
+      store_part(t1, buf ^ 1, Rstore, kq);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    store_tiles(nxt, buf ^ 1);
     __syncthreads();
+  };
+
+  Regs RA, RB;
+  load_tiles(0, RA);
+#pragma unroll
+  for (int part = 0; part < 4; ++part) store_part(0, 0, RA, part);
+  load_tiles(nsteps > 1 ? 1 : 0, RB);
+  __syncthreads();
+  for (int step = 0; step < nsteps; step += 2) {
+    kstep(step, RA, RB);
+    if (step + 1 < nsteps) kstep(step + 1, RB, RA);
   }
 
   // ---- epilogue: 64 rows (4 row-subtiles) at a time through LDS ------------------------------
