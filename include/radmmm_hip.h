@@ -162,9 +162,13 @@ int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* z, int ldz,
                                float* gO, float* gz, int rows, int h, int scaling,
                                radmmm_stream_t stream);
 
-/* y[r, c] = g[r, c] * act'(saved[r, c])  (derivative from the saved OUTPUT), c < cols */
+/* y[r, c] = g[r, c] * act'(saved[r, c]) * w(r), c < cols: derivative of the activation from its
+ * saved OUTPUT (dact 0: none, saved may be NULL) times a row weight (rowscale 0: 1; 1: mask;
+ * 2: mask * partial-conv ratio of a (taps, dil) window) -- the step from dL/d(act output) to
+ * dL/d(conv accumulator) of ConvNorm/PartialConv1d (common.py:179-191) */
 int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y, int ldy,
-                    int rows, int cols, int dact, radmmm_stream_t stream);
+                    int rows, int cols, int dact, int rowscale, int T, const int32_t* lens,
+                    int taps, int dil, radmmm_stream_t stream);
 
 /* out[c] = sum_r w(r) * X[r, c];  row_weight 0: 1 ; 1: [t < lens[b]] ; 2: (cnt+1e-6)/taps over
  * valid rows (undoes the partial-conv ratio: bias gradient of PartialConv1d)          */

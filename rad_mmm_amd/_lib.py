@@ -81,7 +81,7 @@ def _load() -> C.CDLL:
         "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
         "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
         "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
-        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, p],
+        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p],
         "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, p],
         "radmmm_masked_reduce": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_masked_reduce_bwd": [p, i, i, i, i64, i64, i64, p, i, p, p, p],

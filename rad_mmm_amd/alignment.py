@@ -1,0 +1,36 @@
+"""Monotonic alignment search on the GPU (reference alignment.py:31-59 and
+TTSModel.binarize_attention, tts_lightning_modules.py:270-284).
+
+The reference copies the [B, T_mel, T_txt] attention to the host and runs a numba loop per
+item; here the whole batch is one kernel launch and nothing leaves the device.  The DP uses the
+same fp32 additions in the same order, so on identical log inputs the result is bit-exact.
+(The log itself is torch.log on the device; the reference uses numpy's float32 log on the host:
+a 1-ulp difference there can only flip an exact near-tie.)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def binarize_attention(attn: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.Tensor) -> torch.Tensor:
+    """attn [B, 1, T_mel, T_txt] soft attention -> hard 0/1 attention of the same shape."""
+    with torch.no_grad():
+        B, _, T1, T2 = attn.shape
+        logp = torch.log(attn[:, 0].float().contiguous())
+        hard = ops.mas_width1_batch(logp, in_lens.to(torch.int32).contiguous(), out_lens.to(torch.int32).contiguous())
+        return hard[:, None]
+
+
+def mas_width1(attn_map: np.ndarray, device: str = "cuda:0") -> np.ndarray:
+    """numpy [T_mel, T_txt] in, numpy 0/1 out (the reference's signature).  The log is taken on the
+    host with numpy exactly as the reference does."""
+    with np.errstate(divide="ignore"):
+        logp = np.log(attn_map.astype(np.float32))
+    t = torch.from_numpy(logp)[None].to(device)
+    T1, T2 = attn_map.shape
+    hard = ops.mas_width1_batch(t, torch.tensor([T2], dtype=torch.int32, device=device),
+                                torch.tensor([T1], dtype=torch.int32, device=device))
+    return hard[0].cpu().numpy().astype(attn_map.dtype)

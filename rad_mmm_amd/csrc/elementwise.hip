@@ -162,26 +162,39 @@ __global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
 // ------------------------------------------------------------------ dact product
 __global__ __launch_bounds__(256) void dact_mul_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds,
-    float* __restrict__ y, int ldy, int rows, int cols, int dact) {
+    float* __restrict__ y, int ldy, int rows, int cols, int dact, int rowscale, int T,
+    const int* __restrict__ lens, int taps, int dil) {
   const int c4n = (cols + 3) / 4;
   const long long total = (long long)rows * c4n;
   const bool vec = (cols % 4 == 0) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldy % 4 == 0);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n) * 4;
+    float rs = 1.f;
+    if (rowscale) {
+      const int b = r / T, t = r - b * T;
+      const int len = lens ? lens[b] : T;
+      rs = t < len ? 1.f : 0.f;
+      if (rowscale == 2) rs *= radmmm::pconv_ratio(t, len, taps, dil);
+    }
     if (vec) {
       const float4 gv = *reinterpret_cast<const float4*>(g + (long long)r * ldg + c);
-      const float4 sv = *reinterpret_cast<const float4*>(saved + (long long)r * lds + c);
       float4 o;
-      o.x = gv.x * radmmm::dact_from_out(sv.x, dact);
-      o.y = gv.y * radmmm::dact_from_out(sv.y, dact);
-      o.z = gv.z * radmmm::dact_from_out(sv.z, dact);
-      o.w = gv.w * radmmm::dact_from_out(sv.w, dact);
+      if (dact) {
+        const float4 sv = *reinterpret_cast<const float4*>(saved + (long long)r * lds + c);
+        o.x = gv.x * radmmm::dact_from_out(sv.x, dact) * rs;
+        o.y = gv.y * radmmm::dact_from_out(sv.y, dact) * rs;
+        o.z = gv.z * radmmm::dact_from_out(sv.z, dact) * rs;
+        o.w = gv.w * radmmm::dact_from_out(sv.w, dact) * rs;
+      } else {
+        o.x = gv.x * rs; o.y = gv.y * rs; o.z = gv.z * rs; o.w = gv.w * rs;
+      }
       *reinterpret_cast<float4*>(y + (long long)r * ldy + c) = o;
     } else {
-      for (int e = 0; e < 4 && c + e < cols; ++e)
-        y[(long long)r * ldy + c + e] =
-            g[(long long)r * ldg + c + e] * radmmm::dact_from_out(saved[(long long)r * lds + c + e], dact);
+      for (int e = 0; e < 4 && c + e < cols; ++e) {
+        const float d = dact ? radmmm::dact_from_out(saved[(long long)r * lds + c + e], dact) : 1.f;
+        y[(long long)r * ldy + c + e] = g[(long long)r * ldg + c + e] * d * rs;
+      }
     }
   }
 }
@@ -388,11 +401,15 @@ extern "C" int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* 
 }
 
 extern "C" int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y,
-                               int ldy, int rows, int cols, int dact, radmmm_stream_t stream) {
-  RADMMM_REQUIRE(g && saved && y, "dact_mul: null pointer");
-  RADMMM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && lds >= cols && ldy >= cols, "dact_mul: bad dims");
+                               int ldy, int rows, int cols, int dact, int rowscale, int T,
+                               const int32_t* lens, int taps, int dil, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(g && y && (saved || !dact), "dact_mul: null pointer");
+  RADMMM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && ldy >= cols && (!dact || lds >= cols), "dact_mul: bad dims");
+  RADMMM_REQUIRE(!rowscale || (T > 0 && rows % T == 0), "dact_mul: rows must be a multiple of T");
+  RADMMM_REQUIRE(rowscale != 2 || (taps >= 1 && dil >= 1), "dact_mul: taps/dil");
   hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for((long long)rows * ((cols + 3) / 4))), dim3(256), 0,
-                     ST(stream), g, ldg, saved, lds, y, ldy, rows, cols, dact);
+                     ST(stream), g, ldg, saved, lds, y, ldy, rows, cols, dact, rowscale, T > 0 ? T : 1, lens, taps,
+                     dil);
   return radmmm::check_launch("dact_mul");
 }
 

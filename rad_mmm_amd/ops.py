@@ -208,7 +208,7 @@ class AffineFlowStepFn(torch.autograd.Function):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
             # through softplus of the res/skip branch
-            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, stream()), "dact_mul")
+            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, stream()), "dact_mul")
             g_res[3 * j + 2] = colsum(gQ, Wc)
             slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
@@ -291,3 +291,138 @@ def fused_add_tanh_sigmoid_multiply(a: torch.Tensor, b: torch.Tensor, n_channels
     check(lib.radmmm_fused_add_tanh_sigmoid_multiply(ptr(a), ptr(b), ld, ptr(y), n_channels, rows, n_channels,
                                                      stream()), "fused_add_tanh_sigmoid_multiply")
     return y
+
+
+# ---------------------------------------------------------------------------------------
+# generic weight-normed ConvNorm (common.py:152-191) on channels-last rows
+# ---------------------------------------------------------------------------------------
+class ConvNormFn(torch.autograd.Function):
+    """y = act( mask_out * ( pconv_ratio * conv(x * mask_in, weight_norm(v, g)) + bias ) ).
+
+    x [N, ldx] (first Cin columns), v [Cout, Cin, taps], g [Cout,1,1] or None (plain conv: v IS the
+    weight), bias [Cout].  meta: B, T, dil, partial (PartialConv1d: input masking + window
+    re-normalisation), mask_out (ConvNorm multiplies by the mask again), act code.
+    Returns y [N, round_up(Cout, 4)].
+    """
+
+    @staticmethod
+    def forward(ctx, meta, x, v, g, bias, lens):
+        B, T, dil = meta["B"], meta["T"], meta["dil"]
+        partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
+        Cout, Cin, taps = v.shape
+        N = B * T
+        assert x.shape[0] == N and x.shape[1] >= Cin and x.shape[1] % 4 == 0 and x.is_contiguous()
+        if g is not None:
+            W, inv = weightnorm_fwd(v, g)
+        else:
+            ldw = round_up(Cin, 4)
+            W = torch.zeros(taps, Cout, ldw, device=x.device, dtype=torch.float32)
+            W[:, :, :Cin] = v.permute(2, 0, 1)
+            inv = None
+        ldy = round_up(Cout, 4)
+        y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
+        rowgemm(A=x, lda=x.shape[1], B=W, ldb=W.shape[2], b_tap_stride=W.stride(0), b_layout=0, C=y, ldc=ldy,
+                M=N, N=Cout, K=Cin, taps=taps, dil=dil, sign=1, T=T, lens=lens, a_mask_mode=1 if partial else 0,
+                bias=bias, pconv=1 if partial else 0, ratio_taps=taps, ratio_dil=dil,
+                postmask=1 if mask_out else 0, act=act)
+        ctx.meta = meta
+        ctx.has_g = g is not None
+        ctx.save_for_backward(x, v, g if g is not None else v, bias if bias is not None else v, lens if lens is not None else v,
+                              W, inv if inv is not None else v, y)
+        ctx.has_bias = bias is not None
+        ctx.has_lens = lens is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        meta = ctx.meta
+        B, T, dil = meta["B"], meta["T"], meta["dil"]
+        partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
+        x, v, g, bias, lens, W, inv, y = ctx.saved_tensors
+        lens = lens if ctx.has_lens else None
+        Cout, Cin, taps = v.shape
+        N = B * T
+        gy = gy.contiguous()
+        ldy = y.shape[1]
+        rowscale = 2 if partial else (1 if mask_out else 0)
+        gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
+        check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
+                                  taps, dil, stream()), "dact_mul")
+        g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil) if ctx.has_bias else None
+        ldw = W.shape[2]
+        slabs = wgrad_slabs(gpre, Cout, x, Cin, ldw, T, lens, taps=taps, dil=dil, x_mask_mode=1 if partial else 0)
+        if ctx.has_g:
+            g_v, g_g = weightnorm_bwd(v, g, inv, slabs, ldw)
+        else:
+            g_v, g_g = slabs.sum(0)[:, :, :Cin].permute(1, 2, 0).contiguous(), None
+        gx = torch.zeros_like(x) if x.shape[1] != Cin else torch.empty_like(x)
+        if ctx.needs_input_grad[1]:
+            rowgemm(A=gpre, lda=ldy, B=W, ldb=ldw, b_tap_stride=W.stride(0), b_layout=1, C=gx, ldc=x.shape[1], M=N,
+                    N=Cin, K=Cout, taps=taps, dil=dil, sign=-1, T=T, lens=lens, a_mask_mode=0,
+                    premask=1 if partial else 0)
+        else:
+            gx = None
+        return None, gx, g_v, g_g, g_bias, None
+
+
+def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none"):
+    meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act])
+    return ConvNormFn.apply(meta, x, v, g, bias, lens)
+
+
+# ---------------------------------------------------------------------------------------
+# alignment attention core (common.py:1262-1277)
+# ---------------------------------------------------------------------------------------
+class AttentionCoreFn(torch.autograd.Function):
+    """Q [B,T1,Ca], K [B,T2,Ca] (channels-last, contiguous), prior [B,T1,T2] or None, in_lens int32 [B]
+    or None -> attn, attn_logprob [B,T1,T2]."""
+
+    @staticmethod
+    def forward(ctx, Q, K, prior, in_lens, temp):
+        B, T1, Ca = Q.shape
+        T2 = K.shape[1]
+        attn = _empty(B, T1, T2, like=Q)
+        logprob = _empty(B, T1, T2, like=Q)
+        check(lib.radmmm_attn_fwd(ptr(Q), ptr(K), ptr(prior), ptr(in_lens), ptr(attn), ptr(logprob), B, T1, T2, Ca,
+                                  temp, stream()), "attn_fwd")
+        ctx.save_for_backward(Q, K, prior if prior is not None else Q, in_lens if in_lens is not None else Q, attn, logprob)
+        ctx.flags = (prior is not None, in_lens is not None, temp)
+        return attn, logprob
+
+    @staticmethod
+    def backward(ctx, gattn, glogprob):
+        Q, K, prior, in_lens, attn, logprob = ctx.saved_tensors
+        has_prior, has_lens, temp = ctx.flags
+        B, T1, Ca = Q.shape
+        T2 = K.shape[1]
+        gQ, gK = torch.empty_like(Q), torch.empty_like(K)
+        scratch = _empty(B, T1, T2, like=Q)
+        ga = gattn.contiguous() if gattn is not None else None
+        gl = glogprob.contiguous() if glogprob is not None else None
+        check(lib.radmmm_attn_bwd(ptr(Q), ptr(K), ptr(prior) if has_prior else None, ptr(in_lens) if has_lens else None,
+                                  ptr(attn), ptr(logprob), ptr(ga), ptr(gl), ptr(gQ), ptr(gK), ptr(scratch), B, T1, T2,
+                                  Ca, temp, stream()), "attn_bwd")
+        return gQ, gK, None, None, None
+
+
+def mas_width1_batch(logp: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.Tensor) -> torch.Tensor:
+    """logp [B,T1,T2] = log(attn) on the GPU -> 0/1 hard alignment [B,T1,T2] (alignment.py:31-59)."""
+    B, T1, T2 = logp.shape
+    hard = _empty(B, T1, T2, like=logp)
+    scratch = torch.empty(int(lib.radmmm_mas_scratch_bytes(B, T1, T2)), device=logp.device, dtype=torch.uint8)
+    check(lib.radmmm_mas_width1(ptr(logp.contiguous()), ptr(in_lens), ptr(out_lens), ptr(hard), ptr(scratch), B, T1,
+                                T2, stream()), "mas_width1")
+    return hard
+
+
+def stft_mel(audio: torch.Tensor, basis: torch.Tensor, mel_basis: torch.Tensor, n_fft: int, hop: int,
+             clip: float = 1e-5) -> torch.Tensor:
+    """audio [B,S] -> log-mel [B, n_mel, 1+S//hop] (audio_processing.py:137-154)."""
+    B, S = audio.shape
+    n_mel = mel_basis.shape[0]
+    F_ = 1 + S // hop
+    mel = _empty(B, n_mel, F_, like=audio)
+    scratch = _empty(int(lib.radmmm_stft_mel_scratch_floats(B, S, n_fft, hop, n_mel)), like=audio)
+    check(lib.radmmm_stft_mel(ptr(audio.contiguous()), ptr(basis), ptr(mel_basis), ptr(mel), ptr(scratch), B, S, n_fft,
+                              hop, n_mel, clip, stream()), "stft_mel")
+    return mel

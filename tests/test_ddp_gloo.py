@@ -1,0 +1,111 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the bucketed gradient reducer that the
+N-GPU benchmark uses over RCCL: per-flow flat buckets whose slices are the parameters' .grad,
+async all-reduce launched from grad hooks, mean over ranks."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class _Flow(torch.nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.randn(c, c) * 0.3)
+        self.b = torch.nn.Parameter(torch.zeros(c))
+        self.frozen = torch.nn.Parameter(torch.ones(c), requires_grad=False)
+
+    def forward(self, z):
+        return torch.tanh(z @ self.w + self.b) * self.frozen
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.flows = torch.nn.ModuleList([_Flow(6) for _ in range(3)])
+        self.context_lstm = torch.nn.LSTM(6, 3, batch_first=True, bidirectional=True)
+
+    def forward(self, x):
+        y, _ = self.context_lstm(x)
+        for f in self.flows:
+            y = f(y)
+        return (y ** 2).mean()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rad_mmm_amd.ddp import BucketedGradReducer, broadcast_module_state, default_bucket_key
+    torch.manual_seed(100 + rank)           # different init per rank on purpose
+    model = _Toy()
+    broadcast_module_state(model, 0)
+    red = BucketedGradReducer(model)
+    keys = [b["key"] for b in red.buckets]
+    assert keys == ["flows.0", "flows.1", "flows.2", "misc"], keys
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(world, 4, 5, 6, generator=g)
+    ok = True
+    for it in range(2):                      # twice: prepare() must re-arm the hooks
+        red.prepare()
+        loss = model(data[rank])
+        loss.backward()
+        red.finish()
+        # reference: mean over ranks of the local gradients, computed serially on every rank
+        ref = [torch.zeros_like(p) for p in model.parameters() if p.requires_grad]
+        for r in range(world):
+            m2 = _Toy()
+            m2.load_state_dict(model.state_dict())
+            m2(data[r]).backward()
+            for a, p in zip(ref, [p for p in m2.parameters() if p.requires_grad]):
+                a += p.grad / world
+        for a, p in zip(ref, [p for p in model.parameters() if p.requires_grad]):
+            ok = ok and torch.allclose(p.grad, a, rtol=1e-5, atol=1e-7)
+        # .grad tensors are views into the flat buckets
+        for b in red.buckets:
+            off = 0
+            for p in b["params"]:
+                ok = ok and p.grad.data_ptr() == b["flat"].data_ptr() + 4 * off
+                off += p.numel()
+    # identical parameters on every rank after broadcast
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_bucket_key():
+    from rad_mmm_amd.ddp import default_bucket_key
+    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.start.weight_v") == "flows.3"
+    assert default_bucket_key("context_lstm.weight_ih_l0") == "misc"
