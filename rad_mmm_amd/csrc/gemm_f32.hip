@@ -371,7 +371,11 @@ extern "C" int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t 
     const char* e = getenv("RADMMM_ROWGEMM_TILE");
     return e && atoi(e) == 32;
   }();
-  if (!use32) return radmmm::launch_rowgemm16(*d, static_cast<hipStream_t>(stream));
+  if (!use32 && d->K % 16 == 0) {
+    // fast path: 16-row-granular tiling with a VALU-free K loop (needs K % 16 == 0, operands < 2 GiB)
+    const int rc = radmmm::launch_rowgemm16(*d, static_cast<hipStream_t>(stream));
+    if (rc <= 0) return rc;
+  }
   const int ntm = (d->M + BM - 1) / BM, ntn = (d->N + BN - 1) / BN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->b_layout == 0) {

@@ -22,6 +22,8 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define U2F(u) __builtin_bit_cast(float, (unsigned int)(u))
 
 constexpr int BN = 128, BK = 16;
 constexpr int LDB = 144;                       // 144 % 32 == 16
@@ -71,7 +73,7 @@ __device__ __forceinline__ void stage_pass(float* smem, const f32x4 (&acc)[MT][2
 
 template <int MT, int B_LAYOUT>
 __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_desc p, const int rows_per_tile,
-                                                            const int nmt) {
+                                                            const int nmt, const int a_bytes, const int b_bytes) {
   using G = Geo<MT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [2][BK][LDA]
@@ -88,9 +90,16 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
   const int kpt = (p.K + BK - 1) / BK;
   const int nsteps = kpt * p.taps;
 
-  // ---- per-thread staging coordinates ----------------------------------------------------
-  int a_row[G::NI], a_chunk[G::NI], a_t[G::NI], a_lim[G::NI];
-  const float* a_ptr[G::NI];
+  // ---- staging through BUFFER loads -----------------------------------------------------------
+  // fp32 MFMA shares the SIMD's FMA datapath with ordinary VALU instructions (measured:
+  // profiles/r01_mfma_valu_mix.txt), so the K loop must carry (almost) no vector ALU work.
+  // Every global address is therefore split into a per-thread byte offset that only changes
+  // when the TAP changes (a handful of VALU ops every K/16 steps) and a wave-uniform scalar
+  // offset per K step (SALU); frames that fall outside their item / valid length get an
+  // out-of-range offset, for which the buffer unit returns zeros in hardware -- no selects.
+  // Requires K % 16 == 0 (checked by the host dispatcher).
+  constexpr int OOB = 0x7fffffff;
+  int a_row[G::NI], a_chunk[G::NI], a_t[G::NI], a_lim[G::NI], a_base[G::NI], a_voff[G::NI];
 #pragma unroll
   for (int i = 0; i < G::NI; ++i) {
     const int idx = tid + i * 256;
@@ -98,91 +107,83 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
     a_row[i] = idx - a_chunk[i] * G::ROWS;
     const int r = m0 + a_row[i];
     a_t[i] = 0;
-    a_lim[i] = 0;                           // lim 0 -> never valid
-    a_ptr[i] = p.A;
+    a_lim[i] = 0;                           // lim 0 -> never valid -> zeros
+    a_base[i] = 0;
+    a_voff[i] = OOB;
     if (a_chunk[i] < 4 && r < m_end) {
       const int b = r / p.T;
       a_t[i] = r - b * p.T;
       a_lim[i] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
-      a_ptr[i] = p.A + (p.a_item_stride ? (long long)b * p.a_item_stride : (long long)b * p.T * p.lda);
+      const long long item = p.a_item_stride ? (long long)b * p.a_item_stride : (long long)b * p.T * p.lda;
+      a_base[i] = (int)((item + a_chunk[i] * 4) * 4);      // bytes; buffers are < 2 GiB (host check)
     }
   }
-  const int b_row = tid & 127, b_kc = tid >> 7;      // layout 0: row n, chunks b_kc + 2*i
-  const int bn = n0 + b_row;
-  const bool bn_ok = bn < p.N;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.A), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.B), 0, b_bytes, 0x00020000);
+  const int b_row = tid & 127, b_kc = tid >> 7;      // layout 0: row n, 16-B chunks b_kc + 2*i
   const int b_n4 = tid & 31, b_k0 = tid >> 5;        // layout 1: 4 n at b_n4*4, k rows b_k0 + 8*i
-
-  struct Regs {
-    float4 a[G::NI];
-    float4 b[2];
-  };
-
-  // Issue the global loads of one K-step tile into a register set (addresses clamped to valid
-  // memory; the validity selects are applied when the set is written to LDS).
-  auto load_tiles = [&](int step, Regs& R) __attribute__((always_inline)) {
-    const int tap = step / kpt, kb = step - tap * kpt;
+  int b_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (B_LAYOUT == 0) {
+      const int n = n0 + b_row;
+      b_voff[i] = n < p.N ? (n * p.ldb + (b_kc + 2 * i) * 4) * 4 : OOB;
+    } else {
+      const int n = n0 + b_n4 * 4;
+      b_voff[i] = n < p.N ? ((b_k0 + 8 * i) * p.ldb + n) * 4 : OOB;
+    }
+  }
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
     const int s = p.sign * (tap - p.taps / 2) * p.dil;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
       const int ts = a_t[i] + s;
-      const int k = kb * BK + a_chunk[i] * 4;
-      const bool av = ts >= 0 && ts < a_lim[i] && k < p.K;
-      R.a[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (long long)(av ? ts : 0) * p.lda + (av ? k : 0));
-    }
-    const float* bbase = p.B + (long long)tap * p.b_tap_stride;
-    if (B_LAYOUT == 0) {
-      const float* brow = bbase + (long long)(bn_ok ? bn : 0) * p.ldb;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int k = kb * BK + (b_kc + 2 * i) * 4;
-        R.b[i] = *reinterpret_cast<const float4*>(brow + ((bn_ok && k < p.K) ? k : 0));
-      }
-    } else {
-      const int n = n0 + b_n4 * 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int k = kb * BK + b_k0 + 8 * i;
-        const bool kv = k < p.K && n < p.N;
-        R.b[i] = *reinterpret_cast<const float4*>(bbase + (long long)(kv ? k : 0) * p.ldb + (kv ? n : 0));
-      }
+      a_voff[i] = (ts >= 0 && ts < a_lim[i]) ? a_base[i] + ts * p.lda * 4 : OOB;
     }
   };
-  // Write part `part` (of 4) of a register set into LDS buffer `buf`: the part-th float4 of the
-  // A operand and (parts 0,1) of the B operand.
-  auto store_part = [&](int step, int buf, const Regs& R, const int part) __attribute__((always_inline)) {
+
+  struct Regs {
+    u32x4 a[G::NI];
+    u32x4 b[2];
+  };
+  auto load_tiles = [&](int step, Regs& R) __attribute__((always_inline)) {
     const int tap = step / kpt, kb = step - tap * kpt;
-    const int s = p.sign * (tap - p.taps / 2) * p.dil;
+    if (kb == 0) set_tap(tap);               // uniform branch, once per tap
+    const int so_a = kb * (BK * 4);
+    const int so_b = B_LAYOUT == 0 ? (int)(tap * p.b_tap_stride * 4) + kb * (BK * 4)
+                                   : (int)(tap * p.b_tap_stride * 4) + kb * (BK * 4) * p.ldb;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) R.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], so_a, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], so_b, 0);
+  };
+  // Write part `part` (of 4) of a register set into LDS buffer `buf`: pure ds_write traffic.
+  auto store_part = [&](int buf, const Regs& R, const int part) __attribute__((always_inline)) {
     float* as = As + buf * G::A_TILE;
     float* bs = Bs + buf * G::B_TILE;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
       if (i == part && a_chunk[i] < 4) {
-        const int ts = a_t[i] + s;
-        const int k = kb * BK + a_chunk[i] * 4;
-        const float4 v = sel4(R.a[i], ts >= 0 && ts < a_lim[i] && k < p.K, k, p.K);
         float* d = as + (a_chunk[i] * 4) * G::LDA + a_row[i];
-        d[0] = v.x;
-        d[G::LDA] = v.y;
-        d[2 * G::LDA] = v.z;
-        d[3 * G::LDA] = v.w;
+        d[0] = U2F(R.a[i].x);
+        d[G::LDA] = U2F(R.a[i].y);
+        d[2 * G::LDA] = U2F(R.a[i].z);
+        d[3 * G::LDA] = U2F(R.a[i].w);
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i == part) {
         if (B_LAYOUT == 0) {
-          const int kc = (b_kc + 2 * i) * 4;
-          const int k = kb * BK + kc;
-          const float4 v = sel4(R.b[i], bn_ok && k < p.K, k, p.K);
-          float* d = bs + kc * LDB + b_row;
-          d[0] = v.x;
-          d[LDB] = v.y;
-          d[2 * LDB] = v.z;
-          d[3 * LDB] = v.w;
+          float* d = bs + (b_kc + 2 * i) * 4 * LDB + b_row;
+          d[0] = U2F(R.b[i].x);
+          d[LDB] = U2F(R.b[i].y);
+          d[2 * LDB] = U2F(R.b[i].z);
+          d[3 * LDB] = U2F(R.b[i].w);
         } else {
-          const int n = n0 + b_n4 * 4;
-          const int k = kb * BK + b_k0 + 8 * i;
-          *reinterpret_cast<float4*>(bs + (b_k0 + 8 * i) * LDB + b_n4 * 4) = sel4(R.b[i], k < p.K && n < p.N, n, p.N);
+          *reinterpret_cast<u32x4*>(bs + (b_k0 + 8 * i) * LDB + b_n4 * 4) = R.b[i];
         }
       }
     }
@@ -205,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
   // stream is the address arithmetic, one barrier and the first fragment read of the next step.
   auto kstep = [&](int step, Regs& Rload, const Regs& Rstore) __attribute__((always_inline)) {
     const int buf = step & 1;
-    const int t1 = step + 1 < nsteps ? step + 1 : nsteps - 1;
     const int t2 = step + 2 < nsteps ? step + 2 : nsteps - 1;
     load_tiles(t2, Rload);
     const float* as = As + buf * G::A_TILE + fa;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
         // rolling refill: a[mt] is dead once its two MFMAs have issued
         if (kq + 1 < BK / 4) a[mt] = as[(kq + 1) * 4 * G::LDA + mt * 16];
       }
-      store_part(t1, buf ^ 1, Rstore, kq);
+      store_part(buf ^ 1, Rstore, kq);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
   Regs RA, RB;
   load_tiles(0, RA);
 #pragma unroll
-  for (int part = 0; part < 4; ++part) store_part(0, 0, RA, part);
+  for (int part = 0; part < 4; ++part) store_part(0, RA, part);
   load_tiles(nsteps > 1 ? 1 : 0, RB);
   __syncthreads();
   for (int step = 0; step < nsteps; step += 2) {
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
 }
 
 template <int MT, int BL>
-int launch_one(const radmmm_rowgemm_desc& d, int rows_per_tile, int nmt, int ntn, hipStream_t s) {
+int launch_one(const radmmm_rowgemm_desc& d, int rows_per_tile, int nmt, int ntn, int a_bytes, int b_bytes,
+               hipStream_t s) {
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm16_kernel<MT, BL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -291,26 +292,27 @@ int launch_one(const radmmm_rowgemm_desc& d, int rows_per_tile, int nmt, int ntn
     return 0;
   }();
   if (once) return once;
-  hipLaunchKernelGGL((rowgemm16_kernel<MT, BL>), dim3(nmt * ntn), dim3(256), SMEM_BYTES, s, d, rows_per_tile, nmt);
+  hipLaunchKernelGGL((rowgemm16_kernel<MT, BL>), dim3(nmt * ntn), dim3(256), SMEM_BYTES, s, d, rows_per_tile, nmt,
+                     a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm16_f32");
 }
 
 template <int BL>
-int launch_mt(int MT, const radmmm_rowgemm_desc& d, int rows_per_tile, int nmt, int ntn, hipStream_t s) {
+int launch_mt(int MT, const radmmm_rowgemm_desc& d, int rows_per_tile, int nmt, int ntn, int a_bytes, int b_bytes,
+              hipStream_t s) {
   switch (MT) {
-    case 4: return launch_one<4, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 6: return launch_one<6, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 8: return launch_one<8, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 10: return launch_one<10, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 12: return launch_one<12, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 13: return launch_one<13, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 14: return launch_one<14, BL>(d, rows_per_tile, nmt, ntn, s);
-    case 15: return launch_one<15, BL>(d, rows_per_tile, nmt, ntn, s);
-    default: return launch_one<16, BL>(d, rows_per_tile, nmt, ntn, s);
+    case 4: return launch_one<4, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 6: return launch_one<6, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 8: return launch_one<8, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 10: return launch_one<10, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 12: return launch_one<12, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 13: return launch_one<13, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    case 14: return launch_one<14, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);
+    default: return launch_one<15, BL>(d, rows_per_tile, nmt, ntn, a_bytes, b_bytes, s);   // MT=16 would spill (256 VGPRs)
   }
 }
 
-const int kMT[] = {4, 6, 8, 10, 12, 13, 14, 15, 16};
+const int kMT[] = {4, 6, 8, 10, 12, 13, 14, 15};
 
 }  // namespace
 
@@ -320,7 +322,7 @@ int radmmm::launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream) {
   const int ntn = (d.N + BN - 1) / BN;
   const int slots = 512;
   double best_cost = 1e300;
-  int best_mt = 16, best_rows = 256, best_nmt = (d.M + 255) / 256;
+  int best_mt = 15, best_rows = 240, best_nmt = (d.M + 239) / 240;
   for (int mt : kMT) {
     const int cap = mt * 16;
     const int nmt_min = (d.M + cap - 1) / cap;
@@ -351,6 +353,15 @@ int radmmm::launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream) {
       }
     }
   }
-  if (d.b_layout == 0) return launch_mt<0>(best_mt, d, best_rows, best_nmt, ntn, stream);
-  return launch_mt<1>(best_mt, d, best_rows, best_nmt, ntn, stream);
+  // byte extents of the operands for the buffer descriptors (the bounds check sees voffset only)
+  const long long items = d.M / d.T;
+  const long long a_last = d.a_item_stride ? (items - 1) * d.a_item_stride + (long long)(d.T - 1) * d.lda
+                                           : (long long)(d.M - 1) * d.lda;
+  const long long a_bytes = (a_last + d.K) * 4;
+  const long long b_bytes = d.b_layout == 0 ? (long long)d.N * d.ldb * 4 : (long long)BK * d.ldb * 4;
+  const long long b_total = ((long long)(d.taps - 1) * d.b_tap_stride +
+                             (d.b_layout == 0 ? (long long)d.N * d.ldb : (long long)d.K * d.ldb)) * 4;
+  if (a_bytes >= 0x7fffffffLL || b_total >= 0x7fffffffLL) return 1;   // caller falls back to the generic kernel
+  if (d.b_layout == 0) return launch_mt<0>(best_mt, d, best_rows, best_nmt, ntn, (int)a_bytes, (int)b_bytes, stream);
+  return launch_mt<1>(best_mt, d, best_rows, best_nmt, ntn, (int)a_bytes, (int)b_bytes, stream);
 }
