@@ -94,6 +94,26 @@ def time_dominant_kernel(N, T, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
 
 
+def time_wgrad_kernel(N, T, reps=10):
+    """Average duration of the in_layer weight-gradient launch (5 taps, split-K as the step uses)."""
+    from rad_mmm_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(1)
+    gy = torch.randn(N, 1024, generator=g).to(dev)
+    x = torch.randn(N, 1024, generator=g).to(dev)
+    lens = torch.full((N // T,), T, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        ops.wgrad_slabs(gy, 1024, x, 1024, 1024, T, lens, taps=5, dil=2, x_mask_mode=1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ops.wgrad_slabs(gy, 1024, x, 1024, 1024, T, lens, taps=5, dil=2, x_mask_mode=1)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
+
+
 def host_threads() -> int:
     """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
     (os.cpu_count() reports the whole host and oversubscribing it is catastrophically slow)."""
@@ -162,6 +182,9 @@ def main():
         kdur, kflop = time_dominant_kernel(N, Tg)
         print(json.dumps({"kernel": "rowgemm_f32 in_layer fwd", "M": N, "avg_launch_ms": kdur * 1e3,
                           "tflops": kflop / kdur / 1e12, "tile_env": os.environ.get("RADMMM_ROWGEMM_TILE", "16")}))
+        wdur, wflop = time_wgrad_kernel(N, Tg)
+        print(json.dumps({"kernel": "wgrad_f32 in_layer", "R": N, "avg_launch_ms": wdur * 1e3,
+                          "tflops": wflop / wdur / 1e12}))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

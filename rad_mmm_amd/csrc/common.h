@@ -12,6 +12,8 @@ void set_error(const char* fmt, ...);
 
 // rowgemm16_f32.hip: 16-row-granular tiling of radmmm_rowgemm_f32 (descriptor already validated)
 int launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream);
+// wgrad16_f32.hip: fast path of radmmm_wgrad_f32 (0 launched, <0 error, 1 not applicable)
+int launch_wgrad16(const radmmm_wgrad_desc& d, hipStream_t stream);
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -398,6 +398,14 @@ extern "C" int radmmm_wgrad_f32(const radmmm_wgrad_desc* d, radmmm_stream_t stre
   RADMMM_REQUIRE(d->ldgy % 4 == 0 && d->ldgy >= ((d->Mc + 3) & ~3) && radmmm::aligned16(d->GY), "wgrad: GY alignment (ldgy=%d Mc=%d)", d->ldgy, d->Mc);
   RADMMM_REQUIRE(d->ldx % 4 == 0 && d->ldx >= ((d->Nc + 3) & ~3) && radmmm::aligned16(d->X), "wgrad: X alignment (ldx=%d Nc=%d)", d->ldx, d->Nc);
   RADMMM_REQUIRE(d->ldp >= d->Nc, "wgrad: ldp < Nc");
+  static const bool generic_only = [] {
+    const char* e = getenv("RADMMM_ROWGEMM_TILE");
+    return e && atoi(e) == 32;
+  }();
+  if (!generic_only) {
+    const int rc = radmmm::launch_wgrad16(*d, static_cast<hipStream_t>(stream));
+    if (rc <= 0) return rc;
+  }
   const int ntm = (d->Mc + BM - 1) / BM, ntn = (d->Nc + BN - 1) / BN;
   static int once = ensure_smem(wgrad_f32_kernel);
   if (once) return once;

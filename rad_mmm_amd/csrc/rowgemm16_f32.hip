@@ -353,15 +353,16 @@ int radmmm::launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream) {
       }
     }
   }
-  // byte extents of the operands for the buffer descriptors (the bounds check sees voffset only)
+  // byte extents of the operands for the buffer descriptors
   const long long items = d.M / d.T;
   const long long a_last = d.a_item_stride ? (items - 1) * d.a_item_stride + (long long)(d.T - 1) * d.lda
                                            : (long long)(d.M - 1) * d.lda;
   const long long a_bytes = (a_last + d.K) * 4;
-  const long long b_bytes = d.b_layout == 0 ? (long long)d.N * d.ldb * 4 : (long long)BK * d.ldb * 4;
-  const long long b_total = ((long long)(d.taps - 1) * d.b_tap_stride +
+  // (measured on gfx950: the scalar offset IS part of the hardware range check, so the descriptor
+  //  spans the whole operand and invalid elements are flagged through the vector offset alone)
+  const long long b_bytes = ((long long)(d.taps - 1) * d.b_tap_stride +
                              (d.b_layout == 0 ? (long long)d.N * d.ldb : (long long)d.K * d.ldb)) * 4;
-  if (a_bytes >= 0x7fffffffLL || b_total >= 0x7fffffffLL) return 1;   // caller falls back to the generic kernel
+  if (a_bytes >= 0x7fffffffLL || b_bytes >= 0x7fffffffLL) return 1;   // caller falls back to the generic kernel
   if (d.b_layout == 0) return launch_mt<0>(best_mt, d, best_rows, best_nmt, ntn, (int)a_bytes, (int)b_bytes, stream);
   return launch_mt<1>(best_mt, d, best_rows, best_nmt, ntn, (int)a_bytes, (int)b_bytes, stream);
 }

@@ -115,6 +115,38 @@ def test_conv_dgrad_wgrad(R, Cin, Cout, dil):
     assert rel_err(gw, w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,dil,Tn,lens", [(16, 16, 1, 48, [48, 31, 7]), (144, 130, 4, 32, [32, 32, 20]),
+                                                   (64, 256, 8, 64, [64, 40, 33])])
+def test_wgrad_fast_path(R, Cin, Cout, dil, Tn, lens):
+    """T % 16 == 0 -> wgrad16 (buffer loads, one item per K step); same oracle as above."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(Cin + dil)
+    B = len(lens)
+    x = torch.randn(B, Cin, Tn, generator=g)
+    w = (torch.randn(Cout, Cin, 5, generator=g) * 0.2).requires_grad_(True)
+    mask = O.lengths_to_mask(torch.tensor(lens), Tn)[:, None].float()
+    y = F.conv1d(x * mask, w, None, padding=2 * dil, dilation=dil)
+    gy = torch.randn(B, Cout, Tn, generator=g)
+    (y * gy).sum().backward()
+    ldi, ldo = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    cl = lambda t, ld: F.pad(t.detach().permute(0, 2, 1).reshape(B * Tn, -1), (0, ld - t.shape[1])).contiguous().to(DEV)
+    P = ops.wgrad_slabs(cl(gy, ldo), Cout, cl(x, ldi), Cin, ldi, Tn, _lens_dev(lens), taps=5, dil=dil, x_mask_mode=1)
+    gw = P.sum(0)[:, :, :Cin].cpu().permute(1, 2, 0)
+    assert rel_err(gw, w.grad) < 2e-5
+    # unmasked variant (x_mask_mode 0: zero padding at item borders only) and explicit split-K
+    y2 = F.conv1d(x, w, None, padding=2 * dil, dilation=dil)
+    w.grad = None
+    (y2 * gy).sum().backward()
+    from rad_mmm_amd._lib import wgrad
+    S = 3
+    P2 = torch.full((S, 5, Cout, ldi), float("nan"), device=DEV)
+    wgrad(GY=cl(gy, ldo), ldgy=ldo, X=cl(x, ldi), ldx=ldi, P=P2, ldp=ldi, split_stride=P2.stride(0), R=B * Tn, Mc=Cout,
+          Nc=Cin, taps=5, dil=dil, T=Tn, lens=None, x_mask_mode=0, splits=S)
+    gw2 = P2.sum(0)[:, :, :Cin].cpu().permute(1, 2, 0)
+    assert rel_err(gw2, w.grad) < 2e-5
+
+
 def test_weightnorm_bwd(R):
     from oracle import radmmm_oracle as O
     from rad_mmm_amd import ops
