@@ -170,10 +170,12 @@ int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float*
                     int rows, int cols, int dact, int rowscale, int T, const int32_t* lens,
                     int taps, int dil, radmmm_stream_t stream);
 
-/* out[c] = sum_r w(r) * X[r, c];  row_weight 0: 1 ; 1: [t < lens[b]] ; 2: (cnt+1e-6)/taps over
- * valid rows (undoes the partial-conv ratio: bias gradient of PartialConv1d)          */
+/* out[c] = sum_r w(r) * f(X[r, c]), f = identity or square;  row_weight 0: 1 ; 1: [t < lens[b]] ;
+ * 2: (cnt+1e-6)/taps over valid rows (undoes the partial-conv ratio: bias gradient of
+ * PartialConv1d).  Also the masked first/second moments of MaskedBatchNorm1d
+ * (maskedbatchnorm1d.py:83-84).                                                          */
 int radmmm_colsum(const float* X, int ldx, float* out, float* scratch, int rows, int cols,
-                  int row_weight, int T, const int32_t* lens, int taps, int dil,
+                  int row_weight, int T, const int32_t* lens, int taps, int dil, int square,
                   radmmm_stream_t stream);
 int64_t radmmm_colsum_scratch_floats(int rows, int cols);
 
@@ -209,6 +211,25 @@ int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int ldq, float
 int radmmm_pq_spline_bwd(const float* x, int ldx, const float* q, int ldq, const float* gy,
                          int ldgy, const float* glogj, float* gx, int ldgx, float* gq, int ldgq,
                          int rows, int h, int K, radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * FiLM residual block tail (FiLMResBlock.forward, common.py:728-735) with the training-mode
+ * masked batch-norm (maskedbatchnorm1d.py:53-118) fused in, channels-last [rows, C]:
+ *   y = use_bn ? (h2 - mean) * invstd * w + b : h2 ;  t = y * (c1[:, 0:C] + 1) + c1[:, C:2C]
+ *   out = 0.5 * (leaky_relu(t) + x1r)
+ * mean/invstd are the caller's masked statistics (radmmm_colsum with square = 0/1).
+ * backward: gout -> gh2, gc1 [rows, 2C], gx1r, and dL/dw, dL/db of the batch-norm affine;
+ * n_valid = number of unmasked frames; scratch: radmmm_film_bwd_scratch_floats(rows, C).
+ * ------------------------------------------------------------------------------------ */
+int radmmm_film_fwd(const float* h2, int ldh, const float* c1, int ldc, const float* x1r, int ldx,
+                    const float* mean, const float* invstd, const float* w, const float* b,
+                    float* out, int ldo, int rows, int C, int use_bn, radmmm_stream_t stream);
+int radmmm_film_bwd(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
+                    const float* mean, const float* invstd, const float* w, const float* b,
+                    float n_valid, int T, const int32_t* lens, float* gh2, int ldgh, float* gc1,
+                    int ldgc, float* gx1r, int ldgx, float* gw, float* gb, float* scratch, int rows,
+                    int C, int use_bn, radmmm_stream_t stream);
+int64_t radmmm_film_bwd_scratch_floats(int rows, int C);
 
 /* ------------------------------------------------------------------------------------
  * Alignment attention (ConvAttention.forward, common.py:1262-1277), from projected

@@ -82,10 +82,12 @@ def _load() -> C.CDLL:
         "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
         "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
         "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p],
-        "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, p],
+        "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, i, p],
         "radmmm_masked_reduce": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_masked_reduce_bwd": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_fused_add_tanh_sigmoid_multiply": [p, p, i, p, i, i, i, p],
+        "radmmm_film_fwd": [p, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p],
+        "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
@@ -103,6 +105,7 @@ def _load() -> C.CDLL:
     for name, args in {"radmmm_colsum_scratch_floats": [i, i],
                        "radmmm_masked_reduce_scratch_floats": [i, i, i],
                        "radmmm_mas_scratch_bytes": [i, i, i],
+                       "radmmm_film_bwd_scratch_floats": [i, i],
                        "radmmm_stft_mel_scratch_floats": [i, i, i, i, i]}.items():
         fn = getattr(lib, name)
         fn.argtypes = args

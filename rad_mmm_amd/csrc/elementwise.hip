@@ -200,47 +200,69 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
 }
 
 // ------------------------------------------------------------------ column sums
-constexpr int CS_ROWS_PER_BLOCK = 512;
+// Stage 1: block (bx, by) sums rows [by*CS_ROWS, +CS_ROWS) of the 1024-column slab bx; each thread
+// owns 4 adjacent columns (float4 loads: a block reads 4 KiB contiguous per row).  Stage 2 adds
+// the per-chunk partials.  Deterministic (no atomics).
+constexpr int CS_ROWS_PER_BLOCK = 64;
+__device__ __forceinline__ float colsum_row_weight(int r, int row_weight, int T, const int* lens, int taps,
+                                                   int dil) {
+  if (!row_weight) return 1.f;
+  const int b = r / T, t = r - b * T;
+  const int len = lens ? lens[b] : T;
+  if (t >= len) return 0.f;
+  if (row_weight != 2) return 1.f;
+  int cnt = 0;
+  for (int k = 0; k < taps; ++k) {
+    const int ts = t + (k - taps / 2) * dil;
+    cnt += (ts >= 0 && ts < len) ? 1 : 0;
+  }
+  return ((float)cnt + 1e-6f) / (float)taps;
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
     const float* __restrict__ X, int ldx, float* __restrict__ part, int rows, int cols,
-    int row_weight, int T, const int* __restrict__ lens, int taps, int dil) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+    int row_weight, int T, const int* __restrict__ lens, int taps, int dil, int square) {
+  const int c = blockIdx.x * 1024 + threadIdx.x * 4;
   const int r0 = blockIdx.y * CS_ROWS_PER_BLOCK;
   int r1 = r0 + CS_ROWS_PER_BLOCK;
   if (r1 > rows) r1 = rows;
-  float acc = 0.f;
-  for (int r = r0 + rl; r < r1; r += 4) {
-    float w = 1.f;
-    if (row_weight) {
-      const int b = r / T, t = r - b * T;
-      const int len = lens ? lens[b] : T;
-      if (t >= len) w = 0.f;
-      else if (row_weight == 2) {
-        int cnt = 0;
-        for (int k = 0; k < taps; ++k) {
-          const int ts = t + (k - taps / 2) * dil;
-          cnt += (ts >= 0 && ts < len) ? 1 : 0;
-        }
-        w = ((float)cnt + 1e-6f) / (float)taps;
+  const bool vec = (ldx % 4 == 0) && radmmm::aligned16(X) && c + 3 < cols;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    for (int r = r0; r < r1; ++r) {
+      const float w = colsum_row_weight(r, row_weight, T, lens, taps, dil);   // block-uniform
+      float4 v;
+      if (vec) {
+        v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+      } else {
+        const float* q = X + (long long)r * ldx + c;
+        v.x = q[0];
+        v.y = c + 1 < cols ? q[1] : 0.f;
+        v.z = c + 2 < cols ? q[2] : 0.f;
+        v.w = c + 3 < cols ? q[3] : 0.f;
       }
+      if (square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
+      a0 = fmaf(w, v.x, a0); a1 = fmaf(w, v.y, a1); a2 = fmaf(w, v.z, a2); a3 = fmaf(w, v.w, a3);
     }
-    if (c < cols) acc = fmaf(w, X[(long long)r * ldx + c], acc);
+    float* o = part + (long long)blockIdx.y * cols + c;
+    o[0] = a0;
+    if (c + 1 < cols) o[1] = a1;
+    if (c + 2 < cols) o[2] = a2;
+    if (c + 3 < cols) o[3] = a3;
   }
-  sh[rl][cl] = acc;
-  __syncthreads();
-  if (rl == 0 && c < cols)
-    part[(long long)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part,
                                                            float* __restrict__ out, int nparts,
                                                            int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  // one wave per 64 columns x a slice of the partials, then a 4-way LDS combine
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long long)p * cols + c];
-  out[c] = s;
+  if (c < cols)
+    for (int p = pl; p < nparts; p += 4) s += part[(long long)p * cols + c];
+  sh[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && c < cols) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 
 // ------------------------------------------------------------------ masked reductions
@@ -419,16 +441,16 @@ extern "C" int64_t radmmm_colsum_scratch_floats(int rows, int cols) {
 }
 
 extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch, int rows, int cols,
-                             int row_weight, int T, const int32_t* lens, int taps, int dil,
+                             int row_weight, int T, const int32_t* lens, int taps, int dil, int square,
                              radmmm_stream_t stream) {
   RADMMM_REQUIRE(X && out && scratch, "colsum: null pointer");
   RADMMM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, "colsum: bad dims");
   RADMMM_REQUIRE(row_weight == 0 || (T > 0 && rows % T == 0), "colsum: rows must be a multiple of T");
   RADMMM_REQUIRE(row_weight != 2 || (taps >= 1 && dil >= 1), "colsum: taps/dil");
   const int nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts), dim3(256), 0, ST(stream),
-                     X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), scratch,
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 1023) / 1024, nparts), dim3(256), 0, ST(stream),
+                     X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil, square);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, ST(stream), scratch,
                      out, nparts, cols);
   return radmmm::check_launch("colsum");
 }

@@ -70,7 +70,11 @@ class FlowStep(nn.Module):
             print("initialized invertible conv")
         W_eff, b_eff = self.effective_weight(col_offset)
         log_det_W = conv.log_det()
-        z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T)
+        if self.use_spline:
+            n_valid = int(seq_lens.lengths_host.sum())
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid)
+        else:
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T)
         return z_out, log_det_W, log_s
 
 

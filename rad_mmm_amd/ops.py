@@ -69,12 +69,12 @@ def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0)):
 
 
 def colsum(X: torch.Tensor, cols: int, row_weight: int = 0, T: int = 1,
-           lens: Optional[torch.Tensor] = None, taps: int = 1, dil: int = 1) -> torch.Tensor:
+           lens: Optional[torch.Tensor] = None, taps: int = 1, dil: int = 1, square: bool = False) -> torch.Tensor:
     rows, ld = X.shape
     out = _empty(cols, like=X)
     scratch = _empty(int(lib.radmmm_colsum_scratch_floats(rows, cols)), like=X)
     check(lib.radmmm_colsum(ptr(X), ld, ptr(out), ptr(scratch), rows, cols, row_weight, T,
-                            ptr(lens), taps, dil, stream()), "colsum")
+                            ptr(lens), taps, dil, 1 if square else 0, stream()), "colsum")
     return out
 
 
