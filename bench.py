@@ -130,7 +130,7 @@ def host_threads() -> int:
 def cpu_baseline(cfg, sd, budget_s=25.0):
     """The CPU oracle (fp32 restatement of the reference, kind="port") timed on the host cores
     on a bounded sample of the same workload: the config-2 architecture (8 flows) at the
-    largest of (B,T) in {(2,800),(1,800),(1,400),(1,200)} whose predicted time fits the
+    largest of (B,T) in {(16,800),(8,800),(4,800),(2,800),(1,800),(1,400),(1,200)} whose predicted time fits the
     budget (prediction from a B=1,T=100 probe step; cost is linear in frames)."""
     from oracle import radmmm_oracle as O
     threads = host_threads()
@@ -155,7 +155,7 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
     per_frame = probe / 100.0
     B, T = 1, 100
     dt = probe
-    for cand in ((2, 800), (1, 800), (1, 400), (1, 200)):
+    for cand in ((16, 800), (8, 800), (4, 800), (2, 800), (1, 800), (1, 400), (1, 200)):
         if per_frame * cand[0] * cand[1] <= budget_s:
             B, T = cand
             dt, _ = one(B, T)
@@ -195,8 +195,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RADMMM_FORCE_DIST") == "1"   # the latter: RCCL smoke test on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import rad_mmm_amd  # noqa: F401  (loads libradmmm_hip.so; no fallback)
@@ -229,18 +233,18 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -277,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

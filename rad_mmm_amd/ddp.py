@@ -40,6 +40,7 @@ class BucketedGradReducer:
                  process_group=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()      # reduce even at world size 1 (RCCL smoke test)
         groups: "OrderedDict[str, List[torch.nn.Parameter]]" = OrderedDict()
         for name, p in module.named_parameters():
             if p.requires_grad:
@@ -63,7 +64,7 @@ class BucketedGradReducer:
     def _make_hook(self, bucket):
         def hook(param):
             bucket["pending"] -= 1
-            if bucket["pending"] == 0 and self.world > 1:
+            if bucket["pending"] == 0 and self.active:
                 # RCCL stream waits for the kernels already queued on the compute stream, then
                 # runs concurrently with the rest of backward
                 bucket["handle"] = dist.all_reduce(bucket["flat"], op=dist.ReduceOp.SUM, group=self.pg,
@@ -84,7 +85,7 @@ class BucketedGradReducer:
 
     def finish(self) -> None:
         """Wait for the outstanding reductions and turn sums into means (call after backward)."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             if b["handle"] is None:           # a parameter without gradient this step
@@ -92,7 +93,8 @@ class BucketedGradReducer:
         inv = 1.0 / self.world
         for b in self.buckets:
             b["handle"].wait()
-            b["flat"].mul_(inv)
+            if self.world > 1:
+                b["flat"].mul_(inv)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=None) -> None:

@@ -125,6 +125,8 @@ class RADMMMFlow(nn.Module):
             decoder_cond_dims = n_speaker_dim + n_accent_dim + (n_text_dim + n_f0_dims + n_energy_avg_dims) * n_group_size
         self.decoder_cond_dims = decoder_cond_dims
         self.decoder_out_dims = n_mel_channels
+        self.lstm_two_streams = use_context_lstm and context_lstm_norm is None   # see _bilstm_two_streams
+        self._side_stream = None
         # ---- decoders.py:105-143
         self.matrix_decomposition = "LUS"
         self.use_partial_padding = use_partial_padding
@@ -190,12 +192,38 @@ class RADMMMFlow(nn.Module):
         ul = torch.div(seq_lens.lengths_host, g, rounding_mode="floor")
         self.context_lstm.flatten_parameters()
         if int(ul.min()) == Tg:                       # fixed-length batch: packing is the identity
-            y, _ = self.context_lstm(x)
+            y = self._bilstm_two_streams(x) if self.lstm_two_streams else self.context_lstm(x)[0]
         else:
             packed = nn.utils.rnn.pack_padded_sequence(x, ul, batch_first=True, enforce_sorted=False)
             out, _ = self.context_lstm(packed)
             y, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=Tg)
         return y.contiguous()
+
+    def _bilstm_two_streams(self, x):
+        """Fixed-length batches only: run the two directions of the bi-LSTM (models/radmmm.py:141-146)
+        as two unidirectional MIOpen LSTMs on two HIP streams.  Each direction is T' strictly
+        sequential steps of tiny kernels that leave the GPU almost idle, so overlapping them (and,
+        in backward, their gradients: autograd replays each node on its forward stream) hides
+        one direction behind the other.  Same weights, same arithmetic."""
+        lstm = self.context_lstm
+        names_f = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+        wf = [getattr(lstm, n) for n in names_f]
+        wr = [getattr(lstm, n + "_reverse") for n in names_f]
+        B = x.shape[0]
+        H = lstm.hidden_size
+        h0 = x.new_zeros(1, B, H)
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            yr, _, _ = torch._VF.lstm(torch.flip(x, [1]), (h0, h0), wr, True, 1, 0.0, self.training, False, True)
+            yr = torch.flip(yr, [1])
+        yf, _, _ = torch._VF.lstm(x, (h0, h0), wf, True, 1, 0.0, self.training, False, True)
+        cur.wait_stream(side)
+        yr.record_stream(cur)
+        return torch.cat((yf, yr), 2)
 
     def preprocess_context(self, context, spk_vecs, out_lens=None, f0=None, energy_avg=None, accent_vecs=None):
         """Reference-layout wrapper: returns [B, D, T']."""

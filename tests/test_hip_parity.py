@@ -328,6 +328,37 @@ def test_decoder_golden(R, golden, tag):
     print(f"{tag}: worst grad-norm rel err {worst:.2e}")
 
 
+def test_context_lstm_two_streams_matches_packed_path(R):
+    """The two-stream bi-LSTM (fixed-length fast path) must equal the stock bidirectional call."""
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    torch.manual_seed(0)
+    dec = RADMMMFlow(n_speaker_dim=16, use_accent=True, n_accent_dim=8, n_text_dim=512, n_group_size=2, n_flows=1,
+                     n_f0_dims=1, n_energy_avg_dims=1, use_accent_emb_for_decoder=True).to(DEV).train()
+    B, Tn = 4, 96
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(B, 512, Tn, generator=g).to(DEV).requires_grad_(True)
+    spk = torch.randn(B, 16, generator=g).to(DEV)
+    acc = torch.randn(B, 8, generator=g).to(DEV)
+    f0 = torch.rand(B, Tn, generator=g).to(DEV)
+    en = torch.rand(B, Tn, generator=g).to(DEV)
+    sl = SequenceLength(torch.full((B,), Tn, device=DEV))
+    outs, grads = [], []
+    for two in (True, False):
+        dec.lstm_two_streams = two
+        dec.zero_grad()
+        ctx.grad = None
+        y = dec.preprocess_context_cl(ctx, spk, sl, f0, en, acc)
+        (y * torch.linspace(-1, 1, y.shape[2], device=DEV)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append(y.detach().cpu())
+        grads.append((ctx.grad.cpu().clone(), dec.context_lstm.weight_hh_l0_reverse.grad.cpu().clone(),
+                      dec.context_lstm.weight_ih_l0.grad.cpu().clone()))
+    assert rel_err(outs[0], outs[1]) < 1e-5
+    for a, b in zip(grads[0], grads[1]):
+        assert rel_err(a, b) < 1e-4
+
+
 def test_decoder_full_size_item_independence(R):
     """BASELINE config 2 shape (8 flows, B=32, T=800): item 0 of the full batch must equal the
     CPU oracle run on that item alone (items are independent given initialised weights), and
