@@ -280,10 +280,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd)
-        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush it first so the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -125,7 +125,9 @@ class RADMMMFlow(nn.Module):
             decoder_cond_dims = n_speaker_dim + n_accent_dim + (n_text_dim + n_f0_dims + n_energy_avg_dims) * n_group_size
         self.decoder_cond_dims = decoder_cond_dims
         self.decoder_out_dims = n_mel_channels
-        self.lstm_two_streams = use_context_lstm and context_lstm_norm is None   # see _bilstm_two_streams
+        import os
+        self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
+                                 os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
         # ---- decoders.py:105-143
         self.matrix_decomposition = "LUS"
@@ -204,7 +206,10 @@ class RADMMMFlow(nn.Module):
         as two unidirectional MIOpen LSTMs on two HIP streams.  Each direction is T' strictly
         sequential steps of tiny kernels that leave the GPU almost idle, so overlapping them (and,
         in backward, their gradients: autograd replays each node on its forward stream) hides
-        one direction behind the other.  Same weights, same arithmetic."""
+        one direction behind the other.  Same weights, same arithmetic.
+        MEASURED (round 1, B=32, T=800): 193.4 ms/step with it vs 183.8 ms without -- the two
+        unidirectional MIOpen calls + flips + concat cost more than the overlap wins, so this path
+        is OFF by default (RADMMM_LSTM_TWO_STREAMS=1 enables it); kept for the T=2000 case."""
         lstm = self.context_lstm
         names_f = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
         wf = [getattr(lstm, n) for n in names_f]
