@@ -32,6 +32,10 @@ RADTTS = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8,
               scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
               n_conv_layers_per_step=4, n_flows=8)
 
+# BASELINE configs[4]: 16 kHz / RADMMM dims (n_text_dim 520, accent not in decoder) with 2 spline steps
+RADMMM_SPLINES = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
+CONFIGS = {"radtts": RADTTS, "radmmm_splines": RADMMM_SPLINES}
+
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 
@@ -172,6 +176,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="radtts",
+                    help="radtts = BASELINE configs[1] (headline); radmmm_splines = configs[4] architecture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     args = ap.parse_args()
@@ -210,8 +216,9 @@ def main():
     from rad_mmm_amd.loss import RADMMMLoss
     from rad_mmm_amd import synthetic as O
 
-    cfg, sd = procedural_state(RADTTS)
-    dec = RADMMMFlow(use_accent=True, **RADTTS)
+    CFG = CONFIGS[args.config]
+    cfg, sd = procedural_state(CFG)
+    dec = RADMMMFlow(use_accent=True, **CFG)
     dec.load_state_dict(sd)
     dec = dec.to(dev).train()
     crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)
@@ -263,8 +270,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (procedural random-init weights, N(2.5,0.5) mel, fixed length)",
-            "config": {"workload": "RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
-                                   "D=1048) fwd+NLL+bwd", "batch_per_gpu": B, "n_mel": 80, "frames": T,
+            "config": {"workload": ("RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
+                                    "D=1048) fwd+NLL+bwd") if args.config == "radtts" else
+                                   ("RADMMM 16 kHz-dims flow decoder (configs/RADMMM_16khz_model_config.yaml + "
+                                    "n_splines=2: 2 spline/FiLM + 6 affine/WN flows, D=1056) fwd+NLL+bwd"),
+                       "batch_per_gpu": B, "n_mel": 80, "frames": T,
                        "global_batch": B * world, "parallelism": f"dp{world}", "precision": "fp32 MFMA (exact)"},
             "loss_mel": loss_val,
             "roofline": {"bound": "mfma", "kernel": "rowgemm_f32_kernel<0> (WN in_layer conv fwd, M=%d N=1024 K=5x1024)" % N,

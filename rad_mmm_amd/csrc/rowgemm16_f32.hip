@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm16_kernel(const radmmm_rowgemm_
     for (int mt = 0; mt < MT; ++mt) a[mt] = as[mt * 16];
     bq[0][0] = bs[0];
     bq[0][1] = bs[16];
+    // issue the whole first k-quad's fragment reads as one batch right after the barrier (one
+    // exposed LDS latency instead of one per MFMA group: the compiler otherwise sinks them)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kq = 0; kq < BK / 4; ++kq) {
       const int cur = kq & 1, nx = cur ^ 1;
