@@ -503,6 +503,23 @@ def mas_width1(attn_map: np.ndarray) -> np.ndarray:
     return opt
 
 
+def mas_width1_c(attn_map: np.ndarray) -> np.ndarray:
+    """Same search through the plain-C restatement (oracle/mas_ref.c, built by oracle/Makefile);
+    the log is taken here with numpy exactly as alignment.py:36 does."""
+    import ctypes
+    import os
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmas_ref.so")
+    lib = ctypes.CDLL(so)
+    T1, T2 = attn_map.shape
+    with np.errstate(divide="ignore"):
+        lp = np.ascontiguousarray(np.log(attn_map.astype(np.float32)))
+    opt = np.zeros((T1, T2), dtype=np.float32)
+    rc = lib.mas_width1_ref(lp.ctypes.data_as(ctypes.c_void_p), T1, T2, opt.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError(f"mas_width1_ref failed: {rc}")
+    return opt.astype(attn_map.dtype)
+
+
 def binarize_attention(attn: Tensor, in_lens: Tensor, out_lens: Tensor) -> Tensor:
     """TTSModel.binarize_attention.  tts_lightning_modules.py:270-284.
     attn [B,1,T_mel_max,T_txt_max] -> same shape 0/1."""

@@ -144,8 +144,11 @@ extern "C" int radmmm_film_bwd(const float* h2, int ldh, const float* c1, int ld
                        ldg, mean, invstd, w, b, scratch, rows, C);
     hipLaunchKernelGGL(film_bwd_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, scratch, nparts, C, S);
     // dL/db = S1, dL/dw = S2
-    hipMemcpyAsync(gb, S, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(gw, S + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    if (hipMemcpyAsync(gb, S, sizeof(float) * C, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(gw, S + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      radmmm::set_error("film_bwd: hipMemcpyAsync failed");
+      return -2;
+    }
   }
   hipLaunchKernelGGL(film_bwd_apply_kernel, dim3(grid_for((long long)rows * C)), dim3(256), 0, s, h2, ldh, c1, ldc,
                      gout, ldg, mean, invstd, w, b, S, use_bn ? 1.f / n_valid : 0.f, T > 0 ? T : 1, lens, gh2, ldgh, gc1,

@@ -1,0 +1,147 @@
+"""GPU edge cases: batch of one, odd / tiny lengths, group size 1, data-dependent whitening init,
+non-default scaling functions and padding modes -- HIP path vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(d):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()}
+
+
+def _run_both(kw, B, Tn, lens, seed=5, initialized=True, wn_scale=None):
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    if not initialized:
+        sd["flows.0.invtbl_conv.initialized"] = torch.tensor(False)
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    b = T(O.synthetic_batch(B, Tn, cfg, seed, ragged=False))
+    lens = torch.tensor(lens)
+    b["lengths"] = lens
+    for i in range(B):
+        L = int(lens[i])
+        b["mel"][i, :, L:] = 0
+        b["context"][i, :, L:] = 0
+        b["f0"][i, L:] = 0
+        b["energy"][i, L:] = 0
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+    lm = RADMMMLoss(n_group_size=cfg.n_group_size)(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    # oracle (with the same data-dependent init if requested)
+    p = {k: v.clone() for k, v in sd.items()}
+    if not initialized:
+        z0 = O.squeeze_time(b["mel"], cfg.n_group_size)
+        mean, ud, up = O.whiten_initialize(z0, lens // cfg.n_group_size)
+        p["flows.0.invtbl_conv.input_mean"], p["flows.0.invtbl_conv.upper_diag"], p["flows.0.invtbl_conv.upper"] = mean, ud, up
+    p = {k: (v.requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and not k.endswith((".p", "lower_diag", "input_mean")) else v)
+         for k, v in p.items()}
+    ro = O.decoder_forward(p, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
+    lo, _ = O.decoder_loss(ro, b["lengths"], cfg.n_group_size)
+    lo.backward()
+    return dec, out, lm, p, ro, lo, cfg
+
+
+BASE = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+            n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+            scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+            n_conv_layers_per_step=4, n_flows=3)
+
+
+def _check(dec, out, lm, p, ro, lo, cfg, lens, tol=1e-4):
+    ul = torch.tensor(lens) // cfg.n_group_size
+    Tg = ro["z_mel"].shape[2]
+    m = (torch.arange(Tg)[None] < ul[:, None])[:, None].expand_as(ro["z_mel"])
+    zh = out["z_mel"].detach().cpu()[:, :, :Tg]
+    assert rel_err(zh[m], ro["z_mel"].detach()[m]) < tol
+    assert abs(float(lm.detach()) - float(lo.detach())) < tol * abs(float(lo.detach()))
+    params = dict(dec.named_parameters())
+    for n in ("flows.2.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
+              "flows.0.coupling_tfn.affine_param_predictor.start.weight_g",
+              "flows.1.invtbl_conv.lower", "context_lstm.weight_hh_l0_reverse",
+              "flows.1.coupling_tfn.affine_param_predictor.end.weight"):
+        a, b = params[n].grad.cpu(), p[n].grad
+        assert rel_err(a, b) < 10 * tol, n
+
+
+def test_batch_of_one_odd_length():
+    lens = [31]
+    r = _run_both(BASE, 1, 31, lens)
+    assert r[1]["z_mel"].shape == (1, 160, 15)          # trailing frame dropped by the squeeze
+    _check(*r, lens)
+
+
+def test_tiny_item_in_ragged_batch():
+    lens = [64, 37, 2]                                   # T' = 32, 18, 1
+    r = _run_both(BASE, 3, 64, lens)
+    _check(*r, lens)
+
+
+def test_group_size_one():
+    kw = dict(BASE, n_group_size=1)
+    lens = [40, 29]
+    r = _run_both(kw, 2, 40, lens)
+    assert r[1]["z_mel"].shape == (2, 80, 40)
+    _check(*r, lens)
+
+
+def test_data_dependent_whitening_init():
+    """flows.0.invtbl_conv initialises itself from the first training batch (common.py:569-591)."""
+    lens = [256, 231, 200, 187]
+    r = _run_both(BASE, 4, 256, lens, initialized=False)
+    dec, p = r[0], r[3]
+    c = dec.flows[0].invtbl_conv
+    assert bool(c.initialized)
+    assert rel_err(c.input_mean.cpu(), p["flows.0.invtbl_conv.input_mean"]) < 1e-5
+    assert rel_err(c.upper_diag.detach().cpu(), p["flows.0.invtbl_conv.upper_diag"].detach()) < 2e-4
+    _check(*r, lens, tol=5e-4)
+
+
+@pytest.mark.parametrize("scaling", ["exp", "sigmoid"])
+def test_other_scaling_functions(scaling):
+    kw = dict(BASE, scaling_fn=scaling, n_flows=2)
+    lens = [48, 30]
+    r = _run_both(kw, 2, 48, lens)
+    _check(*r, lens)
+
+
+def test_no_partial_padding():
+    kw = dict(BASE, use_partial_padding=False, n_flows=2)
+    lens = [48, 33]
+    r = _run_both(kw, 2, 48, lens)
+    _check(*r, lens)
+
+
+def test_rowgemm_degenerate_shapes():
+    from rad_mmm_amd._lib import rowgemm
+    g = torch.Generator().manual_seed(2)
+    for (M, N, K) in [(1, 1, 16), (5, 3, 16), (17, 130, 32), (1, 1, 4), (33, 7, 20)]:
+        A = torch.randn(M, (K + 3) // 4 * 4, generator=g)
+        Bm = torch.randn(N, (K + 3) // 4 * 4, generator=g)
+        C = torch.full((M, (N + 3) // 4 * 4), float("nan"), device=DEV)
+        rowgemm(A=A.to(DEV), lda=A.shape[1], B=Bm.to(DEV), ldb=Bm.shape[1], b_layout=0, C=C, ldc=C.shape[1], M=M, N=N,
+                K=K, T=M)
+        ref = A[:, :K].double() @ Bm[:, :K].double().t()
+        assert rel_err(C[:, :N].cpu().double(), ref) < 2e-6, (M, N, K)
+
+
+def test_masked_reduce_with_empty_item():
+    from rad_mmm_amd import ops
+    x = torch.randn(3, 5, 9, device=DEV)
+    lens = torch.tensor([9, 0, 4], dtype=torch.int32, device=DEV)
+    m = (torch.arange(9, device=DEV)[None] < lens[:, None])[:, None].float()
+    assert abs(float(ops.masked_sum(x, lens)) - float((x * m).sum())) < 1e-5
+    assert abs(float(ops.masked_sumsq(x, lens)) - float(((x * m) ** 2).sum())) < 1e-4

@@ -176,6 +176,25 @@ def test_mas_cases_bit_exact(golden):
     assert i == 5
 
 
+def test_mas_c_restatement_bit_exact(golden):
+    """The plain-C MAS (oracle/mas_ref.c) against the reference's outputs and the numpy oracle."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "oracle")])
+    g = golden("attention_tiny.npz")
+    i = 0
+    while f"mas.{i}.in" in g:
+        out = O.mas_width1_c(g[f"mas.{i}.in"].copy())
+        assert np.array_equal(out, g[f"mas.{i}.out"]), i
+        i += 1
+    r = np.random.Generator(np.random.PCG64(11))
+    for (a, b) in [(200, 61), (97, 97), (800, 150)]:
+        m = r.random((a, b)).astype(np.float32) ** 4 + 1e-6
+        m /= m.sum(1, keepdims=True)
+        assert np.array_equal(O.mas_width1_c(m.copy()), O.mas_width1(m.copy()))
+
+
 def test_stft_magnitude(golden):
     g = golden("stft_tiny.npz")
     m = O.stft_magnitude(g["audio"], 64, 16, 64)
