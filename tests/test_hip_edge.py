@@ -69,7 +69,8 @@ def _check(dec, out, lm, p, ro, lo, cfg, lens, tol=1e-4):
     assert rel_err(zh[m], ro["z_mel"].detach()[m]) < tol
     assert abs(float(lm.detach()) - float(lo.detach())) < tol * abs(float(lo.detach()))
     params = dict(dec.named_parameters())
-    for n in ("flows.2.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
+    last = cfg.n_flows - 1
+    for n in (f"flows.{last}.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
               "flows.0.coupling_tfn.affine_param_predictor.start.weight_g",
               "flows.1.invtbl_conv.lower", "context_lstm.weight_hh_l0_reverse",
               "flows.1.coupling_tfn.affine_param_predictor.end.weight"):
