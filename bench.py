@@ -98,6 +98,28 @@ def time_dominant_kernel(N, T, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
 
 
+def time_h3_probe(N, reps=20):
+    """EXPERIMENTAL: the same GEMM volume as the dominant kernel on the split-f16 path (no taps)."""
+    from rad_mmm_amd._lib import lib, check, ptr, stream
+    dev = torch.device("cuda", torch.cuda.current_device())
+    K = 5120
+    mk = lambda r: (torch.empty(r, K, dtype=torch.float16, device=dev).normal_(), torch.empty(r, K, dtype=torch.float16, device=dev).normal_(0, 1e-3))
+    (Ah, Al), (Bh, Bl) = mk(N), mk(1024)
+    C = torch.empty(N, 1024, device=dev)
+    run = lambda: check(lib.radmmm_h3gemm_nt(ptr(Ah), ptr(Al), K, ptr(Bh), ptr(Bl), K, ptr(C), 1024, N, 1024, K, 1.0,
+                                            stream()), "h3gemm")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * K
+
+
 def time_wgrad_kernel(N, T, reps=10):
     """Average duration of the in_layer weight-gradient launch (5 taps, split-K as the step uses)."""
     from rad_mmm_amd import ops
@@ -188,6 +210,13 @@ def main():
         kdur, kflop = time_dominant_kernel(N, Tg)
         print(json.dumps({"kernel": "rowgemm_f32 in_layer fwd", "M": N, "avg_launch_ms": kdur * 1e3,
                           "tflops": kflop / kdur / 1e12, "tile_env": os.environ.get("RADMMM_ROWGEMM_TILE", "16")}))
+        try:
+            hdur, hflop = time_h3_probe(N)
+            print(json.dumps({"kernel": "EXPERIMENTAL h3gemm_nt (split-f16 x3) M=%d N=1024 K=5120" % N,
+                              "avg_launch_ms": hdur * 1e3, "effective_tflops": hflop / hdur / 1e12,
+                              "mfma_tflops": 3 * hflop / hdur / 1e12}))
+        except Exception as e:  # the probe is optional
+            print(json.dumps({"kernel": "h3 probe", "error": str(e)}))
         wdur, wflop = time_wgrad_kernel(N, Tg)
         print(json.dumps({"kernel": "wgrad_f32 in_layer", "R": N, "avg_launch_ms": wdur * 1e3,
                           "tflops": wflop / wdur / 1e12}))

@@ -263,6 +263,19 @@ int radmmm_stft_mel(const float* audio, const float* basis, const float* mel_bas
                     float clip, radmmm_stream_t stream);
 int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_mel);
 
+/* ------------------------------------------------------------------------------------
+ * EXPERIMENTAL (round-1 probe; not used by the product path): fp32-class GEMM on the f16 matrix
+ * cores by operand splitting (x*scale = hi + lo in fp16; A.B ~= Ah.Bh + Ah.Bl + Al.Bh with fp32
+ * accumulate).  radmmm_split_f16 writes hi/lo [rows][ldh] halves (ldh % 8 == 0, zero padded);
+ * radmmm_h3gemm_nt computes C[M,N] = out_scale * (A B^T) from K-contiguous split operands
+ * (K % 32 == 0).  See DESIGN.md §8 for the measured rate and error.
+ * ------------------------------------------------------------------------------------ */
+int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int ldh, int rows, int cols,
+                     float scale, radmmm_stream_t stream);
+int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, const void* Bl, int ldb,
+                     float* C, int ldc, int M, int N, int K, float out_scale,
+                     radmmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

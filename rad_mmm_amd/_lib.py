@@ -88,6 +88,8 @@ def _load() -> C.CDLL:
         "radmmm_fused_add_tanh_sigmoid_multiply": [p, p, i, p, i, i, i, p],
         "radmmm_film_fwd": [p, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p],
         "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
+        "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
+        "radmmm_h3gemm_nt": [p, p, i, p, p, i, p, i, i, i, i, f, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
