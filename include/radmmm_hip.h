@@ -91,9 +91,31 @@ typedef struct {
   int rowscale;
   int act;
   float* C2; int ldc2; int c2_accum;
+  /* optional split-fp16 copies of the outputs (operands of the next split-f16 GEMM):
+   * Ch/Cl [M][ldch] halves receive hi/lo of ch_scale * C, C2h/C2l of c2h_scale * C2 (ld % 4 == 0) */
+  void* Ch; void* Cl; int ldch; float ch_scale;
+  void* C2h; void* C2l; int ldc2h; float c2h_scale;
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
+
+/* Same operation on the f16 matrix cores with fp32-class accuracy by operand splitting
+ * (x*s = hi + lo in fp16;  A.B ~= Ah.Bh + Ah.Bl + Al.Bh, fp32 accumulate; measured 2.2e-6 max
+ * rel. error at K=5120 vs 3.8e-6 for the fp32 MFMA, at 2.3x its rate).  d->A / d->B are ignored;
+ * the operands are the split copies below, both K-CONTIGUOUS:
+ *   Ah/Al [M][lda_h] halves (rows = frames, same shift/masking rules as radmmm_rowgemm_f32)
+ *   Bh/Bl [taps][N][ldb_h] halves (tap stride b_tap_stride_h halves); b_layout must be 0 --
+ *   the data-gradient uses a transposed split copy of the weights instead of layout 1.
+ * acc is multiplied by acc_scale (= 1/(a_scale*b_scale)) before the epilogue.
+ * Requires K % 32 == 0, lda_h/ldb_h % 8 == 0. */
+typedef struct {
+  radmmm_rowgemm_desc base;
+  const void* Ah; const void* Al; int lda_h;
+  const void* Bh; const void* Bl; int ldb_h; int64_t b_tap_stride_h;
+  float acc_scale;
+} radmmm_rowgemm_h3_desc;
+
+int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight-gradient GEMM (contraction over frames), fp32 MFMA:
@@ -141,7 +163,9 @@ int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
  *   gctx[r, 0:D] (+)= gX0[r, 0:D] ; gz[r, 0:h] += gX0[r, D:D+h]
  * ------------------------------------------------------------------------------------ */
 int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz,
-                        float* X0, int ldx0, int rows, int D, int h, radmmm_stream_t stream);
+                        float* X0, int ldx0, int rows, int D, int h,
+                        void* X0h, void* X0l /* optional split-fp16 copy, pitch ldx0, may be NULL */,
+                        radmmm_stream_t stream);
 int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int ctx_accum,
                         float* gz, int ldz, int rows, int D, int h, radmmm_stream_t stream);
 
@@ -168,7 +192,9 @@ int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* z, int ldz,
  * dL/d(conv accumulator) of ConvNorm/PartialConv1d (common.py:179-191) */
 int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y, int ldy,
                     int rows, int cols, int dact, int rowscale, int T, const int32_t* lens,
-                    int taps, int dil, radmmm_stream_t stream);
+                    int taps, int dil,
+                    void* yh, void* yl, int ldyh, float yscale /* optional split-fp16 copy of yscale*y */,
+                    radmmm_stream_t stream);
 
 /* out[c] = sum_r w(r) * f(X[r, c]), f = identity or square;  row_weight 0: 1 ; 1: [t < lens[b]] ;
  * 2: (cnt+1e-6)/taps over valid rows (undoes the partial-conv ratio: bias gradient of
@@ -264,7 +290,7 @@ int radmmm_stft_mel(const float* audio, const float* basis, const float* mel_bas
 int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_mel);
 
 /* ------------------------------------------------------------------------------------
- * EXPERIMENTAL (round-1 probe; not used by the product path): fp32-class GEMM on the f16 matrix
+ * Split-f16 support (radmmm_rowgemm_h3's operands) and the plain NT probe GEMM: fp32-class GEMM on the f16 matrix
  * cores by operand splitting (x*scale = hi + lo in fp16; A.B ~= Ah.Bh + Ah.Bl + Al.Bh with fp32
  * accumulate).  radmmm_split_f16 writes hi/lo [rows][ldh] halves (ldh % 8 == 0, zero padded);
  * radmmm_h3gemm_nt computes C[M,N] = out_scale * (A B^T) from K-contiguous split operands
@@ -272,6 +298,15 @@ int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_m
  * ------------------------------------------------------------------------------------ */
 int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int ldh, int rows, int cols,
                      float scale, radmmm_stream_t stream);
+/* weight-norm fold (see radmmm_weightnorm_fwd) straight into split packed weights
+ * W{h,l}[tap][Cout][ldk] = split(scale * g v/||v||); g == NULL: plain weights (inv_norm unused) */
+int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl, float* inv_norm,
+                             int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo,
+                             int off_hi, float scale, radmmm_stream_t stream);
+/* dst[b][c][r] = src[b][r][c] for both members of a split pair (batches of [rows][cols]) */
+int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, int64_t src_batch,
+                              void* dst_h, void* dst_l, int ld_dst, int64_t dst_batch, int batches,
+                              int rows, int cols, radmmm_stream_t stream);
 int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, const void* Bl, int ldb,
                      float* C, int ldc, int M, int N, int K, float out_scale,
                      radmmm_stream_t stream);

@@ -44,6 +44,17 @@ class RowGemmDesc(C.Structure):
         ("rowscale", C.c_int),
         ("act", C.c_int),
         ("C2", C.c_void_p), ("ldc2", C.c_int), ("c2_accum", C.c_int),
+        ("Ch", C.c_void_p), ("Cl", C.c_void_p), ("ldch", C.c_int), ("ch_scale", C.c_float),
+        ("C2h", C.c_void_p), ("C2l", C.c_void_p), ("ldc2h", C.c_int), ("c2h_scale", C.c_float),
+    ]
+
+
+class RowGemmH3Desc(C.Structure):
+    _fields_ = [
+        ("base", RowGemmDesc),
+        ("Ah", C.c_void_p), ("Al", C.c_void_p), ("lda_h", C.c_int),
+        ("Bh", C.c_void_p), ("Bl", C.c_void_p), ("ldb_h", C.c_int), ("b_tap_stride_h", C.c_int64),
+        ("acc_scale", C.c_float),
     ]
 
 
@@ -75,13 +86,14 @@ def _load() -> C.CDLL:
     sig = {
         "radmmm_rowgemm_f32": [C.POINTER(RowGemmDesc), p],
         "radmmm_wgrad_f32": [C.POINTER(WgradDesc), p],
+        "radmmm_rowgemm_h3": [C.POINTER(RowGemmH3Desc), p],
         "radmmm_weightnorm_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
         "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p],
-        "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p],
+        "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p, p, p],
         "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
         "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
         "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
-        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p],
+        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p, p, i, f, p],
         "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, i, p],
         "radmmm_masked_reduce": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_masked_reduce_bwd": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
@@ -89,6 +101,8 @@ def _load() -> C.CDLL:
         "radmmm_film_fwd": [p, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p],
         "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
+        "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
+        "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],
         "radmmm_h3gemm_nt": [p, p, i, p, p, i, p, i, i, i, i, f, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
@@ -154,6 +168,25 @@ def rowgemm(**kw) -> None:
             v = ptr(v)
         setattr(d, k, v)
     check(lib.radmmm_rowgemm_f32(C.byref(d), stream()), "radmmm_rowgemm_f32")
+
+
+_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale"}
+
+
+def rowgemm_h3(**kw) -> None:
+    """split-f16 row GEMM: keys of RowGemmDesc (epilogue, shapes) + the split operands."""
+    d = RowGemmH3Desc()
+    d.base.sign = 1
+    d.base.taps = 1
+    d.base.dil = 1
+    d.base.ratio_taps = 1
+    d.base.ratio_dil = 1
+    d.acc_scale = 1.0
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = ptr(v)
+        setattr(d if k in _H3_KEYS else d.base, k, v)
+    check(lib.radmmm_rowgemm_h3(C.byref(d), stream()), "radmmm_rowgemm_h3")
 
 
 def wgrad(**kw) -> None:

@@ -214,11 +214,14 @@ class AffineTransformationLayer(nn.Module):
         for i, l in enumerate(self.affine_param_predictor.in_layers):
             assert l.dilation == 2 ** i, "ops.AffineFlowStepFn assumes dilation 2^i"
 
-    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T):
-        """Fused [1x1 mix -> WN -> coupling] on channels-last operands.  Returns z_out, log_s."""
+    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision="fp32", scale_box=None):
+        """Fused [1x1 mix -> WN -> coupling] on channels-last operands.  Returns z_out, log_s.
+        precision "fp32": fp32 MFMA GEMMs; "h3": split-f16 GEMMs (fp32-class accuracy, f16 matrix
+        cores) when the WN width allows it (multiple of 32)."""
         wn = self.affine_param_predictor
         head, layers = wn.flat_params()
         meta = dict(B=B, T=T, C=self.n_mel_channels, D=self.n_context_dim, n_layers=wn.n_layers,
                     act=ACT[wn.affine_activation], scaling=SCALE[self.scaling_fn],
-                    partial=bool(wn.use_partial_padding))
-        return ops.AffineFlowStepFn.apply(meta, z_cl, cond_cl, lens32, W_eff, b_eff, *head, *layers)
+                    partial=bool(wn.use_partial_padding), scale_box=scale_box if scale_box is not None else {})
+        fn = ops.AffineFlowStepH3Fn if (precision == "h3" and wn.n_channels % 32 == 0) else ops.AffineFlowStepFn
+        return fn.apply(meta, z_cl, cond_cl, lens32, W_eff, b_eff, *head, *layers)

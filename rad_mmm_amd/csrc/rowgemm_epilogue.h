@@ -15,6 +15,23 @@ struct EpilogueCtx {
   }
 };
 
+// hi = fp16(s*x) (saturated), lo = fp16(s*x - hi): 4 columns, 8-byte stores (ld % 4 == 0, col % 4 == 0)
+__device__ __forceinline__ void store_split4(void* hi_, void* lo_, int ld, float s, int row, int col, int N,
+                                             const float (&x)[4]) {
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = (col + e < N) ? x[e] * s : 0.f;
+    t = fminf(fmaxf(t, -60000.f), 60000.f);
+    h[e] = (_Float16)t;
+    l[e] = (_Float16)(t - (float)h[e]);
+  }
+  _Float16* hi = static_cast<_Float16*>(hi_) + (long long)row * ld + col;
+  _Float16* lo = static_cast<_Float16*>(lo_) + (long long)row * ld + col;
+  *reinterpret_cast<uint2*>(hi) = *reinterpret_cast<const uint2*>(h);
+  *reinterpret_cast<uint2*>(lo) = *reinterpret_cast<const uint2*>(l);
+}
+
 __device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
                                                 int col, float4 a4) {
   if (row >= p.M || col >= p.N) return;
@@ -67,6 +84,9 @@ __device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, co
     v[e] = x;
     c2v[e] += x;
   }
+  // optional split-fp16 copies (hi/lo of scale*x) feeding the next split-f16 GEMM
+  if (p.Ch) store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, row, col, p.N, v);
+  if (p.C2h) store_split4(p.C2h, p.C2l, p.ldc2h, p.c2h_scale, row, col, p.N, c2v);
   if (full) {
     *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
     if (p.C2)

@@ -9,6 +9,7 @@ state_dict names/shapes, so a config selects it by changing
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -63,7 +64,8 @@ class FlowStep(nn.Module):
             b_eff = F.pad(-(W @ mean).squeeze(1), (0, ZLD - C))
         return W_eff.contiguous(), b_eff.contiguous()
 
-    def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset):
+    def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
+                   scale_box=None):
         conv = self.invtbl_conv
         if isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not bool(conv.initialized):
             conv.initialize(z_cl[:, col_offset:], seq_lens, T)
@@ -74,7 +76,7 @@ class FlowStep(nn.Module):
             n_valid = int(seq_lens.lengths_host.sum())
             z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid)
         else:
-            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T)
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box)
         return z_out, log_det_W, log_s
 
 
@@ -126,6 +128,8 @@ class RADMMMFlow(nn.Module):
         self.decoder_cond_dims = decoder_cond_dims
         self.decoder_out_dims = n_mel_channels
         import os
+        # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA) or "h3" (split-f16 x3, fp32-class accuracy)
+        self.gemm_precision = os.environ.get("RADMMM_PRECISION", "fp32")
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
                                  os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
@@ -254,12 +258,13 @@ class RADMMMFlow(nn.Module):
         unfolded = _UnfoldedLens(out_lens, g, Tg)
 
         z_out, log_s_list, log_det_W_list = [], [], []
+        scale_box = {}                 # gradient scale of the split-f16 path, fixed by the first backward node
         for i, flow in enumerate(self.flows):
             off = 0
             if i in self.exit_steps:
                 z_out.append(z[:, : self.n_early_size])
                 off = self.n_early_size
-            z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off)
+            z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off, self.gemm_precision, scale_box)
             log_s_list.append(log_s.view(B, Tg, -1).transpose(1, 2))
             log_det_W_list.append(log_det_W)
         z_out.append(z[:, : self.flows[-1].n_mel_channels])

@@ -122,7 +122,7 @@ class AffineFlowStepFn(torch.autograd.Function):
                 bias=b_eff)
         # 2. WN input cat((z0, context)) (common.py:819), K-padded
         X0 = _empty(N, Kp, like=z_in)
-        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, stream()), "wn_input_fwd")
+        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, None, None, stream()), "wn_input_fwd")
         # 3. weight-norm fold (common.py:791,813,174)
         perm = (h, D, 0)                             # ref cols [z0 | ctx] -> packed [ctx | z0 | 0]
         Ws, inv_s = weightnorm_fwd(start_v, start_g, Kp, perm)
@@ -208,7 +208,8 @@ class AffineFlowStepFn(torch.autograd.Function):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
             # through softplus of the res/skip branch
-            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, stream()), "dact_mul")
+            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, None, None, 0, 1.0,
+                                      stream()), "dact_mul")
             g_res[3 * j + 2] = colsum(gQ, Wc)
             slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
@@ -347,7 +348,7 @@ class ConvNormFn(torch.autograd.Function):
         rowscale = 2 if partial else (1 if mask_out else 0)
         gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
-                                  taps, dil, stream()), "dact_mul")
+                                  taps, dil, None, None, 0, 1.0, stream()), "dact_mul")
         g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil) if ctx.has_bias else None
         ldw = W.shape[2]
         slabs = wgrad_slabs(gpre, Cout, x, Cin, ldw, T, lens, taps=taps, dil=dil, x_mask_mode=1 if partial else 0)
@@ -426,3 +427,213 @@ def stft_mel(audio: torch.Tensor, basis: torch.Tensor, mel_basis: torch.Tensor, 
     check(lib.radmmm_stft_mel(ptr(audio.contiguous()), ptr(basis), ptr(mel_basis), ptr(mel), ptr(scratch), B, S, n_fft,
                               hop, n_mel, clip, stream()), "stft_mel")
     return mel
+
+
+# ---------------------------------------------------------------------------------------
+# affine flow step on the split-f16 GEMM path (fp32-class accuracy on the f16 matrix cores)
+# ---------------------------------------------------------------------------------------
+from ._lib import rowgemm_h3  # noqa: E402
+
+W_SCALE = 256.0          # power-of-two scale of the split weights (|w| <= |g| ~ 1 after weight norm)
+
+
+def _halves(*shape, like, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f(*shape, device=like.device, dtype=torch.float16), f(*shape, device=like.device, dtype=torch.float16)
+
+
+def split_weight(v, g, ldk, perm=(0, 0, 0)):
+    """v [Cout, Cin, taps] (+ weight-norm g or None) -> split packed W{h,l} [taps, Cout, ldk], inv_norm."""
+    Cout, Cin, taps = v.shape
+    Wh, Wl = _halves(taps, Cout, ldk, like=v, zero=(ldk != Cin or perm != (0, 0, 0)))
+    inv = _empty(Cout, like=v) if g is not None else None
+    check(lib.radmmm_weightnorm_fwd_h3(ptr(v), ptr(g), ptr(Wh), ptr(Wl), ptr(inv), Cout, Cin, taps, ldk, perm[0], perm[1],
+                                       perm[2], W_SCALE, stream()), "weightnorm_fwd_h3")
+    return Wh, Wl, inv
+
+
+def transpose_split(Wh, Wl, rows, cols, ld_dst):
+    """[taps][rows][ld] pair -> [taps][cols][ld_dst] (zero padded), i.e. the K-contiguous operand of the
+    data-gradient GEMM."""
+    taps = Wh.shape[0]
+    Th, Tl = _halves(taps, cols, ld_dst, like=Wh, zero=(ld_dst != rows))
+    check(lib.radmmm_transpose_f16_pair(ptr(Wh), ptr(Wl), Wh.shape[2], Wh.stride(0), ptr(Th), ptr(Tl), ld_dst, Th.stride(0),
+                                        taps, rows, cols, stream()), "transpose_f16_pair")
+    return Th, Tl
+
+
+def split_f16(x, cols, scale, ldh=None):
+    rows = x.shape[0]
+    ldh = ldh or round_up(cols, 8)
+    hi, lo = _halves(rows, ldh, like=x)
+    check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale, stream()), "split_f16")
+    return hi, lo
+
+
+def grad_scale(box, g: torch.Tensor) -> float:
+    """Power-of-two scale of the split GRADIENT tensors, fixed once per backward pass from the first
+    incoming gradient (one host sync per step): amax * S ~ 16 leaves 2^12 of fp16 headroom."""
+    if box.get("S") is None:
+        amax = float(g.abs().max())
+        box["S"] = 1.0 if not (amax > 0 and math.isfinite(amax)) else float(2.0 ** max(0, min(40, math.floor(math.log2(16.0 / amax)))))
+    return box["S"]
+
+
+class AffineFlowStepH3Fn(torch.autograd.Function):
+    """Same contract as AffineFlowStepFn; the WN convs run on radmmm_rowgemm_h3 (split-f16, fp32
+    accumulate).  The 160-wide invertible 1x1, all weight gradients (contraction over frames) and
+    every elementwise / reduction kernel stay fp32."""
+
+    @staticmethod
+    def forward(ctx, meta, z_in, cond, lens, W_eff, b_eff, start_v, start_g, start_b, end_w, end_b,
+                *layer_params):
+        B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
+        act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
+        h = C // 2
+        N = B * T
+        Wc = start_v.shape[0]
+        Kp = round_up(D + h, 32)
+        in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
+        assert Wc % 32 == 0 and z_in.shape == (N, ZLD) and cond.shape == (N, D)
+        inv_ws = 1.0 / W_SCALE
+
+        z1 = _empty(N, ZLD, like=z_in)
+        rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
+        X0 = _empty(N, Kp, like=z_in)
+        X0h, X0l = _halves(N, Kp, like=z_in)
+        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l), stream()),
+              "wn_input_fwd")
+        perm = (h, D, 0)
+        Wsh, Wsl, inv_s = split_weight(start_v, start_g, Kp, perm)
+        Wih, Wil, inv_i, Wrh, Wrl, inv_r = [], [], [], [], [], []
+        for j in range(nl):
+            a, b, iv = split_weight(in_p[3 * j], in_p[3 * j + 1], Wc)
+            Wih.append(a); Wil.append(b); inv_i.append(iv)
+            a, b, iv = split_weight(res_p[3 * j], res_p[3 * j + 1], Wc)
+            Wrh.append(a); Wrl.append(b); inv_r.append(iv)
+        Weh, Wel, _ = split_weight(end_w, None, Wc)
+
+        H = [_empty(N, Wc, like=z_in)]
+        Hh, Hl = _halves(N, Wc, like=z_in)
+        rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, acc_scale=inv_ws, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
+                   T=T, bias=start_b, Ch=Hh, Cl=Hl, ldch=Wc, ch_scale=1.0)
+        OUT = _empty(N, Wc, like=z_in)
+        OUTh, OUTl = _halves(N, Wc, like=z_in)
+        R = []
+        for j in range(nl):
+            d = 2 ** j
+            kt = in_p[3 * j].shape[2]
+            Hn = _empty(N, Wc, like=z_in)
+            Hnh, Hnl = _halves(N, Wc, like=z_in)
+            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
+                       acc_scale=inv_ws, C=Hn, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, T=T, lens=lens,
+                       a_mask_mode=1 if partial else 0, bias=in_p[3 * j + 2], pconv=1 if partial else 0, ratio_taps=kt,
+                       ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, ldch=Wc, ch_scale=1.0)
+            H.append(Hn)
+            Hh, Hl = Hnh, Hnl
+            Rj = _empty(N, Wc, like=z_in)
+            last = j == nl - 1
+            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, acc_scale=inv_ws, C=Rj, ldc=Wc, M=N, N=Wc,
+                       K=Wc, T=T, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
+                       C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0)
+            R.append(Rj)
+        O = _empty(N, ZLD, like=z_in)
+        rowgemm_h3(Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, acc_scale=inv_ws, C=O, ldc=ZLD, M=N, N=C, K=Wc,
+                   T=T, bias=end_b)
+        z_out = _empty(N, ZLD, like=z_in)
+        log_s = _empty(N, h, like=z_in)
+        check(lib.radmmm_affine_coupling_fwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(z_out), ptr(log_s), N, h, scaling,
+                                             stream()), "affine_coupling_fwd")
+        ctx.meta = meta
+        ctx.nl = nl
+        ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
+                              *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *layer_params)
+        return z_out, log_s
+
+    @staticmethod
+    def backward(ctx, g_zout, g_logs):
+        meta, nl = ctx.meta, ctx.nl
+        B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
+        act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
+        sv = ctx.saved_tensors
+        z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel = sv[:15]
+        p = 15
+        take = lambda n: sv[p: p + n]
+        H = sv[p: p + nl + 1]; p += nl + 1
+        R = sv[p: p + nl]; p += nl
+        Wih = sv[p: p + nl]; p += nl
+        Wil = sv[p: p + nl]; p += nl
+        inv_i = sv[p: p + nl]; p += nl
+        Wrh = sv[p: p + nl]; p += nl
+        Wrl = sv[p: p + nl]; p += nl
+        inv_r = sv[p: p + nl]; p += nl
+        layer_params = sv[p:]
+        in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
+        h = C // 2
+        N = B * T
+        Wc = start_v.shape[0]
+        Kp = X0.shape[1]
+        g_zout = g_zout.contiguous()
+        if g_logs is not None:
+            g_logs = g_logs.contiguous()
+        SG = grad_scale(meta["scale_box"], g_zout)
+        inv_acc = 1.0 / (SG * W_SCALE)
+
+        gO = torch.zeros(N, ZLD, device=z_in.device, dtype=torch.float32)      # columns >= C stay zero (K = ZLD)
+        gz1 = _empty(N, ZLD, like=z_in)
+        check(lib.radmmm_affine_coupling_bwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(g_zout), ptr(g_logs), ptr(gO), ptr(gz1),
+                                             N, h, scaling, stream()), "affine_coupling_bwd")
+        g_end_b = colsum(gO, C)
+        g_end_w = wgrad_slabs(gO, C, OUT, Wc, Wc, T, None).sum(0).view(C, Wc, 1)
+        gOh, gOl = split_f16(gO, ZLD, SG, ZLD)
+        WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD)                    # [1][Wc][ZLD]
+        gOUT = _empty(N, Wc, like=z_in)
+        rowgemm_h3(Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, acc_scale=inv_acc, C=gOUT, ldc=Wc, M=N, N=Wc,
+                   K=ZLD, T=T)
+        g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
+        g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
+        G = None
+        Gh = Gl = None
+        gQ = _empty(N, Wc, like=z_in)
+        gQh, gQl = _halves(N, Wc, like=z_in)
+        for j in range(nl - 1, -1, -1):
+            d = 2 ** j
+            kt = in_p[3 * j].shape[2]
+            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
+                                      ptr(gQl), Wc, SG, stream()), "dact_mul")
+            g_res[3 * j + 2] = colsum(gQ, Wc)
+            slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
+            g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
+            WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc)
+            g_conv = _empty(N, Wc, like=z_in)
+            gch, gcl = _halves(N, Wc, like=z_in)
+            rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, acc_scale=inv_acc, C=g_conv, ldc=Wc, M=N,
+                       N=Wc, K=Wc, T=T, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
+                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
+            g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
+            slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
+            g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
+            WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc)            # [taps][ci][co]
+            G = _empty(N, Wc, like=z_in)
+            if j == 0:
+                Gh, Gl = _halves(N, Wc, like=z_in)
+            rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
+                       acc_scale=inv_acc, C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens,
+                       a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
+                       ldch=Wc, ch_scale=SG)
+        g_start_b = colsum(G, Wc)
+        perm = (h, D, 0)
+        slabs = wgrad_slabs(G, Wc, X0, Kp, Kp, T, None)
+        g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
+        WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc)                      # [1][Kp][Wc]
+        gX0 = _empty(N, Kp, like=z_in)
+        rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, acc_scale=inv_acc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc,
+                   T=T)
+        g_cond = _empty(N, D, like=z_in)
+        check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
+        g_b_eff = colsum(gz1, ZLD)
+        g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
+        g_zin = _empty(N, ZLD, like=z_in)
+        rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
+        return (None, g_zin, g_cond, None, g_W_eff, g_b_eff, g_start_v, g_start_g, g_start_b, g_end_w, g_end_b,
+                *g_in, *g_res)

@@ -28,7 +28,7 @@ def test_h3gemm_accuracy(M, N, K, wscale):
     Bw = (torch.randn(N, K, generator=g) * 0.03).to(DEV)                                # weights-like
     Ah, Al = _split(A, 1.0)
     Bh, Bl = _split(Bw, wscale)
-    assert rel_err((Ah.float() + Al.float()), A) < 1e-6
+    assert rel_err((Ah.float() + Al.float())[:, :K].cpu(), A.cpu()) < 1e-6
     C = torch.full((M, N), float("nan"), device=DEV)
     check(lib.radmmm_h3gemm_nt(ptr(Ah), ptr(Al), Ah.shape[1], ptr(Bh), ptr(Bl), Bh.shape[1], ptr(C), N, M, N, K,
                                1.0 / wscale, stream()), "h3gemm")

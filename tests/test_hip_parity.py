@@ -265,7 +265,7 @@ def test_flow_loss_golden(R, golden):
         assert rel_err(t.grad.cpu(), (-m / denom).expand_as(t)) < 1e-6
 
 
-def _build_decoder(g):
+def _build_decoder(g, precision="fp32"):
     from oracle import radmmm_oracle as O
     from rad_mmm_amd.decoders import RADMMMFlow
     kw = {k: (v.item() if v.shape == () else v) for k, v in sub(g, "cfg.").items()}
@@ -273,11 +273,13 @@ def _build_decoder(g):
     sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
     dec = RADMMMFlow(use_accent=True, **kw)
     dec.load_state_dict(sd)
+    dec.gemm_precision = precision
     return dec.to(DEV).train(), cfg, sd
 
 
-@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small", "cfg5_small"])
-def test_decoder_golden(R, golden, tag):
+@pytest.mark.parametrize("tag,precision", [("cfg1", "fp32"), ("cfg2_small", "fp32"), ("cfg5_small", "fp32"),
+                                           ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3")])
+def test_decoder_golden(R, golden, tag, precision):
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
     cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture;
     cfg5_small = config-5 architecture (RADMMM dims, 2 spline + 2 affine flows, masked batch-norm)."""
@@ -285,7 +287,7 @@ def test_decoder_golden(R, golden, tag):
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.loss import RADMMMLoss
     g = golden(f"decoder_{tag}.npz")
-    dec, cfg, sd = _build_decoder(g)
+    dec, cfg, sd = _build_decoder(g, precision)      # "h3": WN GEMMs on the split-f16 path, same tolerances
     b = T(O.synthetic_batch(int(g["B"]), int(g["T"]), cfg, 1234, bool(g["ragged"])))
     gb = {k: v.to(DEV) for k, v in b.items()}
     mel = gb["mel"].clone().requires_grad_(True)
@@ -325,7 +327,7 @@ def test_decoder_golden(R, golden, tag):
     for n, gr in sub(g, "gradslice.").items():
         p = dict(dec.named_parameters())[n]
         assert np.abs(p.grad[:4, :8].cpu().numpy() - gr).max() < 5e-4 * np.abs(gr).max() + 1e-8, n
-    print(f"{tag}: worst grad-norm rel err {worst:.2e}")
+    print(f"{tag}/{precision}: z rel err {rel_err(zm, g['z_mel']):.2e}, worst grad-norm rel err {worst:.2e}")
 
 
 def test_context_lstm_two_streams_matches_packed_path(R):
