@@ -311,6 +311,22 @@ int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, co
                      float* C, int ldc, int M, int N, int K, float out_scale,
                      radmmm_stream_t stream);
 
+/* Weight gradient on the split-f16 path.  Operands are transposed, time-contiguous, zero-gapped
+ * split copies made by radmmm_transpose_split_act from channels-last fp32 [B*T][ld]:
+ *   out[c][front + b*Tp + t] = split(scale * x[b*T+t][c]),  t < (mask_mode ? lens[b] : T), else 0
+ * (Tp >= T + max|shift|, front >= max|shift|, ldk % 8 == 0, ldk >= front + B*Tp; the front columns
+ * and the row tail must be zero: allocate zeroed once, the gaps are rewritten on every call).
+ * o1h/o1l (optional) receive the copy advanced by one column, used for odd tap shifts.
+ *   P[split][tap][m][n] = acc_scale * sum_k GYt[m][k] * Xt[n][k + (tap - taps/2)*dil]
+ * over the Kt (% 32 == 0) columns k in [k0, k0 + Kt), k0 = front; split-K into `splits` slabs as
+ * radmmm_wgrad_f32.  ldk >= k0 + Kt + max|shift|. */
+int radmmm_transpose_split_act(const float* x, int ld, int C, int B, int T, int Tp, int front,
+                               const int32_t* lens, int mask_mode, float scale, void* oh, void* ol,
+                               void* o1h, void* o1l, int ldk, radmmm_stream_t stream);
+int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void* Xl, const void* X1h,
+                    const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
+                    int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -470,6 +470,45 @@ def split_f16(x, cols, scale, ldh=None):
     return hi, lo
 
 
+_TS_FRONT = 16           # leading zero columns / zero gap between utterances (>= max tap shift 2*8)
+_ts_pool = {}
+
+
+def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False):
+    """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
+    Buffers come from a small zero-initialised pool keyed by shape and role: the pads are never
+    written, the data and the gaps are rewritten on every call (single stream => reuse is ordered)."""
+    Tp = T + _TS_FRONT
+    Kt = round_up(B * Tp, 32)                 # contracted columns [FRONT, FRONT + Kt)
+    ldk = Kt + 2 * _TS_FRONT
+    key = (x.device, C, Kt, role, need_odd)
+    bufs = _ts_pool.get(key)
+    if bufs is None:
+        n = 4 if need_odd else 2
+        bufs = [torch.zeros(C, ldk, device=x.device, dtype=torch.float16) for _ in range(n)]
+        _ts_pool[key] = bufs
+    oh, ol = bufs[0], bufs[1]
+    o1h, o1l = (bufs[2], bufs[3]) if need_odd else (None, None)
+    check(lib.radmmm_transpose_split_act(ptr(x), x.shape[1], C, B, T, Tp, _TS_FRONT, ptr(lens), mask_mode, scale, ptr(oh),
+                                         ptr(ol), ptr(o1h), ptr(o1l), ldk, stream()), "transpose_split_act")
+    return oh, ol, o1h, o1l, Kt
+
+
+def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale):
+    """gy_t / x_t: results of transpose_split_act -> P [S, taps, Mc, ldp] fp32 slabs."""
+    gh, gl, _, _, Kt = gy_t
+    xh, xl, x1h, x1l, Kt2 = x_t
+    assert Kt == Kt2
+    tiles = -(-Mc // 128) * -(-Nc // 128) * taps
+    S = pick_splits(tiles, Kt)
+    P = torch.empty(S, taps, Mc, ldp, device=gh.device, dtype=torch.float32)
+    if ldp != Nc:
+        P.zero_()
+    check(lib.radmmm_wgrad_h3(ptr(gh), ptr(gl), ptr(xh), ptr(xl), ptr(x1h), ptr(x1l), Kt + 2 * _TS_FRONT, _TS_FRONT, Kt, ptr(P), ldp, P.stride(0),
+                              Mc, Nc, taps, dil, S, acc_scale, stream()), "wgrad_h3")
+    return P
+
+
 def grad_scale(box, g: torch.Tensor) -> float:
     """Power-of-two scale of the split GRADIENT tensors, fixed once per backward pass from the first
     incoming gradient (one host sync per step): amax * S ~ 16 leaves 2^12 of fp16 headroom."""
@@ -602,7 +641,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
                                       ptr(gQl), Wc, SG, stream()), "dact_mul")
             g_res[3 * j + 2] = colsum(gQ, Wc)
-            slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
+            gy_t = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy")
+            x_t = transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
+            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
             WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc)
             g_conv = _empty(N, Wc, like=z_in)
@@ -611,7 +652,12 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        N=Wc, K=Wc, T=T, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
                        rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
             g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
-            slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
+            if (kt // 2) * d <= _TS_FRONT:
+                gy_t = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy")
+                x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
+                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG)
+            else:
+                slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
             g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
             WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc)            # [taps][ci][co]
             G = _empty(N, Wc, like=z_in)
@@ -623,7 +669,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        ldch=Wc, ch_scale=SG)
         g_start_b = colsum(G, Wc)
         perm = (h, D, 0)
-        slabs = wgrad_slabs(G, Wc, X0, Kp, Kp, T, None)
+        gy_t = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy")
+        x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
+        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
         WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc)                      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)

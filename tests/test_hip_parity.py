@@ -147,6 +147,44 @@ def test_wgrad_fast_path(R, Cin, Cout, dil, Tn, lens):
     assert rel_err(gw2, w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,dil,Tn,lens", [(16, 16, 1, 48, [48, 31, 7]), (144, 130, 4, 37, [37, 37, 20]),
+                                                   (64, 256, 8, 64, [64, 40, 33]), (32, 32, 2, 21, [21, 1])])
+def test_wgrad_h3(R, Cin, Cout, dil, Tn, lens):
+    """split-f16 weight gradient on transposed zero-gapped copies (odd/even tap shifts, ragged
+    lengths, explicit split-K) vs autograd through the masked dilated conv."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(Cin + dil)
+    B = len(lens)
+    x = torch.randn(B, Cin, Tn, generator=g)
+    w = (torch.randn(Cout, Cin, 5, generator=g) * 0.2).requires_grad_(True)
+    mask = O.lengths_to_mask(torch.tensor(lens), Tn)[:, None].float()
+    y = F.conv1d(x * mask, w, None, padding=2 * dil, dilation=dil)
+    gy = torch.randn(B, Cout, Tn, generator=g) * 1e-3
+    (y * gy).sum().backward()
+    ldi, ldo = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    cl = lambda t, ld: F.pad(t.detach().permute(0, 2, 1).reshape(B * Tn, -1), (0, ld - t.shape[1])).contiguous().to(DEV)
+    SG = 4096.0
+    for rep in range(2):                     # second pass reuses the pooled buffers
+        gy_t = ops.transpose_split_act(cl(gy, ldo), Cout, B, Tn, None, 0, SG, "gy")
+        x_t = ops.transpose_split_act(cl(x, ldi), Cin, B, Tn, _lens_dev(lens), 1, 1.0, "x", need_odd=(dil % 2 == 1))
+        P = ops.wgrad_h3_slabs(gy_t, x_t, Cout, Cin, ldi, 5, dil, 1.0 / SG)
+        gw = P.sum(0)[:, :, :Cin].cpu().permute(1, 2, 0)
+        assert rel_err(gw, w.grad) < 5e-6
+    # the transposed copy itself: hi + lo reproduces the masked activations to ~2^-22
+    xh, xl, x1h, _, Kt = x_t
+    Tp = Tn + 16
+    rec = (xh.float() + xl.float()).cpu()
+    assert torch.all(rec[:, :16] == 0)
+    for b in range(B):
+        seg = rec[:, 16 + b * Tp: 16 + (b + 1) * Tp]
+        ref = (x * mask)[b]
+        assert rel_err(seg[:, :Tn], ref) < 1e-6
+        assert torch.all(seg[:, Tn:] == 0)
+    if x1h is not None:
+        assert torch.equal(x1h[:, :-1].cpu(), xh[:, 1:].cpu())
+
+
 def test_weightnorm_bwd(R):
     from oracle import radmmm_oracle as O
     from rad_mmm_amd import ops
