@@ -37,6 +37,7 @@ RADMMM_SPLINES = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False, 
 CONFIGS = {"radtts": RADTTS, "radmmm_splines": RADMMM_SPLINES}
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -96,6 +97,71 @@ def time_dominant_kernel(N, T, reps=20):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
+
+
+def time_dominant_kernel_h3(N, T, reps=20):
+    """Same launch as time_dominant_kernel on the split-f16 path (the default precision):
+    rowgemm_h3 as the WN in_layer forward conv, split activations in, fp32 + split copies out."""
+    from rad_mmm_amd._lib import rowgemm_h3
+    from rad_mmm_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(N, 1024, generator=g).to(dev)
+    v = (torch.randn(1024, 1024, 5, generator=g) * 0.02).to(dev)
+    gg = torch.ones(1024, 1, 1, device=dev)
+    b = torch.zeros(1024, device=dev)
+    xh, xl = ops.split_f16(x, 1024, 1.0)
+    Wh, Wl, _ = ops.split_weight(v, gg, 1024)
+    y = torch.empty(N, 1024, device=dev)
+    yh, yl = torch.empty_like(xh), torch.empty_like(xl)
+    lens = torch.full((N // T,), T, dtype=torch.int32, device=dev)
+
+    def launch():
+        rowgemm_h3(Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0),
+                   acc_scale=1.0 / ops.W_SCALE, C=y, ldc=1024, M=N, N=1024, K=1024, taps=5, dil=2, sign=1, T=T, lens=lens,
+                   a_mask_mode=1, bias=b, pconv=1, ratio_taps=5, ratio_dil=2, postmask=1, act=1, Ch=yh, Cl=yl, ldch=1024,
+                   ch_scale=1.0)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
+
+
+def time_wgrad_h3(N, T, reps=10):
+    """in_layer weight gradient on the split-f16 path incl. the two transposing split producers."""
+    from rad_mmm_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(1)
+    gy = torch.randn(N, 1024, generator=g).to(dev)
+    x = torch.randn(N, 1024, generator=g).to(dev)
+    B = N // T
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+
+    def run(with_producers=True):
+        gy_t = ops.transpose_split_act(gy, 1024, B, T, None, 0, 1.0, "gy")
+        x_t = ops.transpose_split_act(x, 1024, B, T, lens, 1, 1.0, "x")
+        return gy_t, x_t
+    gy_t, x_t = run()
+    ops.wgrad_h3_slabs(gy_t, x_t, 1024, 1024, 1024, 5, 2, 1.0)
+    out = []
+    for what in ("gemm", "gemm+producers"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            if what != "gemm":
+                gy_t, x_t = run()
+            ops.wgrad_h3_slabs(gy_t, x_t, 1024, 1024, 1024, 5, 2, 1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e-3 / reps)
+    return out, 2.0 * N * 1024 * 5 * 1024
 
 
 def time_h3_probe(N, reps=20):
@@ -220,6 +286,12 @@ def main():
         wdur, wflop = time_wgrad_kernel(N, Tg)
         print(json.dumps({"kernel": "wgrad_f32 in_layer", "R": N, "avg_launch_ms": wdur * 1e3,
                           "tflops": wflop / wdur / 1e12}))
+        hdur, hflop = time_dominant_kernel_h3(N, Tg)
+        print(json.dumps({"kernel": "rowgemm_h3 in_layer fwd", "M": N, "avg_launch_ms": hdur * 1e3,
+                          "fp32_equiv_tflops": hflop / hdur / 1e12, "mfma_tflops": 3 * hflop / hdur / 1e12}))
+        (w1, w2), wf = time_wgrad_h3(N, Tg)
+        print(json.dumps({"kernel": "wgrad_h3 in_layer", "gemm_ms": w1 * 1e3, "gemm_plus_producers_ms": w2 * 1e3,
+                          "fp32_equiv_tflops": wf / w1 / 1e12}))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,8 +362,20 @@ def main():
 
     if rank == 0:
         N = B * (T // cfg.n_group_size)
-        kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)
-        achieved = kflop / kdur / 1e12
+        h3 = dec.gemm_precision == "h3"
+        if h3:
+            # split-f16 path: every fp32 product is three f16 MFMA products (Ah*Bh + Ah*Bl + Al*Bh), so the
+            # kernel executes 3x the fp32-equivalent flops on the f16 matrix cores; the roofline is the dense
+            # f16 MFMA peak and `achieved` counts the executed MFMA flops
+            kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size)
+            achieved, peak = 3.0 * kflop / kdur / 1e12, PEAK_F16_MFMA_TFLOPS
+            kname = "rowgemm_h3_kernel (WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA products per fp32 product)" % N
+            prec = "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)"
+        else:
+            kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)
+            achieved, peak = kflop / kdur / 1e12, PEAK_FP32_MFMA_TFLOPS
+            kname = "rowgemm_f32_kernel<0> (WN in_layer conv fwd, M=%d N=1024 K=5x1024)" % N
+            prec = "fp32 MFMA"
         fl = algorithmic_flops_per_frame(cfg)
         by = algorithmic_bytes_per_frame(cfg) + 3 * 4 * sum(p.numel() for p in dec.parameters()) / (B * T)
         res = {
@@ -304,12 +388,13 @@ def main():
                                    ("RADMMM 16 kHz-dims flow decoder (configs/RADMMM_16khz_model_config.yaml + "
                                     "n_splines=2: 2 spline/FiLM + 6 affine/WN flows, D=1056) fwd+NLL+bwd"),
                        "batch_per_gpu": B, "n_mel": 80, "frames": T,
-                       "global_batch": B * world, "parallelism": f"dp{world}", "precision": "fp32 MFMA (exact)"},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec},
             "loss_mel": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "rowgemm_f32_kernel<0> (WN in_layer conv fwd, M=%d N=1024 K=5x1024)" % N,
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": kdur * 1e3,
-                         "flop_per_launch": kflop, "traffic": None},
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "avg_launch_ms": kdur * 1e3,
+                         "flop_per_launch": (3.0 if h3 else 1.0) * kflop, "fp32_equiv_tflops": kflop / kdur / 1e12,
+                         "traffic": None},
             "step_flops": {"algorithmic_tflop_per_step": fl * B * T / 1e12,
                            "achieved_tflops_per_gpu": fl * B * T / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_fp32_mfma_peak": fl * B * T / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},

@@ -32,17 +32,41 @@ __device__ __forceinline__ void store_split4(void* hi_, void* lo_, int ld, float
   *reinterpret_cast<uint2*>(lo) = *reinterpret_cast<const uint2*>(l);
 }
 
-__device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
-                                                int col, float4 a4) {
-  if (row >= p.M || col >= p.N) return;
-  float maskv = 1.f, ratio = 1.f;
-  if (ec.need_row) {
+// per-row factors of the epilogue: length mask and partial-conv renormalisation ratio
+__device__ __forceinline__ void epilogue_row_factors(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
+                                                     float& maskv, float& ratio) {
+  maskv = 1.f;
+  ratio = 1.f;
+  if (ec.need_row && row < p.M) {
     const int b = row / p.T;
     const int t = row - b * p.T;
     const int len = p.lens ? p.lens[b] : p.T;
     maskv = t < len ? 1.f : 0.f;
     if (p.pconv || p.rowscale == 2) ratio = pconv_ratio(t, len, p.ratio_taps, p.ratio_dil);
   }
+}
+
+__device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
+                                                    float4 a4, float maskv, float ratio, const float (&biasv)[4]);
+
+__device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
+                                                int col, float4 a4) {
+  if (row >= p.M || col >= p.N) return;
+  float maskv, ratio;
+  epilogue_row_factors(p, ec, row, maskv, ratio);
+  float biasv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) biasv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+  }
+  epilogue_store4_pre(p, ec, row, col, a4, maskv, ratio, biasv);
+}
+
+// same with the row factors and the bias of the 4 columns supplied by the caller (kernels that hoist
+// them out of the per-row loop: no dependent global loads remain in the store path)
+__device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
+                                                    float4 a4, float maskv, float ratio, const float (&biasv)[4]) {
+  if (row >= p.M || col >= p.N) return;
   float v[4] = {a4.x, a4.y, a4.z, a4.w};
   const bool full = ec.vec_ok && col + 3 < p.N;
   float addv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f}, c2v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -74,7 +98,7 @@ __device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, co
     float x = v[e];
     if (p.pconv) x *= ratio;
     if (p.premask) x *= maskv;
-    if (p.bias) x += (col + e < p.N) ? p.bias[col + e] : 0.f;
+    x += biasv[e];
     x += addv[e];
     if (p.postmask) x *= maskv;
     if (p.dact) x *= dact_from_out(dsv[e], p.dact);

@@ -14,6 +14,8 @@
 // buffer loads: per-thread byte offsets change only with the tap, the K position is a scalar
 // offset, masked / out-of-item frames get an out-of-range offset (zeros from the buffer unit).
 // Both operands are K-contiguous; the data-gradient uses a transposed split copy of the weights.
+#include <stdlib.h>
+
 #include "common.h"
 #include "rowgemm_epilogue.h"
 
@@ -189,6 +191,12 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   const long long a_bytes = (long long)p.M * d->lda_h * 2;
   const long long b_bytes = ((long long)(p.taps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "rowgemm_h3: operand >= 2 GiB");
+  // default: the wide-tile kernel (rowgemm_h3w.hip); RADMMM_H3_TILE=128 keeps this file's 128x128 one (A/B runs)
+  static const bool narrow = [] {
+    const char* e = getenv("RADMMM_H3_TILE");
+    return e && atoi(e) == 128;
+  }();
+  if (!narrow) return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);

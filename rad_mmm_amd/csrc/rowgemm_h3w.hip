@@ -1,0 +1,375 @@
+// rowgemm_h3w: wide-tile version of the split-f16 conv GEMM (same contract as rowgemm_h3.hip).
+//
+// PMC on the 128x128 kernel (profiles/r01_pmc_h3.txt) showed MFMA busy 32 %, LDS busy 32 % and
+// the waves waiting 52 % of their cycles: two small workgroups per CU with one barrier per 24
+// MFMAs are latency bound.  This version gives every CU ONE workgroup with a (32*MB) x 256 tile:
+//
+//   * 4 waves = 4 column groups of 64; each wave owns all MB row blocks -> MB x 2 accumulators of
+//     32x32 (up to 256 registers; one wave per SIMD has the full 512-register file);
+//   * per 16-deep k block a wave reads 2*MB A fragments + 4 B fragments for 6*MB MFMAs (0.43
+//     ds_read_b128 per MFMA at MB = 7, the 128x128 kernel: 0.67) and a K step (32) carries
+//     12*MB MFMAs per wave between barriers (84 vs 24);
+//   * LDS rows are 64 B (32 halves) with the 16-byte chunk index XOR-swizzled by row bits 2..3:
+//     no padding, conflict-free for the 16-lane groups of ds_read_b128 and for the staging
+//     stores (stage = (2*32*MB + 512) * 64 B <= 64 KiB, double buffered);
+//   * MB in {4..8} is chosen by the host so that ceil(M / 32MB) * ceil(N / 256) fills whole
+//     rounds of the 256 CUs: 12 800 frames x 1024 channels -> MB = 7 -> 58 x 4 = 232 workgroups
+//     in one round (89 % of the MFMA slots useful; 128-row tiles: 78 %).
+#include <stdlib.h>
+
+#include "common.h"
+#include "rowgemm_epilogue.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BN = 256, BK = 32, ROWB = 64;
+constexpr int OOB = 0x7fffffff;
+
+template <int MB>
+struct Geo {
+  static constexpr int BMR = MB * 32;
+  static constexpr int A_BYTES = BMR * ROWB;     // one of {Ah, Al}
+  static constexpr int B_BYTES = BN * ROWB;      // one of {Bh, Bl}
+  static constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  static constexpr int SMEM = 2 * STAGE + 4096;   // + dump area for the masked half of an odd A pass
+  static constexpr int AI = (MB + 1) / 2;        // A rows staged per thread (64 rows per pass)
+};
+
+// Epilogue of row block I (compile-time index: a runtime-indexed accumulator array would live in
+// scratch): the four waves park their 32x64 pieces in LDS, then all threads run the fused epilogue
+// on coalesced float4 rows.
+template <int MB, int I>
+__device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], float* smf, const float2* rowf,
+                                                const radmmm_rowgemm_desc& p, const radmmm::EpilogueCtx& ec, float sc,
+                                                int m0, int n0, int tid, int lane, int wave, const float (&biasv)[4]) {
+  if constexpr (I < MB) {
+    if (I > 0) __syncthreads();            // the previous block has been read out
+    float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[I][j][e] * sc;
+    __syncthreads();
+    if (m0 + I * 32 < p.M) {
+      const int c4 = (tid & 63) * 4;
+#pragma unroll 4
+      for (int k = 0; k < 8; ++k) {
+        const int rl = k * 4 + (tid >> 6);
+        const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
+        const float2 rf = rowf[I * 32 + rl];
+        radmmm::epilogue_store4_pre(p, ec, m0 + I * 32 + rl, n0 + c4, a4, rf.x, rf.y, biasv);
+      }
+    }
+    epilogue_blocks<MB, I + 1>(acc, smf, rowf, p, ec, sc, m0, n0, tid, lane, wave, biasv);
+  }
+}
+
+// The K step as one software pipeline of 2*MB "items" (k block kb = t / MB, row block i = t % MB):
+//   item t:  ds_read A fragments of item t + D | 6 MFMAs of item t | 2 staging ds_writes (t < NW)
+// plus the B fragments of the second k block D items before they are needed and, once the staging
+// registers are free (t == NW), the 16 buffer loads of the tile two steps ahead.  The instruction
+// order is pinned with sched_group_barrier; without it the scheduler keeps a single ds_read in
+// flight and every MFMA group waits for LDS (measured: 39 % MFMA busy inside a workgroup).
+constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100, SGB_DSW = 0x200;
+constexpr int LOOKAHEAD = 2;
+
+template <int MB, int T>
+__device__ __forceinline__ void pin_items() {
+  constexpr int NT = 2 * MB, NW = (MB + 1) / 2 + 4;
+  if constexpr (T < NT) {
+    if constexpr (T + LOOKAHEAD < NT) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
+    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
+    if constexpr (T < NW) __builtin_amdgcn_sched_group_barrier(SGB_DSW, 2, 0);
+    if constexpr (T == NW) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2 * ((MB + 1) / 2) + 8, 0);
+    pin_items<MB, T + 1>();
+  }
+}
+
+// ABL: ablation bits for bottleneck hunting (results are wrong when != 0): 1 no global loads,
+// 2 no staging stores, 4 no fragment reads, 8 no MFMAs inside the K loop.
+template <int MB, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
+                                                              const int b_bytes) {
+  using G = Geo<MB>;
+  constexpr int NT = 2 * MB, NW = G::AI + 4, D = LOOKAHEAD;
+  constexpr bool DO_LOAD = !(ABL & 1), DO_STORE = !(ABL & 2), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
+  static_assert(NW < NT && D <= MB, "pipeline shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const radmmm_rowgemm_desc& p = q.base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BMR - 1) / G::BMR;
+  const int nt = ntn * ntm, wg = blockIdx.x;
+  const int xcd = wg & 7, loc = wg >> 3, qq = nt >> 3, r8 = nt & 7;
+  const int tile = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int m0 = tm * G::BMR, n0 = tn * BN;
+  const int kpt = p.K / BK;
+  const int nsteps = kpt * p.taps;
+
+  // staging: thread -> row (tid >> 2) + 64 i, 16-byte chunk (tid & 3); the chunk lands in LDS slot
+  // chunk ^ ((row >> 2) & 3), and 64 i does not touch row bits 2..3.  Odd MB: the last A pass has
+  // only 32 rows; the other 32 threads-rows write to a dump area behind the two stages instead
+  // of branching (a branch would split the pinned schedule).
+  const int s_row = tid >> 2, s_chunk = tid & 3;
+  const int s_lds = s_row * ROWB + ((s_chunk ^ ((s_row >> 2) & 3)) << 4);
+  int a_t[G::AI], a_lim[G::AI], a_base[G::AI], b_voff[4];
+#pragma unroll
+  for (int i = 0; i < G::AI; ++i) {
+    const int rl = s_row + 64 * i;
+    const int r = m0 + rl;
+    a_t[i] = 0;
+    a_lim[i] = -1;                                       // no frame passes "ts < a_lim"
+    a_base[i] = 0;
+    if (rl < G::BMR && r < p.M) {
+      const int b = r / p.T;
+      a_t[i] = r - b * p.T;
+      a_lim[i] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
+      a_base[i] = (b * p.T * q.lda_h + s_chunk * 8) * 2;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + s_row + 64 * i;
+    b_voff[i] = n < p.N ? (n * q.ldb_h + s_chunk * 8) * 2 : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Ah), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Al), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bh), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bl), 0, b_bytes, 0x00020000);
+
+  struct Regs {
+    u32x4 a[2][G::AI];
+    u32x4 b[2][4];
+  };
+  // branch-free: the frame shift of tap `tap` is applied to every load (a few VALU ops per step)
+  auto load_tiles = [&](int tap, int kb, Regs& R) __attribute__((always_inline)) {
+    const int s = p.sign * (tap - p.taps / 2) * p.dil;
+    const int so_a = kb * (BK * 2);
+    const int so_b = (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < G::AI; ++i) {
+      const int ts = a_t[i] + s;
+      const int vo = (ts >= 0 && ts < a_lim[i]) ? a_base[i] + ts * q.lda_h * 2 : OOB;
+      R.a[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rAh, vo, so_a, 0);
+      R.a[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rAl, vo, so_a, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      R.b[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rBh, b_voff[i], so_b, 0);
+      R.b[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rBl, b_voff[i], so_b, 0);
+    }
+  };
+  // staging store piece w of 0 .. AI+3 (two ds_write_b128 each): A pass w, then B pass w - AI
+  const int dump = 2 * G::STAGE + (s_row & 31) * ROWB + (s_chunk << 4);
+  auto store_piece = [&](int buf, int w, const Regs& R) __attribute__((always_inline)) {
+    unsigned char* st = sm + buf * G::STAGE + s_lds;
+    if (w < G::AI) {
+      unsigned char* d0 = st + w * 64 * ROWB;
+      unsigned char* d1 = d0 + G::A_BYTES;
+      if ((MB & 1) && w == G::AI - 1) {                    // 32 real rows in this pass
+        const bool real = s_row < 32;
+        d0 = real ? d0 : sm + dump;
+        d1 = real ? d1 : sm + dump + 2048;
+      }
+      *reinterpret_cast<u32x4*>(d0) = R.a[0][w];
+      *reinterpret_cast<u32x4*>(d1) = R.a[1][w];
+    } else {
+      const int i = w - G::AI;
+      *reinterpret_cast<u32x4*>(st + 2 * G::A_BYTES + i * 64 * ROWB) = R.b[0][i];
+      *reinterpret_cast<u32x4*>(st + 2 * G::A_BYTES + G::B_BYTES + i * 64 * ROWB) = R.b[1][i];
+    }
+  };
+
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment of a 16-deep k block kb: lane l holds row (l & 31), chunk 2 kb + (l >> 5)
+  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3;
+  const int f_off0 = f_row + (((0 + (lane >> 5)) ^ f_swz) << 4);
+  const int f_off1 = f_row + (((2 + (lane >> 5)) ^ f_swz) << 4);
+
+  // (tap, kb) of the tile two steps ahead, advanced without divisions; clamped to the last tile
+  int l_tap = 0, l_kb = 0;
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool last = (l_tap == p.taps - 1) && (l_kb == kpt - 1);
+    const bool wrap = l_kb == kpt - 1;
+    l_kb = last ? l_kb : (wrap ? 0 : l_kb + 1);
+    l_tap = (wrap && !last) ? l_tap + 1 : l_tap;
+  };
+  Regs R;
+  load_tiles(0, 0, R);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) store_piece(0, w, R);
+  advance();
+  load_tiles(l_tap, l_kb, R);                        // tile 1 (or tile 0 again if there is only one)
+  __syncthreads();
+  f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
+  if constexpr (!DO_READ) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      fah[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16);
+      fal[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16 + 512);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bh[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 20000 + t * 1024 + lane * 16);
+      bl[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 30000 + t * 1024 + lane * 16);
+    }
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    advance();                                       // -> tile step + 2
+    const unsigned char* st = sm + buf * G::STAGE;
+    const unsigned char* sB = st + 2 * G::A_BYTES + wave * 64 * ROWB;
+    auto read_a = [&](int t) __attribute__((always_inline)) {
+      if constexpr (!DO_READ) return;
+      const int fo = (t >= MB) ? f_off1 : f_off0;
+      const int i = t >= MB ? t - MB : t;
+      fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
+      fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+    };
+    auto read_b = [&](int kb) __attribute__((always_inline)) {
+      if constexpr (!DO_READ) return;
+      const int fo = kb ? f_off1 : f_off0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
+        bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+      }
+    };
+    read_b(0);
+#pragma unroll
+    for (int t = 0; t < D; ++t) read_a(t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + D < NT) read_a(t + D);
+      if (t + D == MB) read_b(1);
+      const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
+      if constexpr (DO_MFMA) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(fah[t]), "v"(fal[t]), "v"(bh[kb][0]), "v"(bh[kb][1]), "v"(bl[kb][0]), "v"(bl[kb][1]));
+      }
+      if (DO_STORE && t < NW) store_piece(buf ^ 1, t, R);   // tile step + 1, loaded during the previous step
+      if (DO_LOAD && t == NW) load_tiles(l_tap, l_kb, R);   // tile step + 2
+    }
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
+    pin_items<MB, 0>();
+    __syncthreads();
+  }
+
+  // ---- epilogue: one 32-row block at a time through LDS ([32][256] fp32 = 32 KiB).  The per-row
+  // factors (length mask, partial-conv ratio: an integer division and a dependent lens[] load each)
+  // are computed once per row into LDS and the bias of this thread's 4 columns is kept in
+  // registers: with one workgroup per CU nothing else hides the latency of loads in this tail.
+  const radmmm::EpilogueCtx ec(p);
+  float* smf = reinterpret_cast<float*>(sm);
+  float2* rowf = reinterpret_cast<float2*>(sm + 32768);
+  if (tid < G::BMR) {
+    float mk, rt;
+    radmmm::epilogue_row_factors(p, ec, m0 + tid, mk, rt);
+    rowf[tid] = make_float2(mk, rt);
+  }
+  float biasv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const int c = n0 + (tid & 63) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
+  }
+  epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
+}
+
+template <int MB, int ABL = 0>
+int launch(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  using G = Geo<MB>;
+  static int once = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3w_kernel<MB, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+    if (e != hipSuccess) {
+      radmmm::set_error("hipFuncSetAttribute(rowgemm_h3w<%d>): %s", MB, hipGetErrorString(e));
+      return -2;
+    }
+    return 0;
+  }();
+  if (once) return once;
+  const radmmm_rowgemm_desc& p = d.base;
+  const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((rowgemm_h3w_kernel<MB, ABL>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  return radmmm::check_launch("rowgemm_h3w");
+}
+
+}  // namespace
+
+namespace radmmm {
+
+// Row-block count per workgroup: minimise (rounds of the CUs) x (MFMA rows per workgroup + fixed
+// per-workgroup cost in the same unit); ties go to the larger tile (fewer operand re-reads).
+int pick_h3w_mb(int M, int N, int slots) {
+  const int ntn = (N + BN - 1) / BN;
+  int best = 4;
+  double best_cost = 1e300;
+  for (int mb = 4; mb <= 7; ++mb) {   // MB = 8 compiles with spills; kept for experiments via RADMMM_H3W_MB
+    const long long wg = (long long)((M + 32 * mb - 1) / (32 * mb)) * ntn;
+    const double rounds = (double)((wg + slots - 1) / slots);
+    const double cost = rounds * (mb + 0.75);
+    if (cost <= best_cost + 1e-9) {
+      best_cost = cost;
+      best = mb;
+    }
+  }
+  return best;
+}
+
+int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  static const int slots = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int mb = pick_h3w_mb(d.base.M, d.base.N, slots);
+  if (const char* e = getenv("RADMMM_H3W_MB")) {
+    const int v = atoi(e);
+    if (v >= 4 && v <= 8) mb = v;
+  }
+#ifdef RADMMM_ABLATION
+  if (const char* e = getenv("RADMMM_H3W_ABL")) {
+    switch (atoi(e)) {
+      case 1: return launch<7, 1>(d, stream, a_bytes, b_bytes);
+      case 2: return launch<7, 2>(d, stream, a_bytes, b_bytes);
+      case 3: return launch<7, 3>(d, stream, a_bytes, b_bytes);
+      case 4: return launch<7, 4>(d, stream, a_bytes, b_bytes);
+      case 7: return launch<7, 7>(d, stream, a_bytes, b_bytes);
+      case 8: return launch<7, 8>(d, stream, a_bytes, b_bytes);
+      case 11: return launch<7, 11>(d, stream, a_bytes, b_bytes);
+      case 12: return launch<7, 12>(d, stream, a_bytes, b_bytes);
+      case 14: return launch<7, 14>(d, stream, a_bytes, b_bytes);
+      case 15: return launch<7, 15>(d, stream, a_bytes, b_bytes);
+      default: break;
+    }
+  }
+#endif
+  switch (mb) {
+    case 4: return launch<4>(d, stream, a_bytes, b_bytes);
+    case 5: return launch<5>(d, stream, a_bytes, b_bytes);
+    case 6: return launch<6>(d, stream, a_bytes, b_bytes);
+    case 7: return launch<7>(d, stream, a_bytes, b_bytes);
+    default: return launch<8>(d, stream, a_bytes, b_bytes);
+  }
+}
+
+}  // namespace radmmm

@@ -129,7 +129,7 @@ class RADMMMFlow(nn.Module):
         self.decoder_out_dims = n_mel_channels
         import os
         # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA) or "h3" (split-f16 x3, fp32-class accuracy)
-        self.gemm_precision = os.environ.get("RADMMM_PRECISION", "fp32")
+        self.gemm_precision = os.environ.get("RADMMM_PRECISION", "h3")
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
                                  os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
