@@ -294,6 +294,254 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgem
   epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant: the operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), no
+// staging registers and no ds_write instructions.  A wave instruction writes 1 KiB = 16 LDS rows
+// lane-linearly (lane l -> row l >> 2, 16-byte slot l & 3), so the XOR swizzle is applied on the
+// SOURCE side: lane l fetches chunk (l & 3) ^ ((l >> 4) & 3) of its row.  Out-of-range lanes (rows
+// beyond M / N, frames outside the utterance or masked) get an out-of-range buffer offset and
+// the DMA writes zeros.  The tile for step s + 1 is issued, two pieces per item, early in step s into
+// the other LDS stage and has the rest of the step to land; the barrier's vmcnt(0) retires it.
+template <int MB, int T>
+__device__ __forceinline__ void pin_items_dma() {
+  constexpr int NT = 2 * MB;
+  if constexpr (T < NT - LOOKAHEAD) {
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
+    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
+    if constexpr (2 * T + 1 < MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2, 0);
+    if constexpr (2 * T + 1 == MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
+    pin_items_dma<MB, T + 1>();
+  }
+}
+
+typedef __attribute__((address_space(3))) unsigned int* lds_u32_ptr;
+
+// 16 bytes per lane, global -> LDS at (wave-uniform dst) + 16 * lane.  Kept out of the kernel template
+// and behind the device-compile guard: in the host pass the builtin is unknown and silently drops the
+// whole kernel template's host stub.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
+template <int MB, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
+                                                              const int b_bytes) {
+  using G = Geo<MB>;
+  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NP = MB + 8;   // NG: 16-row groups of an A array; NP: DMA pieces per wave
+  constexpr bool DO_LOAD = !(ABL & 1), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
+  static_assert(MB >= 4 && MB <= 8 && D <= MB, "pipeline shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const radmmm_rowgemm_desc& p = q.base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BMR - 1) / G::BMR;
+  const int nt = ntn * ntm, wg = blockIdx.x;
+  const int xcd = wg & 7, loc = wg >> 3, qq = nt >> 3, r8 = nt & 7;
+  const int tile = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int m0 = tm * G::BMR, n0 = tn * BN;
+  const int kpt = p.K / BK;
+  const int nsteps = kpt * p.taps;
+
+  // DMA pieces of one wave per step: MB pieces of A (the 4*MB 16-row groups of {Ah, Al} dealt round
+  // robin to the 4 waves) + 8 pieces of B (4 groups of Bh, 4 of Bl).  This lane's row and chunk:
+  const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  int a_t[MB], a_lim[MB], a_base[MB], a_vo[MB], a_dst[MB], a_isl[MB], b_voff[4], b_dst[4];
+#pragma unroll
+  for (int k = 0; k < MB; ++k) {
+    const int c = 4 * k + wave;                       // wave-uniform
+    a_isl[k] = c >= NG ? 1 : 0;
+    const int j = c >= NG ? c - NG : c;
+    const int r = m0 + 16 * j + d_row;
+    a_t[k] = 0;
+    a_lim[k] = -1;
+    a_base[k] = 0;
+    if (r < p.M) {
+      const int b = r / p.T;
+      a_t[k] = r - b * p.T;
+      a_lim[k] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
+      a_base[k] = (b * p.T * q.lda_h + d_chunk * 8) * 2;
+    }
+    a_dst[k] = a_isl[k] * G::A_BYTES + j * 1024;
+    a_vo[k] = OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = 4 * k + wave;
+    const int n = n0 + 16 * j + d_row;
+    b_voff[k] = n < p.N ? (n * q.ldb_h + d_chunk * 8) * 2 : OOB;
+    b_dst[k] = 2 * G::A_BYTES + j * 1024;
+  }
+  const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Ah), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Al), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bh), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bl), 0, b_bytes, 0x00020000);
+
+  // per-lane A offsets of the tap being fetched, branch-free (control flow would split the pinned
+  // schedule): out-of-item / masked frames get OOB.  OOB + (k offset) stays >= 2^31 = out of range.
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
+    const int s = p.sign * (tap - p.taps / 2) * p.dil;
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      const int ts = a_t[k] + s;
+      const int ok = -(int)((ts >= 0) & (ts < a_lim[k]));        // all ones when the frame is readable
+      a_vo[k] = ((a_base[k] + ts * q.lda_h * 2) & ok) | (OOB & ~ok);
+    }
+  };
+  // piece w of 0 .. MB+7 of tile (tap, kb) into stage `buf`
+  auto dma_piece = [&](int buf, int w, int tap, int kb) __attribute__((always_inline)) {
+    const int sbase = buf * G::STAGE;
+    if (w < MB) {
+      dma16(a_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + sbase + a_dst[w]), a_vo[w] + kb * (BK * 2));
+    } else {
+      const int k = (w - MB) & 3, arr = (w - MB) >> 2;
+      const int vo = b_voff[k] + (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
+      dma16(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + sbase + b_dst[k] + arr * G::B_BYTES), vo);
+    }
+  };
+
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3;
+  const int f_off0 = f_row + (((0 + (lane >> 5)) ^ f_swz) << 4);
+  const int f_off1 = f_row + (((2 + (lane >> 5)) ^ f_swz) << 4);
+
+  int l_tap = 0, l_kb = 0;                             // tile being fetched; clamped to the last one
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool last = (l_tap == p.taps - 1) && (l_kb == kpt - 1);
+    const bool wrap = l_kb == kpt - 1;
+    l_kb = last ? l_kb : (wrap ? 0 : l_kb + 1);
+    l_tap = (wrap && !last) ? l_tap + 1 : l_tap;
+  };
+  set_tap(0);
+#pragma unroll
+  for (int w = 0; w < NP; ++w) dma_piece(0, w, 0, 0);
+  __syncthreads();
+  f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
+  if constexpr (!DO_READ) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      fah[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16);
+      fal[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16 + 512);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bh[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 20000 + t * 1024 + lane * 16);
+      bl[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 30000 + t * 1024 + lane * 16);
+    }
+  }
+  // fragment readers of LDS stage `bsel`
+  auto read_a = [&](int bsel, int t) __attribute__((always_inline)) {
+    if constexpr (!DO_READ) return;
+    const unsigned char* st = sm + bsel * G::STAGE;
+    const int fo = (t >= MB) ? f_off1 : f_off0;
+    const int i = t >= MB ? t - MB : t;
+    fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
+    fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+  };
+  auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
+    if constexpr (!DO_READ) return;
+    const unsigned char* sB = sm + bsel * G::STAGE + 2 * G::A_BYTES + wave * 64 * ROWB;
+    const int fo = kb ? f_off1 : f_off0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
+      bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+    }
+  };
+  auto mfma_item = [&](int t) __attribute__((always_inline)) {
+    const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
+    if constexpr (DO_MFMA) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+    } else {
+      asm volatile("" ::"v"(fah[t]), "v"(fal[t]), "v"(bh[kb][0]), "v"(bh[kb][1]), "v"(bl[kb][0]), "v"(bl[kb][1]));
+    }
+  };
+  // first fragments of step 0; every later step gets them from the tail of the previous one
+  read_b(0, 0);
+#pragma unroll
+  for (int t = 0; t < D; ++t) read_a(0, t);
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    advance();                                       // -> tile step + 1
+    set_tap(l_tap);
+    // items 0 .. NT-D-1: fragments of item t + D | MFMAs of item t | two DMA pieces of tile step + 1
+#pragma unroll
+    for (int t = 0; t < NT - D; ++t) {
+      read_a(buf, t + D);
+      if (t + D == MB) read_b(buf, 1);
+      mfma_item(t);
+      if constexpr (DO_LOAD) {
+        if (2 * t < NP) dma_piece(buf ^ 1, 2 * t, l_tap, l_kb);
+        if (2 * t + 1 < NP) dma_piece(buf ^ 1, 2 * t + 1, l_tap, l_kb);
+      }
+    }
+    pin_items_dma<MB, 0>();
+    // every read of stage `buf` has been issued: retire them and this wave's DMA, meet the other
+    // waves, then fetch the first fragments of the next step while the last D items' MFMAs run
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(buf ^ 1, 0);
+#pragma unroll
+    for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
+#pragma unroll
+    for (int t = NT - D; t < NT; ++t) mfma_item(t);
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6 * D, 0);
+  }
+  __syncthreads();                                   // stray fragment reads / DMA of the clamped extra tile
+
+  const radmmm::EpilogueCtx ec(p);
+  float* smf = reinterpret_cast<float*>(sm);
+  float2* rowf = reinterpret_cast<float2*>(sm + 32768);
+  if (tid < G::BMR) {
+    float mk, rt;
+    radmmm::epilogue_row_factors(p, ec, m0 + tid, mk, rt);
+    rowf[tid] = make_float2(mk, rt);
+  }
+  float biasv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const int c = n0 + (tid & 63) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
+  }
+  epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
+}
+
+template <int MB, int ABL = 0>
+int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  using G = Geo<MB>;
+  static int once = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+    if (e != hipSuccess) {
+      radmmm::set_error("hipFuncSetAttribute(rowgemm_h3d<%d>): %s", MB, hipGetErrorString(e));
+      return -2;
+    }
+    return 0;
+  }();
+  if (once) return once;
+  const radmmm_rowgemm_desc& p = d.base;
+  const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  return radmmm::check_launch("rowgemm_h3d");
+}
+
 template <int MB, int ABL = 0>
 int launch(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = Geo<MB>;
@@ -345,6 +593,33 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
   if (const char* e = getenv("RADMMM_H3W_MB")) {
     const int v = atoi(e);
     if (v >= 4 && v <= 8) mb = v;
+  }
+  // default: LDS-DMA staging (rowgemm_h3d_kernel); RADMMM_H3W_DMA=0 selects the register-staged variant
+  static const bool dma = [] {
+    const char* e = getenv("RADMMM_H3W_DMA");
+    return !(e && atoi(e) == 0);
+  }();
+  if (dma) {
+#ifdef RADMMM_ABLATION
+    if (const char* e = getenv("RADMMM_H3W_ABL")) {
+      switch (atoi(e)) {
+        case 1: return launch_dma<7, 1>(d, stream, a_bytes, b_bytes);
+        case 4: return launch_dma<7, 4>(d, stream, a_bytes, b_bytes);
+        case 5: return launch_dma<7, 5>(d, stream, a_bytes, b_bytes);
+        case 8: return launch_dma<7, 8>(d, stream, a_bytes, b_bytes);
+        case 12: return launch_dma<7, 12>(d, stream, a_bytes, b_bytes);
+        case 13: return launch_dma<7, 13>(d, stream, a_bytes, b_bytes);
+        default: break;
+      }
+    }
+#endif
+    switch (mb) {
+      case 4: return launch_dma<4>(d, stream, a_bytes, b_bytes);
+      case 5: return launch_dma<5>(d, stream, a_bytes, b_bytes);
+      case 6: return launch_dma<6>(d, stream, a_bytes, b_bytes);
+      case 7: return launch_dma<7>(d, stream, a_bytes, b_bytes);
+      default: return launch_dma<8>(d, stream, a_bytes, b_bytes);
+    }
   }
 #ifdef RADMMM_ABLATION
   if (const char* e = getenv("RADMMM_H3W_ABL")) {
