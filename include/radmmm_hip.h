@@ -323,6 +323,9 @@ int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, co
 int radmmm_transpose_split_act(const float* x, int ld, int C, int B, int T, int Tp, int front,
                                const int32_t* lens, int mask_mode, float scale, void* oh, void* ol,
                                void* o1h, void* o1l, int ldk, radmmm_stream_t stream);
+/* number of workgroup tiles radmmm_wgrad_h3 launches per split (the caller picks `splits` so that
+ * tiles * splits fills whole rounds of the CUs: one workgroup per CU) */
+int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);
 int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void* Xl, const void* X1h,
                     const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
                     int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream);

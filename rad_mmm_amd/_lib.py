@@ -102,6 +102,7 @@ def _load() -> C.CDLL:
         "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
+        "radmmm_wgrad_h3_tiles": [i, i, i],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],

@@ -18,12 +18,12 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned int* lds_u32_ptr;
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PITCH = 40, TILE_H = BM * PITCH;
-constexpr int SMEM_BYTES = 2 * 4 * TILE_H * 2;   // 80 KiB
+constexpr int BN = 256, BK = 32, ROWB = 64;
 constexpr int OOB = 0x7fffffff;
+constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100;
+constexpr int LOOKAHEAD = 2;
 
 struct WgradH3Args {
   const _Float16 *GYh, *GYl;      // [Mc][ldk]
@@ -36,20 +36,88 @@ struct WgradH3Args {
   int a_bytes, b_bytes;           // exact extents of the operand arrays (buffer range check)
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradH3Args a) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntm = (a.Mc + BM - 1) / BM, ntn = (a.Nc + BN - 1) / BN;
-  int id = blockIdx.x;
+// Same tile machine as rowgemm_h3w.hip's rowgemm_h3d_kernel (one workgroup per CU, (32*MB) x 256
+// tile, 4 waves x (MB x 2) accumulators, swizzled 64-byte LDS rows filled by LDS-DMA, pinned
+// software pipeline); see that file for the layout.  Here both operands are plain [rows][ldk]
+// arrays, the tap is a constant column offset of the B operand and the K range is one split.
+template <int MB>
+struct Geo {
+  static constexpr int BMR = MB * 32;
+  static constexpr int A_BYTES = BMR * ROWB;
+  static constexpr int B_BYTES = BN * ROWB;
+  static constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  static constexpr int SMEM = 2 * STAGE;
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
+template <int MB, int T>
+__device__ __forceinline__ void pin_items() {
+  constexpr int NT = 2 * MB;
+  if constexpr (T < NT - LOOKAHEAD) {
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
+    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
+    if constexpr (2 * T + 1 < MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2, 0);
+    if constexpr (2 * T + 1 == MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
+    pin_items<MB, T + 1>();
+  }
+}
+
+template <int MB, int I>
+__device__ __forceinline__ void store_blocks(const f32x16 (&acc)[MB][2], float* smf, float* P, int ldp, int Mc, int Nc,
+                                             float sc, int m0, int n0, int tid, int lane, int wave, bool vec_ok) {
+  if constexpr (I < MB) {
+    if (I > 0) __syncthreads();
+    float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[I][j][e] * sc;
+    __syncthreads();
+    const int c4 = (tid & 63) * 4, col = n0 + c4;
+#pragma unroll 4
+    for (int k = 0; k < 8; ++k) {
+      const int rl = k * 4 + (tid >> 6);
+      const int row = m0 + I * 32 + rl;
+      if (row < Mc && col < Nc) {
+        const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
+        if (vec_ok && col + 3 < Nc) {
+          *reinterpret_cast<float4*>(P + (long long)row * ldp + col) = a4;
+        } else {
+          const float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < Nc) P[(long long)row * ldp + col + e] = v[e];
+        }
+      }
+    }
+    store_blocks<MB, I + 1>(acc, smf, P, ldp, Mc, Nc, sc, m0, n0, tid, lane, wave, vec_ok);
+  }
+}
+
+template <int MB>
+__global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
+  using G = Geo<MB>;
+  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NP = MB + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntm = (a.Mc + G::BMR - 1) / G::BMR, ntn = (a.Nc + BN - 1) / BN;
+  const int nt = ntm * ntn * a.taps * a.splits, wg = blockIdx.x;
+  const int xcd = wg & 7, loc = wg >> 3, qq = nt >> 3, r8 = nt & 7;
+  int id = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
   const int tn = id % ntn; id /= ntn;
   const int tm = id % ntm; id /= ntm;
   const int tap = id % a.taps;
   const int split = id / a.taps;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * G::BMR, n0 = tn * BN;
   const int shift = (tap - a.taps / 2) * a.dil;
-  // odd shift -> read the advanced copy at shift-1 (even)
-  const bool odd = (shift & 1) != 0;
+  const bool odd = (shift & 1) != 0;                 // odd shift -> the advanced copy at shift - 1
   const int bshift = odd ? shift - 1 : shift;
 
   const int steps_total = a.Kt / BK;
@@ -59,122 +127,144 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(const WgradH3Args a) {
   if (step_hi > steps_total) step_hi = steps_total;
   const int nsteps = step_hi - step_lo;
 
-  const int s_row = tid >> 2, s_chunk = tid & 3;
-  int a_voff[2], b_voff[2];
+  const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  int a_vo[MB], a_dst[MB], a_isl[MB], b_vo[4], b_dst[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = m0 + s_row + 64 * i, rb = n0 + s_row + 64 * i;
-    a_voff[i] = ra < a.Mc ? (ra * a.ldk + s_chunk * 8) * 2 : OOB;
-    b_voff[i] = rb < a.Nc ? (rb * a.ldk + s_chunk * 8) * 2 : OOB;
+  for (int k = 0; k < MB; ++k) {
+    const int c = 4 * k + wave;
+    a_isl[k] = c >= NG ? 1 : 0;
+    const int j = c >= NG ? c - NG : c;
+    const int r = m0 + 16 * j + d_row;
+    a_vo[k] = r < a.Mc ? (r * a.ldk + d_chunk * 8 + a.k0) * 2 : OOB;
+    a_dst[k] = a_isl[k] * G::A_BYTES + j * 1024;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = 4 * k + wave;
+    const int n = n0 + 16 * j + d_row;
+    b_vo[k] = n < a.Nc ? (n * a.ldk + d_chunk * 8 + a.k0 + bshift) * 2 : OOB;
+    b_dst[k] = 2 * G::A_BYTES + j * 1024;
   }
   const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.GYh), 0, a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.GYl), 0, a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(odd ? a.X1h : a.Xh), 0, a.b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(odd ? a.X1l : a.Xl), 0, a.b_bytes, 0x00020000);
 
-  struct Regs {
-    u32x4 v[4][2];
-  };
-  auto load_tiles = [&](int step, Regs& R) __attribute__((always_inline)) {
-    const int so_a = (a.k0 + step * BK) * 2;
-    // columns k + bshift >= 0 because k0 >= max |shift| (checked by the host): offsets never go
-    // negative; a read past the row end lands in the next row's leading zeros or, for the last
-    // row, is range-checked to zero
-    const int so_b = so_a + bshift * 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      R.v[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rAh, a_voff[i], so_a, 0);
-      R.v[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rAl, a_voff[i], so_a, 0);
-      R.v[2][i] = __builtin_amdgcn_raw_buffer_load_b128(rBh, b_voff[i], so_b, 0);
-      R.v[3][i] = __builtin_amdgcn_raw_buffer_load_b128(rBl, b_voff[i], so_b, 0);
+  // piece w of 0 .. MB+7 of K step `step` (absolute) into stage `buf`.  OOB + (step offset) stays
+  // >= 2^31, i.e. out of range.
+  auto dma_piece = [&](int buf, int w, int step) __attribute__((always_inline)) {
+    const int sbase = buf * G::STAGE;
+    const int koff = step * (BK * 2);
+    if (w < MB) {
+      dma16(a_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + sbase + a_dst[w]), a_vo[w] + koff);
+    } else {
+      const int k = (w - MB) & 3, arr = (w - MB) >> 2;
+      dma16(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + sbase + b_dst[k] + arr * G::B_BYTES), b_vo[k] + koff);
     }
   };
-  auto store_tiles = [&](int buf, const Regs& R) __attribute__((always_inline)) {
-    _Float16* base = smh + buf * 4 * TILE_H;
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<u32x4*>(base + o * TILE_H + (s_row + 64 * i) * PITCH + s_chunk * 8) = R.v[o][i];
-  };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MB][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int f_off = (lane & 31) * PITCH + (lane >> 5) * 8;
+  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3;
+  const int f_off0 = f_row + (((0 + (lane >> 5)) ^ f_swz) << 4);
+  const int f_off1 = f_row + (((2 + (lane >> 5)) ^ f_swz) << 4);
+  f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
+  auto read_a = [&](int bsel, int t) __attribute__((always_inline)) {
+    const unsigned char* st = sm + bsel * G::STAGE;
+    const int fo = (t >= MB) ? f_off1 : f_off0;
+    const int i = t >= MB ? t - MB : t;
+    fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
+    fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+  };
+  auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
+    const unsigned char* sB = sm + bsel * G::STAGE + 2 * G::A_BYTES + wave * 64 * ROWB;
+    const int fo = kb ? f_off1 : f_off0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
+      bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+    }
+  };
+  auto mfma_item = [&](int t) __attribute__((always_inline)) {
+    const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
+    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
+    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
+    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+  };
+
   if (nsteps > 0) {
-    Regs R;
-    load_tiles(step_lo, R);
-    store_tiles(0, R);
+#pragma unroll
+    for (int w = 0; w < NP; ++w) dma_piece(0, w, step_lo);
     __syncthreads();
+    read_b(0, 0);
+#pragma unroll
+    for (int t = 0; t < D; ++t) read_a(0, t);
     for (int s = 0; s < nsteps; ++s) {
       const int buf = s & 1;
-      const int nxt = s + 1 < nsteps ? s + 1 : s;
-      load_tiles(step_lo + nxt, R);
-      const _Float16* base = smh + buf * 4 * TILE_H;
+      const int nxt = step_lo + (s + 1 < nsteps ? s + 1 : s);   // clamped: the last step re-fetches itself
 #pragma unroll
-      for (int kb = 0; kb < BK / 16; ++kb) {
-        f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int ro = (wm * 64 + t * 32) * PITCH + kb * 16 + f_off;
-          const int co = (wn * 64 + t * 32) * PITCH + kb * 16 + f_off;
-          ah[t] = *reinterpret_cast<const f16x8*>(base + 0 * TILE_H + ro);
-          al[t] = *reinterpret_cast<const f16x8*>(base + 1 * TILE_H + ro);
-          bh[t] = *reinterpret_cast<const f16x8*>(base + 2 * TILE_H + co);
-          bl[t] = *reinterpret_cast<const f16x8*>(base + 3 * TILE_H + co);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+      for (int t = 0; t < NT - D; ++t) {
+        read_a(buf, t + D);
+        if (t + D == MB) read_b(buf, 1);
+        mfma_item(t);
+        if (2 * t < NP) dma_piece(buf ^ 1, 2 * t, nxt);
+        if (2 * t + 1 < NP) dma_piece(buf ^ 1, 2 * t + 1, nxt);
       }
-      store_tiles(buf ^ 1, R);
+      pin_items<MB, 0>();
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(buf ^ 1, 0);
+#pragma unroll
+      for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
+#pragma unroll
+      for (int t = NT - D; t < NT; ++t) mfma_item(t);
+      __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
+      __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6 * D, 0);
     }
+    __syncthreads();
   }
 
-  // epilogue through LDS: [128][128] fp32 (64 KiB of the 80 KiB)
-  float* smf = reinterpret_cast<float*>(smh);
-  {
-    float* base = smf + (wm * 64 + 4 * (lane >> 5)) * BN + wn * 64 + (lane & 31);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          base[(mi * 32 + (e & 3) + 8 * (e >> 2)) * BN + ni * 32] = acc[mi][ni][e] * a.acc_scale;
-  }
-  __syncthreads();
   float* P = a.P + (long long)split * a.split_stride + (long long)tap * a.Mc * a.ldp;
   const bool vec_ok = (a.ldp % 4 == 0) && radmmm::aligned16(a.P) && (a.split_stride % 4 == 0);
-  const int c4 = (tid & 31) * 4;
-  const int col = n0 + c4;
-  for (int i = 0; i < 16; ++i) {
-    const int rl = i * 8 + (tid >> 5);
-    const int row = m0 + rl;
-    if (row < a.Mc && col < a.Nc) {
-      const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
-      if (vec_ok && col + 3 < a.Nc) {
-        *reinterpret_cast<float4*>(P + (long long)row * a.ldp + col) = a4;
-      } else {
-        const float v[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < a.Nc) P[(long long)row * a.ldp + col + e] = v[e];
-      }
+  store_blocks<MB, 0>(acc, reinterpret_cast<float*>(sm), P, a.ldp, a.Mc, a.Nc, a.acc_scale, m0, n0, tid, lane, wave, vec_ok);
+}
+
+template <int MB>
+int launch_wgrad(const WgradH3Args& a, hipStream_t stream) {
+  using G = Geo<MB>;
+  static int once = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel<MB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+    if (e != hipSuccess) {
+      radmmm::set_error("hipFuncSetAttribute(wgrad_h3<%d>): %s", MB, hipGetErrorString(e));
+      return -2;
     }
+    return 0;
+  }();
+  if (once) return once;
+  const int ntm = (a.Mc + G::BMR - 1) / G::BMR, ntn = (a.Nc + BN - 1) / BN;
+  hipLaunchKernelGGL(wgrad_h3_kernel<MB>, dim3(ntm * ntn * a.taps * a.splits), dim3(256), G::SMEM, stream, a);
+  return radmmm::check_launch("wgrad_h3");
+}
+
+// rows per workgroup tile the kernel will use for Mc output channels: the largest MB whose last
+// row tile is at least 3/4 full (1024 -> 8 x 32 = 256 rows)
+int wgrad_mb(int Mc) {
+  for (int mb = 8; mb > 4; --mb) {
+    const int rows = 32 * mb, nt = (Mc + rows - 1) / rows;
+    if (nt * rows - Mc <= rows / 4) return mb;
   }
+  return 4;
 }
 
 // fp32 [B*T rows][ld] (first C columns) -> split, transposed, zero-gapped [C][ldk]:
@@ -234,9 +324,15 @@ extern "C" int radmmm_transpose_split_act(const float* x, int ld, int C, int B, 
   return radmmm::check_launch("transpose_split_act");
 }
 
+extern "C" int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps) {
+  if (Mc <= 0 || Nc <= 0 || taps <= 0) return 0;
+  const int rows = 32 * wgrad_mb(Mc);
+  return ((Mc + rows - 1) / rows) * ((Nc + BN - 1) / BN) * taps;
+}
+
 extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void* Xl, const void* X1h,
-                               const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc, int Nc,
-                               int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream) {
+                               const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
+                               int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream) {
   RADMMM_REQUIRE(GYh && GYl && Xh && Xl && P, "wgrad_h3: null pointer");
   RADMMM_REQUIRE(Mc > 0 && Nc > 0 && taps >= 1 && dil >= 1 && splits >= 1 && Kt > 0 && Kt % BK == 0 && ldk % 8 == 0 && k0 % 8 == 0 &&
                      ldk >= k0 + Kt + (taps / 2) * dil && k0 >= (taps / 2) * dil,
@@ -246,16 +342,6 @@ extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh,
   RADMMM_REQUIRE(!has_odd || (X1h && X1l), "wgrad_h3: odd tap shifts need the advanced copy X1");
   const long long a_bytes = (long long)Mc * ldk * 2, b_bytes = (long long)Nc * ldk * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "wgrad_h3: operand >= 2 GiB");
-  static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) {
-      radmmm::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return -2;
-    }
-    return 0;
-  }();
-  if (once) return once;
   WgradH3Args a;
   a.GYh = static_cast<const _Float16*>(GYh); a.GYl = static_cast<const _Float16*>(GYl);
   a.Xh = static_cast<const _Float16*>(Xh); a.Xl = static_cast<const _Float16*>(Xl);
@@ -263,8 +349,12 @@ extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh,
   a.ldk = ldk; a.k0 = k0; a.Kt = Kt; a.P = P; a.ldp = ldp; a.split_stride = split_stride;
   a.Mc = Mc; a.Nc = Nc; a.taps = taps; a.dil = dil; a.splits = splits; a.acc_scale = acc_scale;
   a.a_bytes = (int)a_bytes; a.b_bytes = (int)b_bytes;
-  const int ntm = (Mc + BM - 1) / BM, ntn = (Nc + BN - 1) / BN;
-  hipLaunchKernelGGL(wgrad_h3_kernel, dim3(ntm * ntn * taps * splits), dim3(256), SMEM_BYTES,
-                     static_cast<hipStream_t>(stream), a);
-  return radmmm::check_launch("wgrad_h3");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (wgrad_mb(Mc)) {
+    case 8: return launch_wgrad<8>(a, st);
+    case 7: return launch_wgrad<7>(a, st);
+    case 6: return launch_wgrad<6>(a, st);
+    case 5: return launch_wgrad<5>(a, st);
+    default: return launch_wgrad<4>(a, st);
+  }
 }

@@ -499,8 +499,8 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale):
     gh, gl, _, _, Kt = gy_t
     xh, xl, x1h, x1l, Kt2 = x_t
     assert Kt == Kt2
-    tiles = -(-Mc // 128) * -(-Nc // 128) * taps
-    S = pick_splits(tiles, Kt)
+    tiles = int(lib.radmmm_wgrad_h3_tiles(Mc, Nc, taps))
+    S = pick_splits(tiles, Kt, slots=256)            # one workgroup per CU
     P = torch.empty(S, taps, Mc, ldp, device=gh.device, dtype=torch.float32)
     if ldp != Nc:
         P.zero_()
