@@ -330,6 +330,21 @@ int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void
                     const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
                     int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream);
 
+/* Bidirectional single-layer LSTM, recurrent part (reference: the decoder's context LSTM,
+ * models/radmmm.py:141-146 = torch.nn.LSTM(bidirectional, batch_first) on a packed batch; gate order
+ * i, f, g, o; frames t >= lens[b] produce h = c = 0 as pad_packed_sequence does).
+ *   G  [B*T][8H]  in: x W_ih^T + b_ih + b_hh (direction d in columns d*4H ..); out: gate activations
+ *   W_hh [2][4H][H];  y, c [B*T][2H];  scratch sizes: radmmm_lstm_scratch_bytes(B, H, which) with
+ *   which = 0 wsplit, 1 hsplit (fwd), 2 wtpack, 3 P, 4 dcbuf (bwd).
+ * radmmm_lstm_bwd overwrites G with the pre-activation gradients dG; the input / weight / bias
+ * gradients are plain GEMMs of dG (dW_ih = dG^T x, dx = dG W_ih, db = colsum dG, dW_hh[d] = dG_d^T h_prev).
+ * gscale: device scalar, power of two bringing dG into fp16 range (e.g. 2^floor(log2(64 / max|dy|))). */
+int64_t radmmm_lstm_scratch_bytes(int B, int H, int which);
+int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32_t* lens, void* wsplit, void* hsplit,
+                    int B, int T, int H, radmmm_stream_t stream);
+int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens, void* wtpack,
+                    float* P, float* dcbuf, int B, int T, int H, const float* gscale, radmmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

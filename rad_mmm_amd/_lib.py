@@ -103,6 +103,8 @@ def _load() -> C.CDLL:
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
+        "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
+        "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],
@@ -125,7 +127,8 @@ def _load() -> C.CDLL:
                        "radmmm_masked_reduce_scratch_floats": [i, i, i],
                        "radmmm_mas_scratch_bytes": [i, i, i],
                        "radmmm_film_bwd_scratch_floats": [i, i],
-                       "radmmm_stft_mel_scratch_floats": [i, i, i, i, i]}.items():
+                       "radmmm_stft_mel_scratch_floats": [i, i, i, i, i],
+                       "radmmm_lstm_scratch_bytes": [i, i, i]}.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int64

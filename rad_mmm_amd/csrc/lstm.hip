@@ -1,0 +1,343 @@
+// Bidirectional single-layer LSTM (the decoder's context LSTM, reference models/radmmm.py:141-146 /
+// torch.nn.LSTM semantics incl. packed variable-length batches), recurrent part.
+//
+// The time loop is T' strictly sequential steps of a tiny GEMM ([B x H] x [H x 4H], B = 32,
+// H = 524) plus gate arithmetic.  MIOpen runs it as 4 launches per step and direction
+// (profiles/r01_h3b: 28.6 ms of a 129 ms training step).  Here one launch per step serves BOTH
+// directions and fuses GEMM + gates + state update:
+//
+//  forward step s  (dir 0: t = s, dir 1: t = T-1-s), workgroup = (8 hidden units, direction):
+//     a[b][g*8+j] = sum_k h_prev[b][k] * W_hh[g*H + u0 + j][k]        32 x 32 x H split-f16 MFMA, K
+//                                                                      split over the 4 waves
+//     gates = act(a + Gx[b][t])  (Gx = x W_ih^T + b_ih + b_hh, precomputed by one big GEMM)
+//     c = f c_prev + i g,  h = o tanh(c);  frames t >= len[b] give h = c = 0 (packed-sequence
+//     semantics: the reverse direction starts at each utterance's own last frame)
+//     h is written to y (fp32) and, split hi/lo fp16, to the ping-pong operand buffer of step s+1;
+//     the gate activations overwrite Gx in place (saved for backward).
+//
+//  backward step s (dir 0: t = T-1-s, dir 1: t = s), same workgroup decomposition:
+//     dh = dy[b][t] + sum over all slices jj of P_prev[jj][b][u]       (recurrent gradient, see below)
+//     gate gradients dG (overwrite the saved gates in place: one [B*T][8H] buffer ends up holding
+//     the pre-activation gradients that the batched weight/input-gradient GEMMs consume)
+//     P[j][b][u'] = sum_{k' < 32} dG[b][k'] * W_hh[row(k')][u']        this slice's 32 gate rows only
+//  i.e. the contraction over the 4H gate rows is split across the workgroups that own them and the
+//  partial products are summed by the consumer one step later: every workgroup reads one slice
+//  of W_hh (67 KB) + one [B x 8] column block of all partials (67 KB) per step instead of the
+//  whole dG row block and a 16-column slab of W_hh^T (400 KB).
+//
+// All recurrent products use the split-f16 scheme of rowgemm_h3.hip (hi/lo fp16 operands, three
+// MFMA products, fp32 accumulate): max rel. error ~2e-6.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int UPW = 8;          // hidden units per workgroup (x 4 gates = 32 gate rows = one MFMA tile)
+constexpr int MAXKB = 12;       // k blocks (16 wide) per wave in the forward GEMM: H <= 4*12*16 = 768
+
+struct LstmArgs {
+  // forward
+  float* G;                     // [B*T][8H]: in  x W_ih^T + b  /  out gate activations (i, f, g, o per direction)
+  const _Float16 *Wh, *Wl;      // [2][4H][ldk] split W_hh (zero padded k >= H)
+  _Float16 *hs_h, *hs_l;        // [2 dirs][2 ping-pong][Bp][ldk] split h operand
+  float* y;                     // [B*T][2H]
+  float* c;                     // [B*T][2H]
+  const int* lens;              // [B] or null
+  int B, T, H, ldk, Bp;         // Bp = B rounded up to 32
+  // backward
+  const float* dy;              // [B*T][2H]
+  const _Float16 *Wth, *Wtl;    // [2][NS][Hp][32] packed transposed slices (k' = gate*8 + unit-in-slice)
+  float* P;                     // [2 dirs][2 ping-pong][Bp/32][NS][32][Hp] partial recurrent gradients
+  float* dcbuf;                 // [2][Bp][H] carried cell gradient
+  int Hp, NS;                   // Hp = H rounded up to 32, NS = ceil(H / 8)
+  const float* gscale;          // device scalar: power-of-two scale applied to dG before the fp16 split
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+  const float e = __expf(-2.f * fabsf(x));
+  const float t = __fdividef(1.f - e, 1.f + e);
+  return x < 0.f ? -t : t;
+}
+__device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
+  v = fminf(fmaxf(v, -60000.f), 60000.f);
+  h = (_Float16)v;
+  l = (_Float16)(v - (float)h);
+}
+
+// ---- weight preparation ---------------------------------------------------------------------------
+// W [2][4H][H] fp32 -> Wh/Wl [2][4H][ldk]
+__global__ void lstm_split_w_kernel(const float* __restrict__ W, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
+                                    int rows, int H, int ldk) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows * ldk) return;
+  const int r = (int)(idx / ldk), k = (int)(idx - (long long)r * ldk);
+  _Float16 h, l;
+  split_h(k < H ? W[(long long)r * H + k] : 0.f, h, l);
+  Wh[idx] = h;
+  Wl[idx] = l;
+}
+// W [2][4H][H] -> Wt [2][NS][Hp][32]: Wt[d][j][u][g*8 + ju] = W[d][g*H + 8j + ju][u]
+__global__ void lstm_pack_wt_kernel(const float* __restrict__ W, _Float16* __restrict__ Wth, _Float16* __restrict__ Wtl,
+                                    int H, int Hp, int NS) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = 2LL * NS * Hp * 32;
+  if (idx >= total) return;
+  const int kq = (int)(idx & 31);
+  long long rest = idx >> 5;
+  const int u = (int)(rest % Hp); rest /= Hp;
+  const int j = (int)(rest % NS);
+  const int d = (int)(rest / NS);
+  const int g = kq >> 3, unit = 8 * j + (kq & 7);
+  float v = 0.f;
+  if (unit < H && u < H) v = W[((long long)d * 4 * H + (long long)g * H + unit) * H + u];
+  _Float16 h, l;
+  split_h(v, h, l);
+  Wth[idx] = h;
+  Wtl[idx] = l;
+}
+
+// ---- forward step -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a, const int s) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.x, d = blockIdx.y, bb = blockIdx.z * 32;
+  const int t = d == 0 ? s : a.T - 1 - s;
+  const int H = a.H, ldk = a.ldk;
+  const _Float16* hs_h = a.hs_h + ((long long)(d * 2 + (s & 1)) * a.Bp + bb) * ldk;
+  const _Float16* hs_l = a.hs_l + ((long long)(d * 2 + (s & 1)) * a.Bp + bb) * ldk;
+  const _Float16* Wh = a.Wh + (long long)d * 4 * H * ldk;
+  const _Float16* Wl = a.Wl + (long long)d * 4 * H * ldk;
+
+  // operand fragments straight from global memory (L2 resident): lane -> row (lane & 31), 8 k at 8 (lane >> 5)
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  const int n_g = fr >> 3, n_unit = UPW * j + (fr & 7);
+  const bool n_ok = n_unit < H;
+  const long long a_off = (long long)fr * ldk + fk;                       // rows >= B are zero in the operand buffer
+  const long long b_off = ((long long)n_g * H + n_unit) * ldk + fk;
+  const int nkb = ldk >> 4;
+  f16x8 ah[MAXKB], al[MAXKB], bh[MAXKB], bl[MAXKB];
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < MAXKB; ++i) {
+    const int kb = wave + 4 * i;
+    const bool ok = kb < nkb;
+    ah[i] = ok ? *reinterpret_cast<const f16x8*>(hs_h + a_off + kb * 16) : z8;
+    al[i] = ok ? *reinterpret_cast<const f16x8*>(hs_l + a_off + kb * 16) : z8;
+    bh[i] = (ok && n_ok) ? *reinterpret_cast<const f16x8*>(Wh + b_off + kb * 16) : z8;
+    bl[i] = (ok && n_ok) ? *reinterpret_cast<const f16x8*>(Wl + b_off + kb * 16) : z8;
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < MAXKB; ++i) {
+    if (wave + 4 * i < nkb) {                                  // wave-uniform
+      f32x16& acc = (i & 1) ? acc1 : acc0;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[i], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[i], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[i], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)][lane & 31] = acc0[e] + acc1[e];
+  __syncthreads();
+
+  // gates and state update: thread -> (batch row, unit of the slice)
+  const int bl_ = tid >> 3, ju = tid & 7;
+  const int b = bb + bl_, u = UPW * j + ju;
+  if (u >= H) return;
+  _Float16* ho_h = a.hs_h + ((long long)(d * 2 + ((s + 1) & 1)) * a.Bp + bb + bl_) * ldk + u;
+  _Float16* ho_l = a.hs_l + ((long long)(d * 2 + ((s + 1) & 1)) * a.Bp + bb + bl_) * ldk + u;
+  if (b >= a.B) return;                                        // operand rows >= B stay zero (memset once)
+  const long long row = (long long)b * a.T + t;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    pre[g] = red[0][bl_][g * 8 + ju] + red[1][bl_][g * 8 + ju] + red[2][bl_][g * 8 + ju] + red[3][bl_][g * 8 + ju];
+  float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const bool valid = t < len;
+  const int tp = d == 0 ? t - 1 : t + 1;                       // time index of the previous step
+  float c_prev = 0.f;
+  if (tp >= 0 && tp < a.T) c_prev = a.c[((long long)b * a.T + tp) * 2 * H + (long long)d * H + u];
+  float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, hn = 0.f;
+  if (valid) {
+    ig = sigmoid_f(pre[0] + Gp[0]);
+    fg = sigmoid_f(pre[1] + Gp[H]);
+    gg = tanh_f(pre[2] + Gp[2 * H]);
+    og = sigmoid_f(pre[3] + Gp[3 * H]);
+    cn = fg * c_prev + ig * gg;
+    hn = og * tanh_f(cn);
+  }
+  Gp[0] = ig; Gp[H] = fg; Gp[2 * H] = gg; Gp[3 * H] = og;
+  a.c[row * 2 * H + (long long)d * H + u] = cn;
+  a.y[row * 2 * H + (long long)d * H + u] = hn;
+  _Float16 hh, hl;
+  split_h(hn, hh, hl);
+  *ho_h = hh;
+  *ho_l = hl;
+}
+
+// ---- backward step ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, const int s) {
+  __shared__ __attribute__((aligned(16))) _Float16 sAh[32][40], sAl[32][40];   // [batch][k' (32) + pad]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.x, d = blockIdx.y, bz = blockIdx.z, bb = bz * 32;
+  const int t = d == 0 ? a.T - 1 - s : s;
+  const int H = a.H, Hp = a.Hp, NS = a.NS, nbz = a.Bp >> 5;
+  const int bl_ = tid >> 3, ju = tid & 7;
+  const int b = bb + bl_, u = UPW * j + ju;
+
+  const float gsc = a.gscale[0];
+  float dG[4] = {0.f, 0.f, 0.f, 0.f};
+  if (b < a.B && u < H) {
+    const long long row = (long long)b * a.T + t;
+    const int len = a.lens ? a.lens[b] : a.T;
+    float dc_prev = 0.f;
+    if (t < len) {
+      float dh = a.dy[row * 2 * H + (long long)d * H + u];
+      float dc = 0.f;
+      if (s > 0) {
+        const float* Pp = a.P + ((((long long)(d * 2 + ((s - 1) & 1)) * nbz + bz) * NS) * 32 + bl_) * Hp + u;
+        float s0 = 0.f, s1 = 0.f;
+        int jj = 0;
+        for (; jj + 1 < NS; jj += 2) {
+          s0 += Pp[(long long)jj * 32 * Hp];
+          s1 += Pp[(long long)(jj + 1) * 32 * Hp];
+        }
+        if (jj < NS) s0 += Pp[(long long)jj * 32 * Hp];
+        dh += s0 + s1;
+        dc = a.dcbuf[((long long)d * a.Bp + b) * H + u];
+      }
+      float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
+      const float ig = Gp[0], fg = Gp[H], gg = Gp[2 * H], og = Gp[3 * H];
+      const float cn = a.c[row * 2 * H + (long long)d * H + u];
+      const int tp = d == 0 ? t - 1 : t + 1;
+      float c_prev = 0.f;
+      if (tp >= 0 && tp < a.T) c_prev = a.c[((long long)b * a.T + tp) * 2 * H + (long long)d * H + u];
+      const float tc = tanh_f(cn);
+      dc += dh * og * (1.f - tc * tc);
+      dG[0] = dc * gg * ig * (1.f - ig);
+      dG[1] = dc * c_prev * fg * (1.f - fg);
+      dG[2] = dc * ig * (1.f - gg * gg);
+      dG[3] = dh * tc * og * (1.f - og);
+      dc_prev = dc * fg;
+      Gp[0] = dG[0]; Gp[H] = dG[1]; Gp[2 * H] = dG[2]; Gp[3 * H] = dG[3];
+    } else {
+      float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
+      Gp[0] = 0.f; Gp[H] = 0.f; Gp[2 * H] = 0.f; Gp[3 * H] = 0.f;
+    }
+    a.dcbuf[((long long)d * a.Bp + b) * H + u] = dc_prev;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    _Float16 h, l;
+    split_h(dG[g] * gsc, h, l);
+    sAh[bl_][g * 8 + ju] = h;
+    sAl[bl_][g * 8 + ju] = l;
+  }
+  __syncthreads();
+
+  // P[j][b][u'] = (1/gscale) * sum_k' A[b][k'] * Wt[d][j][u'][k']
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  f16x8 ah[2], al[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    ah[kb] = *reinterpret_cast<const f16x8*>(&sAh[fr][kb * 16 + fk]);
+    al[kb] = *reinterpret_cast<const f16x8*>(&sAl[fr][kb * 16 + fk]);
+  }
+  const _Float16* Wth = a.Wth + ((long long)d * NS + j) * Hp * 32;
+  const _Float16* Wtl = a.Wtl + ((long long)d * NS + j) * Hp * 32;
+  float* Po = a.P + (((long long)(d * 2 + (s & 1)) * nbz + bz) * NS + j) * 32 * Hp;
+  const float inv = 1.f / gsc;
+  const int ntile = Hp >> 5;
+  for (int tile = wave; tile < ntile; tile += 4) {
+    const _Float16* wr_h = Wth + ((long long)tile * 32 + fr) * 32 + fk;
+    const _Float16* wr_l = Wtl + ((long long)tile * 32 + fr) * 32 + fk;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(wr_h + kb * 16);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(wr_l + kb * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bh, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      Po[(long long)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * Hp + tile * 32 + (lane & 31)] = acc[e] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t radmmm_lstm_scratch_bytes(int B, int H, int which) {
+  // which 0: split W_hh (hi + lo), 1: h operand ping-pong (hi + lo), 2: packed transposed slices (hi + lo),
+  // 3: partial recurrent gradients P, 4: carried cell gradient
+  const int64_t ldk = (H + 15) / 16 * 16, Bp = (B + 31) / 32 * 32, Hp = (H + 31) / 32 * 32, NS = (H + UPW - 1) / UPW;
+  switch (which) {
+    case 0: return 2 * (2 * 4 * (int64_t)H * ldk * 2);
+    case 1: return 2 * (2 * 2 * Bp * ldk * 2);
+    case 2: return 2 * (2 * NS * Hp * 32 * 2);
+    case 3: return 2 * 2 * (Bp / 32) * NS * 32 * Hp * 4;
+    case 4: return 2 * Bp * (int64_t)H * 4;
+    default: return 0;
+  }
+}
+
+// Forward recurrence of both directions.  G [B*T][8H] holds x W_ih^T + b_ih + b_hh (direction d in
+// columns d*4H .., gate order i, f, g, o) and is overwritten by the gate activations; W_hh [2][4H][H];
+// y, c [B*T][2H] outputs; wsplit / hsplit scratch per radmmm_lstm_scratch_bytes(.., 0 / 1).
+extern "C" int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32_t* lens, void* wsplit,
+                               void* hsplit, int B, int T, int H, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(G && W_hh && y && c && wsplit && hsplit, "lstm_fwd: null pointer");
+  RADMMM_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 4 * MAXKB * 16, "lstm_fwd: bad dims (H <= %d)", 4 * MAXKB * 16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LstmArgs a = {};
+  a.G = G; a.y = y; a.c = c; a.lens = lens; a.B = B; a.T = T; a.H = H;
+  a.ldk = (H + 15) / 16 * 16; a.Bp = (B + 31) / 32 * 32; a.Hp = (H + 31) / 32 * 32; a.NS = (H + UPW - 1) / UPW;
+  const long long wn = 2LL * 4 * H * a.ldk;
+  _Float16* Wh = static_cast<_Float16*>(wsplit);
+  _Float16* Wl = Wh + wn;
+  a.Wh = Wh; a.Wl = Wl;
+  const long long hn = 2LL * 2 * a.Bp * a.ldk;
+  a.hs_h = static_cast<_Float16*>(hsplit);
+  a.hs_l = a.hs_h + hn;
+  hipLaunchKernelGGL(lstm_split_w_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, st, W_hh, Wh, Wl, 2 * 4 * H, H, a.ldk);
+  if (hipMemsetAsync(hsplit, 0, (size_t)(2 * hn * 2), st) != hipSuccess) {
+    radmmm::set_error("lstm_fwd: hipMemsetAsync failed");
+    return -2;
+  }
+  const dim3 grid(a.NS, 2, a.Bp / 32);
+  for (int s = 0; s < T; ++s) hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, st, a, s);
+  return radmmm::check_launch("lstm_fwd");
+}
+
+// Backward recurrence.  G holds the saved gate activations and is overwritten by the pre-activation
+// gradients dG [B*T][8H] (the caller forms dW_ih = dG^T x, dx = dG W_ih, db = colsum(dG),
+// dW_hh[d] = dG_d^T h_prev with plain GEMMs).  gscale: DEVICE scalar, a power of two that brings dG
+// into fp16 range (the caller derives it from max|dy| without a host sync).
+extern "C" int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens,
+                               void* wtpack, float* P, float* dcbuf, int B, int T, int H, const float* gscale,
+                               radmmm_stream_t stream) {
+  RADMMM_REQUIRE(G && c && dy && W_hh && wtpack && P && dcbuf && gscale, "lstm_bwd: null pointer");
+  RADMMM_REQUIRE(B > 0 && T > 0 && H > 0, "lstm_bwd: bad dims");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LstmArgs a = {};
+  a.G = G; a.c = const_cast<float*>(c); a.dy = dy; a.lens = lens; a.B = B; a.T = T; a.H = H;
+  a.ldk = (H + 15) / 16 * 16; a.Bp = (B + 31) / 32 * 32; a.Hp = (H + 31) / 32 * 32; a.NS = (H + UPW - 1) / UPW;
+  a.P = P; a.dcbuf = dcbuf; a.gscale = gscale;
+  const long long tn = 2LL * a.NS * a.Hp * 32;
+  _Float16* Wth = static_cast<_Float16*>(wtpack);
+  _Float16* Wtl = Wth + tn;
+  a.Wth = Wth; a.Wtl = Wtl;
+  hipLaunchKernelGGL(lstm_pack_wt_kernel, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, st, W_hh, Wth, Wtl, H, a.Hp, a.NS);
+  const dim3 grid(a.NS, 2, a.Bp / 32);
+  for (int s = 0; s < T; ++s) hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, st, a, s);
+  return radmmm::check_launch("lstm_bwd");
+}

@@ -130,6 +130,9 @@ class RADMMMFlow(nn.Module):
         import os
         # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA) or "h3" (split-f16 x3, fp32-class accuracy)
         self.gemm_precision = os.environ.get("RADMMM_PRECISION", "h3")
+        # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen);
+        # weight/spectral-normed variants (no shipped config uses them) stay on torch
+        self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if (use_context_lstm and context_lstm_norm is None) else "miopen"
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
                                  os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
@@ -196,6 +199,12 @@ class RADMMMFlow(nn.Module):
         if not self.use_context_lstm:
             return x.contiguous()
         ul = torch.div(seq_lens.lengths_host, g, rounding_mode="floor")
+        if self.lstm_impl == "hip":
+            # fused per-step HIP recurrence (csrc/lstm.hip); packed-sequence semantics via the lengths
+            from .lstm import bilstm
+            full = int(ul.min()) == Tg
+            lens32 = None if full else torch.div(seq_lens.lengths, g, rounding_mode="floor").to(torch.int32)
+            return bilstm(self.context_lstm, x.contiguous(), lens32).contiguous()
         self.context_lstm.flatten_parameters()
         if int(ul.min()) == Tg:                       # fixed-length batch: packing is the identity
             y = self._bilstm_two_streams(x) if self.lstm_two_streams else self.context_lstm(x)[0]
