@@ -36,19 +36,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int UPW = 8;          // hidden units per workgroup (x 4 gates = 32 gate rows = one MFMA tile)
 constexpr int MAXKB = 12;       // k blocks (16 wide) per wave in the forward GEMM: H <= 4*12*16 = 768
+constexpr int MAXNS = 128;      // slices whose partials one thread sums: H <= 8 * 128 (the other limits bind first)
+constexpr int MAXT = 6;         // 32-column output tiles per wave in the backward GEMM: H <= 4*6*32 = 768
 
 struct LstmArgs {
   // forward
   float* G;                     // [B*T][8H]: in  x W_ih^T + b  /  out gate activations (i, f, g, o per direction)
-  const _Float16 *Wh, *Wl;      // [2][4H][ldk] split W_hh (zero padded k >= H)
-  _Float16 *hs_h, *hs_l;        // [2 dirs][2 ping-pong][Bp][ldk] split h operand
+  const _Float16 *Wh, *Wl;      // [2][NS][ldk/16][64][8] split W_hh slices, fragment-major (zero padded)
+  _Float16 *hs_h, *hs_l;        // [2 dirs][2 ping-pong][Bp/32][ldk/16][64][8] split h operand, fragment-major
   float* y;                     // [B*T][2H]
   float* c;                     // [B*T][2H]
   const int* lens;              // [B] or null
   int B, T, H, ldk, Bp;         // Bp = B rounded up to 32
   // backward
   const float* dy;              // [B*T][2H]
-  const _Float16 *Wth, *Wtl;    // [2][NS][Hp][32] packed transposed slices (k' = gate*8 + unit-in-slice)
+  const _Float16 *Wth, *Wtl;    // [2][NS][Hp/32][2][64][8] transposed slices, fragment-major (k' = gate*8 + unit-in-slice)
   float* P;                     // [2 dirs][2 ping-pong][Bp/32][NS][32][Hp] partial recurrent gradients
   float* dcbuf;                 // [2][Bp][H] carried cell gradient
   int Hp, NS;                   // Hp = H rounded up to 32, NS = ceil(H / 8)
@@ -68,28 +70,43 @@ __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
 }
 
 // ---- weight preparation ---------------------------------------------------------------------------
-// W [2][4H][H] fp32 -> Wh/Wl [2][4H][ldk]
-__global__ void lstm_split_w_kernel(const float* __restrict__ W, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
-                                    int rows, int H, int ldk) {
+// Operands are stored FRAGMENT-MAJOR: the 64 lanes of a wave read 64 consecutive 16-byte pieces
+// (one fully coalesced 1 KiB request) instead of 32 rows x 32 bytes scattered at the row pitch.
+//   fragment (kb, lane): row = lane & 31, k = 16 kb + 8 (lane >> 5) .. + 7
+// W [2][4H][H] fp32 -> Wp [2][NS][nkb][64][8]: slice j, gate row n = g*8 + ju <-> W row g*H + 8j + ju
+__global__ void lstm_pack_w_kernel(const float* __restrict__ W, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
+                                   int H, int NS, int nkb) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)rows * ldk) return;
-  const int r = (int)(idx / ldk), k = (int)(idx - (long long)r * ldk);
+  const long long total = 2LL * NS * nkb * 512;
+  if (idx >= total) return;
+  const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  long long rest = idx >> 9;
+  const int kb = (int)(rest % nkb); rest /= nkb;
+  const int j = (int)(rest % NS);
+  const int d = (int)(rest / NS);
+  const int n = lane & 31, k = 16 * kb + 8 * (lane >> 5) + e;
+  const int g = n >> 3, unit = 8 * j + (n & 7);
+  float v = 0.f;
+  if (unit < H && k < H) v = W[((long long)d * 4 * H + (long long)g * H + unit) * H + k];
   _Float16 h, l;
-  split_h(k < H ? W[(long long)r * H + k] : 0.f, h, l);
+  split_h(v, h, l);
   Wh[idx] = h;
   Wl[idx] = l;
 }
-// W [2][4H][H] -> Wt [2][NS][Hp][32]: Wt[d][j][u][g*8 + ju] = W[d][g*H + 8j + ju][u]
+// W [2][4H][H] -> Wt [2][NS][ntile][2 kb][64][8]: output unit u' = 32 tile + (lane & 31),
+// k' = 16 kb + 8 (lane >> 5) + e = g*8 + ju <-> W row g*H + 8j + ju, column u'
 __global__ void lstm_pack_wt_kernel(const float* __restrict__ W, _Float16* __restrict__ Wth, _Float16* __restrict__ Wtl,
                                     int H, int Hp, int NS) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = 2LL * NS * Hp * 32;
   if (idx >= total) return;
-  const int kq = (int)(idx & 31);
-  long long rest = idx >> 5;
-  const int u = (int)(rest % Hp); rest /= Hp;
+  const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), kb = (int)((idx >> 9) & 1);
+  long long rest = idx >> 10;
+  const int ntile = Hp >> 5;
+  const int tile = (int)(rest % ntile); rest /= ntile;
   const int j = (int)(rest % NS);
   const int d = (int)(rest / NS);
+  const int u = 32 * tile + (lane & 31), kq = 16 * kb + 8 * (lane >> 5) + e;
   const int g = kq >> 3, unit = 8 * j + (kq & 7);
   float v = 0.f;
   if (unit < H && u < H) v = W[((long long)d * 4 * H + (long long)g * H + unit) * H + u];
@@ -106,35 +123,44 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a, co
   const int j = blockIdx.x, d = blockIdx.y, bb = blockIdx.z * 32;
   const int t = d == 0 ? s : a.T - 1 - s;
   const int H = a.H, ldk = a.ldk;
-  const _Float16* hs_h = a.hs_h + ((long long)(d * 2 + (s & 1)) * a.Bp + bb) * ldk;
-  const _Float16* hs_l = a.hs_l + ((long long)(d * 2 + (s & 1)) * a.Bp + bb) * ldk;
-  const _Float16* Wh = a.Wh + (long long)d * 4 * H * ldk;
-  const _Float16* Wl = a.Wl + (long long)d * 4 * H * ldk;
-
-  // operand fragments straight from global memory (L2 resident): lane -> row (lane & 31), 8 k at 8 (lane >> 5)
-  const int fr = lane & 31, fk = (lane >> 5) * 8;
-  const int n_g = fr >> 3, n_unit = UPW * j + (fr & 7);
-  const bool n_ok = n_unit < H;
-  const long long a_off = (long long)fr * ldk + fk;                       // rows >= B are zero in the operand buffer
-  const long long b_off = ((long long)n_g * H + n_unit) * ldk + fk;
-  const int nkb = ldk >> 4;
+  const int nkb = ldk >> 4, kpw = (nkb + 3) >> 2;
+  // Every launch starts with cold caches (L2 is not coherent across XCDs and is invalidated at kernel
+  // boundaries), so a step costs about one memory round trip per DEPENDENT load.  All loads of the
+  // gate stage are therefore issued here, before the GEMM operands, with clamped (always valid)
+  // addresses; the masks are applied to the values afterwards.
+  const int pbl = tid >> 3, pju = tid & 7;
+  const int pb = bb + pbl, pu = UPW * j + pju;
+  const int pbc = pb < a.B ? pb : a.B - 1, puc = pu < H ? pu : H - 1;
+  const long long prow = (long long)pbc * a.T + t;
+  float* Gp = a.G + prow * 8 * H + (long long)d * 4 * H + puc;
+  const float gx0 = Gp[0], gx1 = Gp[H], gx2 = Gp[2 * H], gx3 = Gp[3 * H];
+  const int tp = d == 0 ? t - 1 : t + 1;                       // time index of the previous step
+  const int tpc = tp < 0 ? 0 : (tp >= a.T ? a.T - 1 : tp);
+  const float c_prev_ld = a.c[((long long)pbc * a.T + tpc) * 2 * H + (long long)d * H + puc];
+  const int len = a.lens ? a.lens[pbc] : a.T;
+  // h operand [dir][ping-pong][batch block][kb][64][8], W slice [dir][slice][kb][64][8]
+  const _Float16* hs_h = a.hs_h + (((long long)(d * 2 + (s & 1)) * (a.Bp >> 5) + blockIdx.z) * nkb) * 512 + lane * 8;
+  const _Float16* hs_l = a.hs_l + (((long long)(d * 2 + (s & 1)) * (a.Bp >> 5) + blockIdx.z) * nkb) * 512 + lane * 8;
+  const _Float16* Wh = a.Wh + (((long long)d * a.NS + j) * nkb) * 512 + lane * 8;
+  const _Float16* Wl = a.Wl + (((long long)d * a.NS + j) * nkb) * 512 + lane * 8;
+  // each wave takes a contiguous range of k blocks; every load is one coalesced 1 KiB request
   f16x8 ah[MAXKB], al[MAXKB], bh[MAXKB], bl[MAXKB];
   const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < MAXKB; ++i) {
-    const int kb = wave + 4 * i;
-    const bool ok = kb < nkb;
-    ah[i] = ok ? *reinterpret_cast<const f16x8*>(hs_h + a_off + kb * 16) : z8;
-    al[i] = ok ? *reinterpret_cast<const f16x8*>(hs_l + a_off + kb * 16) : z8;
-    bh[i] = (ok && n_ok) ? *reinterpret_cast<const f16x8*>(Wh + b_off + kb * 16) : z8;
-    bl[i] = (ok && n_ok) ? *reinterpret_cast<const f16x8*>(Wl + b_off + kb * 16) : z8;
+    const int kb = wave * kpw + i;
+    const bool ok = i < kpw && kb < nkb;
+    ah[i] = ok ? *reinterpret_cast<const f16x8*>(hs_h + kb * 512) : z8;
+    al[i] = ok ? *reinterpret_cast<const f16x8*>(hs_l + kb * 512) : z8;
+    bh[i] = ok ? *reinterpret_cast<const f16x8*>(Wh + kb * 512) : z8;
+    bl[i] = ok ? *reinterpret_cast<const f16x8*>(Wl + kb * 512) : z8;
   }
   f32x16 acc0, acc1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 #pragma unroll
   for (int i = 0; i < MAXKB; ++i) {
-    if (wave + 4 * i < nkb) {                                  // wave-uniform
+    if (i < kpw && wave * kpw + i < nkb) {                     // wave-uniform
       f32x16& acc = (i & 1) ? acc1 : acc0;
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[i], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[i], acc, 0, 0, 0);
@@ -146,35 +172,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a, co
   __syncthreads();
 
   // gates and state update: thread -> (batch row, unit of the slice)
-  const int bl_ = tid >> 3, ju = tid & 7;
-  const int b = bb + bl_, u = UPW * j + ju;
+  const int bl_ = pbl, ju = pju, b = pb, u = pu;
   if (u >= H) return;
-  _Float16* ho_h = a.hs_h + ((long long)(d * 2 + ((s + 1) & 1)) * a.Bp + bb + bl_) * ldk + u;
-  _Float16* ho_l = a.hs_l + ((long long)(d * 2 + ((s + 1) & 1)) * a.Bp + bb + bl_) * ldk + u;
+  // element (row bl_, k = u) of the next step's operand: fragment (u >> 4, lane = ((u >> 3) & 1) * 32 + bl_), e = u & 7
+  const long long ho = ((((long long)(d * 2 + ((s + 1) & 1)) * (a.Bp >> 5) + blockIdx.z) * nkb + (u >> 4)) * 64 +
+                        ((u >> 3) & 1) * 32 + bl_) * 8 + (u & 7);
+  _Float16* ho_h = a.hs_h + ho;
+  _Float16* ho_l = a.hs_l + ho;
   if (b >= a.B) return;                                        // operand rows >= B stay zero (memset once)
-  const long long row = (long long)b * a.T + t;
   float pre[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     pre[g] = red[0][bl_][g * 8 + ju] + red[1][bl_][g * 8 + ju] + red[2][bl_][g * 8 + ju] + red[3][bl_][g * 8 + ju];
-  float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
-  const int len = a.lens ? a.lens[b] : a.T;
   const bool valid = t < len;
-  const int tp = d == 0 ? t - 1 : t + 1;                       // time index of the previous step
-  float c_prev = 0.f;
-  if (tp >= 0 && tp < a.T) c_prev = a.c[((long long)b * a.T + tp) * 2 * H + (long long)d * H + u];
+  const float c_prev = (tp >= 0 && tp < a.T) ? c_prev_ld : 0.f;
   float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, hn = 0.f;
   if (valid) {
-    ig = sigmoid_f(pre[0] + Gp[0]);
-    fg = sigmoid_f(pre[1] + Gp[H]);
-    gg = tanh_f(pre[2] + Gp[2 * H]);
-    og = sigmoid_f(pre[3] + Gp[3 * H]);
+    ig = sigmoid_f(pre[0] + gx0);
+    fg = sigmoid_f(pre[1] + gx1);
+    gg = tanh_f(pre[2] + gx2);
+    og = sigmoid_f(pre[3] + gx3);
     cn = fg * c_prev + ig * gg;
     hn = og * tanh_f(cn);
   }
   Gp[0] = ig; Gp[H] = fg; Gp[2 * H] = gg; Gp[3 * H] = og;
-  a.c[row * 2 * H + (long long)d * H + u] = cn;
-  a.y[row * 2 * H + (long long)d * H + u] = hn;
+  a.c[prow * 2 * H + (long long)d * H + u] = cn;
+  a.y[prow * 2 * H + (long long)d * H + u] = hn;
   _Float16 hh, hl;
   split_h(hn, hh, hl);
   *ho_h = hh;
@@ -191,33 +214,57 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
   const int bl_ = tid >> 3, ju = tid & 7;
   const int b = bb + bl_, u = UPW * j + ju;
 
+  // this wave's W_hh^T fragments (tiles wave, wave + 4, ...) do not depend on anything computed
+  // here: fetch them first so their latency hides behind the partial sums and the gate arithmetic
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  const _Float16* Wth = a.Wth + ((long long)d * NS + j) * Hp * 32 + lane * 8;
+  const _Float16* Wtl = a.Wtl + ((long long)d * NS + j) * Hp * 32 + lane * 8;
+  const int ntile = Hp >> 5;
+  f16x8 wbh[MAXT][2], wbl[MAXT][2];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int tile = wave + 4 * i;
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const long long off = ((long long)tile * 2 + kb) * 512;
+      wbh[i][kb] = tile < ntile ? *reinterpret_cast<const f16x8*>(Wth + off) : z8;
+      wbl[i][kb] = tile < ntile ? *reinterpret_cast<const f16x8*>(Wtl + off) : z8;
+    }
+  }
+  // all loads of the gate stage, unconditionally and with clamped addresses (cold caches at every
+  // launch: one round trip per dependent load, see the forward kernel); masks are applied afterwards
   const float gsc = a.gscale[0];
+  const int bc = b < a.B ? b : a.B - 1, uc = u < H ? u : H - 1;
+  const long long row = (long long)bc * a.T + t;
+  float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + uc;
+  const float ig = Gp[0], fg = Gp[H], gg = Gp[2 * H], og = Gp[3 * H];
+  const float cn = a.c[row * 2 * H + (long long)d * H + uc];
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const int tpc = tp < 0 ? 0 : (tp >= a.T ? a.T - 1 : tp);
+  const float c_prev_ld = a.c[((long long)bc * a.T + tpc) * 2 * H + (long long)d * H + uc];
+  const float dy_ld = a.dy[row * 2 * H + (long long)d * H + uc];
+  const float dc_ld = a.dcbuf[((long long)d * a.Bp + bc) * H + uc];
+  const int len = a.lens ? a.lens[bc] : a.T;
+  float pv[MAXNS];
+  {
+    const float* Pp = a.P + ((((long long)(d * 2 + ((s + 1) & 1)) * nbz + bz) * NS) * 32 + bl_) * Hp + uc;
+    const long long st = 32LL * Hp;
+#pragma unroll
+    for (int jj = 0; jj < MAXNS; ++jj) pv[jj] = jj < NS ? Pp[jj * st] : 0.f;
+  }
+#pragma unroll
+  for (int w = MAXNS / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int jj = 0; jj < w; ++jj) pv[jj] += pv[jj + w];
+
   float dG[4] = {0.f, 0.f, 0.f, 0.f};
   if (b < a.B && u < H) {
-    const long long row = (long long)b * a.T + t;
-    const int len = a.lens ? a.lens[b] : a.T;
     float dc_prev = 0.f;
     if (t < len) {
-      float dh = a.dy[row * 2 * H + (long long)d * H + u];
-      float dc = 0.f;
-      if (s > 0) {
-        const float* Pp = a.P + ((((long long)(d * 2 + ((s - 1) & 1)) * nbz + bz) * NS) * 32 + bl_) * Hp + u;
-        float s0 = 0.f, s1 = 0.f;
-        int jj = 0;
-        for (; jj + 1 < NS; jj += 2) {
-          s0 += Pp[(long long)jj * 32 * Hp];
-          s1 += Pp[(long long)(jj + 1) * 32 * Hp];
-        }
-        if (jj < NS) s0 += Pp[(long long)jj * 32 * Hp];
-        dh += s0 + s1;
-        dc = a.dcbuf[((long long)d * a.Bp + b) * H + u];
-      }
-      float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
-      const float ig = Gp[0], fg = Gp[H], gg = Gp[2 * H], og = Gp[3 * H];
-      const float cn = a.c[row * 2 * H + (long long)d * H + u];
-      const int tp = d == 0 ? t - 1 : t + 1;
-      float c_prev = 0.f;
-      if (tp >= 0 && tp < a.T) c_prev = a.c[((long long)b * a.T + tp) * 2 * H + (long long)d * H + u];
+      const float dh = dy_ld + (s > 0 ? pv[0] : 0.f);          // step 0: the partial buffer is uninitialised
+      float dc = s > 0 ? dc_ld : 0.f;
+      const float c_prev = (tp >= 0 && tp < a.T) ? c_prev_ld : 0.f;
       const float tc = tanh_f(cn);
       dc += dh * og * (1.f - tc * tc);
       dG[0] = dc * gg * ig * (1.f - ig);
@@ -225,11 +272,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
       dG[2] = dc * ig * (1.f - gg * gg);
       dG[3] = dh * tc * og * (1.f - og);
       dc_prev = dc * fg;
-      Gp[0] = dG[0]; Gp[H] = dG[1]; Gp[2 * H] = dG[2]; Gp[3 * H] = dG[3];
-    } else {
-      float* Gp = a.G + row * 8 * H + (long long)d * 4 * H + u;
-      Gp[0] = 0.f; Gp[H] = 0.f; Gp[2 * H] = 0.f; Gp[3 * H] = 0.f;
     }
+    Gp[0] = dG[0]; Gp[H] = dG[1]; Gp[2 * H] = dG[2]; Gp[3 * H] = dG[3];
     a.dcbuf[((long long)d * a.Bp + b) * H + u] = dc_prev;
   }
 #pragma unroll
@@ -242,35 +286,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
   __syncthreads();
 
   // P[j][b][u'] = (1/gscale) * sum_k' A[b][k'] * Wt[d][j][u'][k']
-  const int fr = lane & 31, fk = (lane >> 5) * 8;
   f16x8 ah[2], al[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     ah[kb] = *reinterpret_cast<const f16x8*>(&sAh[fr][kb * 16 + fk]);
     al[kb] = *reinterpret_cast<const f16x8*>(&sAl[fr][kb * 16 + fk]);
   }
-  const _Float16* Wth = a.Wth + ((long long)d * NS + j) * Hp * 32;
-  const _Float16* Wtl = a.Wtl + ((long long)d * NS + j) * Hp * 32;
   float* Po = a.P + (((long long)(d * 2 + (s & 1)) * nbz + bz) * NS + j) * 32 * Hp;
   const float inv = 1.f / gsc;
-  const int ntile = Hp >> 5;
-  for (int tile = wave; tile < ntile; tile += 4) {
-    const _Float16* wr_h = Wth + ((long long)tile * 32 + fr) * 32 + fk;
-    const _Float16* wr_l = Wtl + ((long long)tile * 32 + fr) * 32 + fk;
-    f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int i = 0; i < MAXT; ++i) {
+    const int tile = wave + 4 * i;
+    if (tile < ntile) {                                        // wave-uniform
+      f32x16 acc;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const f16x8 bh = *reinterpret_cast<const f16x8*>(wr_h + kb * 16);
-      const f16x8 bl = *reinterpret_cast<const f16x8*>(wr_l + kb * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb], bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bh, acc, 0, 0, 0);
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb], wbh[i][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], wbl[i][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], wbh[i][kb], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Po[(long long)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * Hp + tile * 32 + (lane & 31)] = acc[e] * inv;
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      Po[(long long)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * Hp + tile * 32 + (lane & 31)] = acc[e] * inv;
   }
 }
 
@@ -281,7 +321,7 @@ extern "C" int64_t radmmm_lstm_scratch_bytes(int B, int H, int which) {
   // 3: partial recurrent gradients P, 4: carried cell gradient
   const int64_t ldk = (H + 15) / 16 * 16, Bp = (B + 31) / 32 * 32, Hp = (H + 31) / 32 * 32, NS = (H + UPW - 1) / UPW;
   switch (which) {
-    case 0: return 2 * (2 * 4 * (int64_t)H * ldk * 2);
+    case 0: return 2 * (2 * NS * (ldk / 16) * 512 * 2);
     case 1: return 2 * (2 * 2 * Bp * ldk * 2);
     case 2: return 2 * (2 * NS * Hp * 32 * 2);
     case 3: return 2 * 2 * (Bp / 32) * NS * 32 * Hp * 4;
@@ -301,14 +341,14 @@ extern "C" int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, 
   LstmArgs a = {};
   a.G = G; a.y = y; a.c = c; a.lens = lens; a.B = B; a.T = T; a.H = H;
   a.ldk = (H + 15) / 16 * 16; a.Bp = (B + 31) / 32 * 32; a.Hp = (H + 31) / 32 * 32; a.NS = (H + UPW - 1) / UPW;
-  const long long wn = 2LL * 4 * H * a.ldk;
+  const long long wn = 2LL * a.NS * (a.ldk / 16) * 512;
   _Float16* Wh = static_cast<_Float16*>(wsplit);
   _Float16* Wl = Wh + wn;
   a.Wh = Wh; a.Wl = Wl;
   const long long hn = 2LL * 2 * a.Bp * a.ldk;
   a.hs_h = static_cast<_Float16*>(hsplit);
   a.hs_l = a.hs_h + hn;
-  hipLaunchKernelGGL(lstm_split_w_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, st, W_hh, Wh, Wl, 2 * 4 * H, H, a.ldk);
+  hipLaunchKernelGGL(lstm_pack_w_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, st, W_hh, Wh, Wl, H, a.NS, a.ldk / 16);
   if (hipMemsetAsync(hsplit, 0, (size_t)(2 * hn * 2), st) != hipSuccess) {
     radmmm::set_error("lstm_fwd: hipMemsetAsync failed");
     return -2;
@@ -326,7 +366,7 @@ extern "C" int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const 
                                void* wtpack, float* P, float* dcbuf, int B, int T, int H, const float* gscale,
                                radmmm_stream_t stream) {
   RADMMM_REQUIRE(G && c && dy && W_hh && wtpack && P && dcbuf && gscale, "lstm_bwd: null pointer");
-  RADMMM_REQUIRE(B > 0 && T > 0 && H > 0, "lstm_bwd: bad dims");
+  RADMMM_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 4 * MAXT * 32, "lstm_bwd: bad dims (H <= %d)", 4 * MAXT * 32);
   hipStream_t st = static_cast<hipStream_t>(stream);
   LstmArgs a = {};
   a.G = G; a.c = const_cast<float*>(c); a.dy = dy; a.lens = lens; a.B = B; a.T = T; a.H = H;
