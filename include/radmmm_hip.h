@@ -323,6 +323,14 @@ int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, co
 int radmmm_transpose_split_act(const float* x, int ld, int C, int B, int T, int Tp, int front,
                                const int32_t* lens, int mask_mode, float scale, void* oh, void* ol,
                                void* o1h, void* o1l, int ldk, radmmm_stream_t stream);
+/* radmmm_transpose_split_act + the weighted column sums of x (bias gradient) from the same pass:
+ * part [B * ceil(Tp / 64)][C] partial rows, to be added by radmmm_colsum_final(part, out, nparts, C).
+ * sum_weight / sum_taps / sum_dil as radmmm_colsum's row_weight / taps / dil. */
+int radmmm_transpose_split_act_colsum(const float* x, int ld, int C, int B, int T, int Tp, int front,
+                                      const int32_t* lens, int mask_mode, float scale, void* oh, void* ol, void* o1h,
+                                      void* o1l, int ldk, float* part, int sum_weight, int sum_taps, int sum_dil,
+                                      radmmm_stream_t stream);
+int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, radmmm_stream_t stream);
 /* number of workgroup tiles radmmm_wgrad_h3 launches per split (the caller picks `splits` so that
  * tiles * splits fills whole rounds of the CUs: one workgroup per CU) */
 int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);

@@ -103,6 +103,8 @@ def _load() -> C.CDLL:
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
+        "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
+        "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, p],

@@ -109,4 +109,20 @@ __device__ __forceinline__ float block_sum(float v, float* sh /* >= 17 floats */
   return sh[16];
 }
 
+// weight of row r in a (bias-gradient) column sum: 0 none, 1 length mask, 2 mask x partial-conv ratio
+__device__ __forceinline__ float colsum_row_weight(int r, int row_weight, int T, const int* lens, int taps,
+                                                   int dil) {
+  if (!row_weight) return 1.f;
+  const int b = r / T, t = r - b * T;
+  const int len = lens ? lens[b] : T;
+  if (t >= len) return 0.f;
+  if (row_weight != 2) return 1.f;
+  int cnt = 0;
+  for (int k = 0; k < taps; ++k) {
+    const int ts = t + (k - taps / 2) * dil;
+    cnt += (ts >= 0 && ts < len) ? 1 : 0;
+  }
+  return ((float)cnt + 1e-6f) / (float)taps;
+}
+
 }  // namespace radmmm

@@ -231,20 +231,6 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
 // owns 4 adjacent columns (float4 loads: a block reads 4 KiB contiguous per row).  Stage 2 adds
 // the per-chunk partials.  Deterministic (no atomics).
 constexpr int CS_ROWS_PER_BLOCK = 64;
-__device__ __forceinline__ float colsum_row_weight(int r, int row_weight, int T, const int* lens, int taps,
-                                                   int dil) {
-  if (!row_weight) return 1.f;
-  const int b = r / T, t = r - b * T;
-  const int len = lens ? lens[b] : T;
-  if (t >= len) return 0.f;
-  if (row_weight != 2) return 1.f;
-  int cnt = 0;
-  for (int k = 0; k < taps; ++k) {
-    const int ts = t + (k - taps / 2) * dil;
-    cnt += (ts >= 0 && ts < len) ? 1 : 0;
-  }
-  return ((float)cnt + 1e-6f) / (float)taps;
-}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
     const float* __restrict__ X, int ldx, float* __restrict__ part, int rows, int cols,
     int row_weight, int T, const int* __restrict__ lens, int taps, int dil, int square) {
@@ -256,7 +242,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < cols) {
     for (int r = r0; r < r1; ++r) {
-      const float w = colsum_row_weight(r, row_weight, T, lens, taps, dil);   // block-uniform
+      const float w = radmmm::colsum_row_weight(r, row_weight, T, lens, taps, dil);   // block-uniform
       float4 v;
       if (vec) {
         v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
@@ -277,19 +263,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
     if (c + 3 < cols) o[3] = a3;
   }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part,
-                                                           float* __restrict__ out, int nparts,
-                                                           int cols) {
-  // one wave per 64 columns x a slice of the partials, then a 4-way LDS combine
-  __shared__ float sh[4][64];
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part,
+                                                            float* __restrict__ out, int nparts,
+                                                            int cols) {
+  // 16 waves per 64 columns, each a slice of the partials, then a fixed-order LDS combine
+  __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < cols)
-    for (int p = pl; p < nparts; p += 4) s += part[(long long)p * cols + c];
-  sh[pl][cl] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int q = pl;
+    for (; q + 16 < nparts; q += 32) {
+      s0 += part[(long long)q * cols + c];
+      s1 += part[(long long)(q + 16) * cols + c];
+    }
+    if (q < nparts) s0 += part[(long long)q * cols + c];
+  }
+  sh[pl][cl] = s0 + s1;
   __syncthreads();
-  if (pl == 0 && c < cols) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  if (pl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w][cl];
+    out[c] = t;
+  }
 }
 
 // ------------------------------------------------------------------ masked reductions
@@ -481,9 +478,17 @@ extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch
   const int nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 1023) / 1024, nparts), dim3(256), 0, ST(stream),
                      X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil, square);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, ST(stream), scratch,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, ST(stream), scratch,
                      out, nparts, cols);
   return radmmm::check_launch("colsum");
+}
+
+// out[c] = sum_p part[p][c] (fixed order): second stage for partials produced by another kernel
+// (radmmm_transpose_split_act_colsum)
+extern "C" int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(part && out && nparts > 0 && cols > 0, "colsum_final: bad arguments");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, ST(stream), part, out, nparts, cols);
+  return radmmm::check_launch("colsum_final");
 }
 
 extern "C" int64_t radmmm_masked_reduce_scratch_floats(int, int, int) { return MR_BLOCKS; }

@@ -273,17 +273,30 @@ int wgrad_mb(int Mc) {
 __global__ __launch_bounds__(256) void transpose_split_act_kernel(
     const float* __restrict__ x, int ld, int C, int T, int Tp, int front, const int* __restrict__ lens, int mask_mode,
     float scale, _Float16* __restrict__ oh, _Float16* __restrict__ ol, _Float16* __restrict__ o1h,
-    _Float16* __restrict__ o1l, int ldk) {
+    _Float16* __restrict__ o1l, int ldk, float* __restrict__ part, int sum_weight, int sum_taps, int sum_dil) {
   __shared__ float tile[64][33];
+  __shared__ float red[8][33];
   const int b = blockIdx.z;
   const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
   const int len = (mask_mode && lens) ? lens[b] : T;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  float csum = 0.f;
   for (int i = ty; i < 64; i += 8) {
     const int t = t0 + i, c = c0 + tx;
-    tile[i][tx] = (t < len && t < T && c < C) ? x[((long long)b * T + t) * ld + c] * scale : 0.f;   // 0 in gap/masked frames
+    const float raw = (t < T && c < C) ? x[((long long)b * T + t) * ld + c] : 0.f;
+    tile[i][tx] = t < len ? raw * scale : 0.f;             // 0 in gap / masked frames
+    if (part && t < T) csum = fmaf(radmmm::colsum_row_weight(b * T + t, sum_weight, T, lens, sum_taps, sum_dil), raw, csum);
   }
+  if (part) red[ty][tx] = csum;
   __syncthreads();
+  // bias-gradient by-product: this block's column sums (all T frames, own row weights) as one row of
+  // partials; radmmm_colsum_final adds the rows in a fixed order
+  if (part && ty == 0 && c0 + tx < C) {
+    float t8 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t8 += red[w][tx];
+    part[((long long)b * gridDim.y + blockIdx.y) * C + c0 + tx] = t8;
+  }
   // lanes run along time: for one channel, 64 consecutive frames = 128 contiguous bytes per array.
   // Frames t in [T, Tp) are the zero gap after the utterance and are (re)written here as zeros.
   const int fl = threadIdx.x & 63, cl0 = threadIdx.x >> 6;   // 64 x 4
@@ -309,9 +322,9 @@ __global__ __launch_bounds__(256) void transpose_split_act_kernel(
 
 }  // namespace
 
-extern "C" int radmmm_transpose_split_act(const float* x, int ld, int C, int B, int T, int Tp, int front,
-                                          const int32_t* lens, int mask_mode, float scale, void* oh, void* ol, void* o1h,
-                                          void* o1l, int ldk, radmmm_stream_t stream) {
+static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp, int front, const int32_t* lens,
+                            int mask_mode, float scale, void* oh, void* ol, void* o1h, void* o1l, int ldk, float* part,
+                            int sum_weight, int sum_taps, int sum_dil, radmmm_stream_t stream) {
   RADMMM_REQUIRE(x && oh && ol, "transpose_split_act: null pointer");
   RADMMM_REQUIRE(C > 0 && B > 0 && T > 0 && Tp >= T && front >= 1 && ldk % 8 == 0 && ldk >= front + B * Tp,
                  "transpose_split_act: bad dims");
@@ -320,8 +333,29 @@ extern "C" int radmmm_transpose_split_act(const float* x, int ld, int C, int B, 
   hipLaunchKernelGGL(transpose_split_act_kernel, dim3((C + 31) / 32, ty, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ld, C, T, Tp, front, lens, mask_mode, scale,
                      static_cast<_Float16*>(oh), static_cast<_Float16*>(ol), static_cast<_Float16*>(o1h),
-                     static_cast<_Float16*>(o1l), ldk);
+                     static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil);
   return radmmm::check_launch("transpose_split_act");
+}
+
+extern "C" int radmmm_transpose_split_act(const float* x, int ld, int C, int B, int T, int Tp, int front,
+                                          const int32_t* lens, int mask_mode, float scale, void* oh, void* ol, void* o1h,
+                                          void* o1l, int ldk, radmmm_stream_t stream) {
+  return launch_transpose(x, ld, C, B, T, Tp, front, lens, mask_mode, scale, oh, ol, o1h, o1l, ldk, nullptr, 0, 1, 1, stream);
+}
+
+// Same, plus the weighted column sums of x (bias gradient) as a by-product of the one pass over x:
+// part [B * ceil(Tp / 64)][C] partial rows (radmmm_colsum_final adds them).  sum_weight / taps / dil
+// as radmmm_colsum's row_weight (0 plain, 1 length mask, 2 mask x partial-conv ratio), independent
+// of mask_mode (which governs the transposed copy).
+extern "C" int radmmm_transpose_split_act_colsum(const float* x, int ld, int C, int B, int T, int Tp, int front,
+                                                 const int32_t* lens, int mask_mode, float scale, void* oh, void* ol,
+                                                 void* o1h, void* o1l, int ldk, float* part, int sum_weight, int sum_taps,
+                                                 int sum_dil, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(part, "transpose_split_act_colsum: null partial buffer");
+  RADMMM_REQUIRE(sum_weight == 0 || sum_weight == 1 || (sum_weight == 2 && sum_taps >= 1 && sum_dil >= 1),
+                 "transpose_split_act_colsum: bad row weight");
+  return launch_transpose(x, ld, C, B, T, Tp, front, lens, mask_mode, scale, oh, ol, o1h, o1l, ldk, part, sum_weight,
+                          sum_taps, sum_dil, stream);
 }
 
 extern "C" int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps) {

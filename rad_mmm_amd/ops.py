@@ -474,10 +474,12 @@ _TS_FRONT = 16           # leading zero columns / zero gap between utterances (>
 _ts_pool = {}
 
 
-def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False):
+def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None):
     """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
     Buffers come from a small zero-initialised pool keyed by shape and role: the pads are never
-    written, the data and the gaps are rewritten on every call (single stream => reuse is ordered)."""
+    written, the data and the gaps are rewritten on every call (single stream => reuse is ordered).
+    colsum = (row_weight, lens, taps, dil): also return the weighted column sums of x (the bias
+    gradient) computed in the same pass -> (copy tuple, sums [C])."""
     Tp = T + _TS_FRONT
     Kt = round_up(B * Tp, 32)                 # contracted columns [FRONT, FRONT + Kt)
     ldk = Kt + 2 * _TS_FRONT
@@ -489,9 +491,20 @@ def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False
         _ts_pool[key] = bufs
     oh, ol = bufs[0], bufs[1]
     o1h, o1l = (bufs[2], bufs[3]) if need_odd else (None, None)
-    check(lib.radmmm_transpose_split_act(ptr(x), x.shape[1], C, B, T, Tp, _TS_FRONT, ptr(lens), mask_mode, scale, ptr(oh),
-                                         ptr(ol), ptr(o1h), ptr(o1l), ldk, stream()), "transpose_split_act")
-    return oh, ol, o1h, o1l, Kt
+    if colsum is None:
+        check(lib.radmmm_transpose_split_act(ptr(x), x.shape[1], C, B, T, Tp, _TS_FRONT, ptr(lens), mask_mode, scale, ptr(oh),
+                                             ptr(ol), ptr(o1h), ptr(o1l), ldk, stream()), "transpose_split_act")
+        return oh, ol, o1h, o1l, Kt
+    weight, wlens, taps, dil = colsum
+    nparts = B * (-(-Tp // 64))
+    part = _empty(nparts, C, like=x)
+    sums = _empty(C, like=x)
+    assert mask_mode == 0 or wlens is lens or wlens is None
+    check(lib.radmmm_transpose_split_act_colsum(ptr(x), x.shape[1], C, B, T, Tp, _TS_FRONT, ptr(lens if mask_mode else wlens),
+                                                mask_mode, scale, ptr(oh), ptr(ol), ptr(o1h), ptr(o1l), ldk, ptr(part),
+                                                weight, taps, dil, stream()), "transpose_split_act_colsum")
+    check(lib.radmmm_colsum_final(ptr(part), ptr(sums), nparts, C, stream()), "colsum_final")
+    return (oh, ol, o1h, o1l, Kt), sums
 
 
 def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale):
@@ -640,8 +653,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
                                       ptr(gQl), Wc, SG, stream()), "dact_mul")
-            g_res[3 * j + 2] = colsum(gQ, Wc)
-            gy_t = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy")
+            gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
             x_t = transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
@@ -651,12 +663,13 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, acc_scale=inv_acc, C=g_conv, ldc=Wc, M=N,
                        N=Wc, K=Wc, T=T, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
                        rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
-            g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
             if (kt // 2) * d <= _TS_FRONT:
-                gy_t = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy")
+                gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
+                                                            colsum=(2 if partial else 0, lens, kt, d))
                 x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG)
             else:
+                g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
             g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
             WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc)            # [taps][ci][co]
@@ -667,9 +680,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        acc_scale=inv_acc, C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens,
                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
                        ldch=Wc, ch_scale=SG)
-        g_start_b = colsum(G, Wc)
         perm = (h, D, 0)
-        gy_t = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy")
+        gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
         x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
         slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
