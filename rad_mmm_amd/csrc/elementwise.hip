@@ -61,6 +61,39 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(
     dv[(long long)co * n + i] = a * gw_at(i) - b * vr[i];
 }
 
+// Same result with one coalesced pass over the gradient slabs: the summed gradient row of this
+// output channel is staged in LDS in checkpoint order ([ci][tap]), reading dW plane by plane with ci
+// fastest (the kernel above walks [ci][tap] directly and touches `taps` planes per 64-byte sector,
+// twice).  Needs Cin * taps * 4 bytes of LDS.
+__global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
+    const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
+    float* __restrict__ dg, int Cout, int Cin, int taps, int ldw, int perm_split, int off_lo,
+    int off_hi) {
+  extern __shared__ float gw[];          // [Cin * taps]
+  __shared__ float sh[17];
+  const int co = blockIdx.x;
+  const int n = Cin * taps;
+  const float* vr = v + (long long)co * n;
+  for (int k = 0; k < taps; ++k) {
+    const float* plane = dW + ((long long)k * Cout + co) * ldw;
+    for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+      const int col = perm_col(ci, perm_split, off_lo, off_hi);
+      float s0 = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s0 += plane[sp * split_stride + col];
+      gw[ci * taps + k] = s0;
+    }
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dot = fmaf(gw[i], vr[i], dot);
+  dot = block_sum(dot, sh);
+  const float inv = inv_norm[co], gg = g[co];
+  if (threadIdx.x == 0) dg[co] = dot * inv;
+  const float a = gg * inv, b = gg * dot * inv * inv * inv;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dv[(long long)co * n + i] = a * gw[i] - b * vr[i];
+}
+
 // ------------------------------------------------------------------ WN input assembly
 __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz,
@@ -400,9 +433,15 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
                                      radmmm_stream_t stream) {
   RADMMM_REQUIRE(v && g && inv_norm && dW && dv && dg, "weightnorm_bwd: null pointer");
   RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldw >= Cin && splits >= 1, "weightnorm_bwd: bad dims");
-  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW,
-                     splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split,
-                     off_lo, off_hi);
+  const size_t lds = (size_t)Cin * taps * sizeof(float);
+  if (lds <= 48 * 1024) {
+    hipLaunchKernelGGL(weightnorm_bwd_lds_kernel, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
+                       splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+  } else {
+    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW,
+                       splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split,
+                       off_lo, off_hi);
+  }
   return radmmm::check_launch("weightnorm_bwd");
 }
 
