@@ -369,7 +369,8 @@ def main():
             # f16 MFMA peak and `achieved` counts the executed MFMA flops
             kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size)
             achieved, peak = 3.0 * kflop / kdur / 1e12, PEAK_F16_MFMA_TFLOPS
-            kname = "rowgemm_h3_kernel (WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA products per fp32 product)" % N
+            kname = ("rowgemm_h3d_kernel<MB> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA products "
+                     "per fp32 product; PMC of this launch: profiles/r01_pmc_h3d.txt)") % N
             prec = "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)"
         else:
             kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)

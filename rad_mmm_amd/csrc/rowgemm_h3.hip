@@ -196,7 +196,12 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
     const char* e = getenv("RADMMM_H3_TILE");
     return e && atoi(e) == 128;
   }();
-  if (!narrow) return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
+  static const bool narrow_1x1 = [] {                 // experiment: short-K launches on the 2-workgroup-per-CU kernel
+    const char* e = getenv("RADMMM_H3_1X1");
+    return e && atoi(e) == 128;
+  }();
+  if (!narrow && !(narrow_1x1 && p.taps == 1))
+    return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
