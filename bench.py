@@ -395,7 +395,12 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "avg_launch_ms": kdur * 1e3,
                          "flop_per_launch": (3.0 if h3 else 1.0) * kflop, "fp32_equiv_tflops": kflop / kdur / 1e12,
-                         "traffic": None},
+                         # memory-side bytes per launch from the separate --pmc passes over this same launch
+                         # (profiles/r01_pmc_h3d.txt): FETCH_SIZE 2.235e5 KiB x2 (gfx950 correction for 16 B/lane
+                         # loads) + WRITE_SIZE 1.024e5 KiB; algorithmic operand + output bytes: 1.78e8
+                         "traffic": (2.235e5 * 2 + 1.024e5) * 1024 if (h3 and N == 12800) else None,
+                         "traffic_source": "profiles/r01_pmc_h3d.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
+                         if (h3 and N == 12800) else None},
             "step_flops": {"algorithmic_tflop_per_step": fl * B * T / 1e12,
                            "achieved_tflops_per_gpu": fl * B * T / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_fp32_mfma_peak": fl * B * T / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
