@@ -267,6 +267,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="radtts",
                     help="radtts = BASELINE configs[1] (headline); radmmm_splines = configs[4] architecture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", action="store_true",
+                    help="also run the fused global-norm clip + RAdam update inside the timed step (NOT the BASELINE metric, "
+                         "which is fwd+bwd only; reported with config.includes_optimizer = true)")
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     args = ap.parse_args()
     if args.kernel_only:
@@ -328,6 +331,10 @@ def main():
     gb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
     sl = SequenceLength(gb["lengths"])
     reducer = BucketedGradReducer(dec)
+    opt = None
+    if args.optimizer:
+        from rad_mmm_amd.optim import FlatRAdam
+        opt = FlatRAdam(dec.named_parameters(), lr=1e-6, weight_decay=1e-6, reducer=reducer)   # tiny lr: loss stays put
 
     def step():
         reducer.prepare()
@@ -336,6 +343,9 @@ def main():
         loss = losses["loss_mel"][0]
         loss.backward()
         reducer.finish()
+        if opt is not None:
+            opt.clip_grad_norm(1.0)
+            opt.step()
         return loss
 
     for _ in range(args.warmup):
@@ -389,7 +399,8 @@ def main():
                                    ("RADMMM 16 kHz-dims flow decoder (configs/RADMMM_16khz_model_config.yaml + "
                                     "n_splines=2: 2 spline/FiLM + 6 affine/WN flows, D=1056) fwd+NLL+bwd"),
                        "batch_per_gpu": B, "n_mel": 80, "frames": T,
-                       "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec,
+                       "includes_optimizer": bool(args.optimizer)},
             "loss_mel": loss_val,
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -353,6 +353,14 @@ int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32
 int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens, void* wtpack,
                     float* P, float* dcbuf, int B, int T, int H, const float* gscale, radmmm_stream_t stream);
 
+/* Optimizer step on flat fp32 buffers (next-row f3): the reference's vendored RAdam (radam.py:63-142)
+ * with the global-norm clip of configs/RADMMM_train_config.yaml:7-8 folded in as a device scalar.
+ * step_size / use_denom (N_sma >= 5) come from the host's step count as radam.py:101-123. */
+int64_t radmmm_sumsq_scratch_floats(void);
+int radmmm_sumsq(const float* x, int64_t n, float* partial, radmmm_stream_t stream);
+int radmmm_radam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* clip_coef, float beta1,
+                      float beta2, float eps, float step_size, float wd_lr, int use_denom, radmmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -635,3 +635,43 @@ def mel_spectrogram(audio: np.ndarray, mel_basis: np.ndarray, n_fft: int, hop: i
     mag = stft_magnitude(audio, n_fft, hop, win)
     mel = np.einsum("mk,bkf->bmf", mel_basis.astype(np.float32), mag, dtype=np.float32)
     return np.log(np.maximum(mel, 1e-5)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# optimizer step: RAdam as vendored by the reference + Lightning's norm clip
+# --------------------------------------------------------------------------
+def clip_grad_norm(grads: Sequence[Tensor], max_norm: float) -> Tuple[Tensor, List[Tensor]]:
+    """torch.nn.utils.clip_grad_norm_ (what Lightning's gradient_clip_val=1.0 / algorithm 'norm'
+    calls, configs/RADMMM_train_config.yaml:7-8): coef = min(1, max_norm / (||g||_2 + 1e-6))."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, [g * coef for g in grads]
+
+
+def radam_scalars(step: int, lr: float, beta1: float, beta2: float) -> Tuple[float, float]:
+    """(N_sma, step_size) of radam.py:101-123 for the 1-based step count."""
+    beta2_t = beta2 ** step
+    n_sma_max = 2.0 / (1.0 - beta2) - 1.0
+    n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t)
+    if n_sma >= 5:
+        step_size = lr * math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma
+                                   * n_sma_max / (n_sma_max - 2)) / (1 - beta1 ** step)
+    else:
+        step_size = lr / (1 - beta1 ** step)
+    return n_sma, step_size
+
+
+def radam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float = 1e-3,
+               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    """One RAdam update of one tensor (radam.py:63-142), in place on p, m, v; `step` is 1-based."""
+    beta1, beta2 = betas
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    n_sma, step_size = radam_scalars(step, lr, beta1, beta2)
+    if weight_decay != 0:
+        p.add_(p, alpha=-weight_decay * lr)
+    if n_sma >= 5:
+        p.addcdiv_(m, v.sqrt().add_(eps), value=-step_size)
+    else:
+        p.add_(m, alpha=-step_size)
+    return p

@@ -103,6 +103,8 @@ def _load() -> C.CDLL:
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
+        "radmmm_sumsq": [p, i64, p, p],
+        "radmmm_radam_step": [p, p, p, p, i64, p, f, f, f, f, f, i, p],
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
         "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
@@ -130,7 +132,8 @@ def _load() -> C.CDLL:
                        "radmmm_mas_scratch_bytes": [i, i, i],
                        "radmmm_film_bwd_scratch_floats": [i, i],
                        "radmmm_stft_mel_scratch_floats": [i, i, i, i, i],
-                       "radmmm_lstm_scratch_bytes": [i, i, i]}.items():
+                       "radmmm_lstm_scratch_bytes": [i, i, i],
+                       "radmmm_sumsq_scratch_floats": []}.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int64

@@ -353,6 +353,30 @@ def main():
                   use_bn=True)
         run_decoder("cfg5_small", mm, 2, 64, True, set())
 
+    # ------------------------------------------------------------------ RAdam + global-norm clip (f3)
+    if want("radam"):
+        import radam as ref_radam
+        g = torch.Generator().manual_seed(77)
+        shapes = [(7, 5), (33,), (4, 3, 5), (1,)]
+        params = [torch.nn.Parameter(torch.randn(*sh, generator=g)) for sh in shapes]
+        p0 = [p.detach().clone() for p in params]
+        opt = ref_radam.RAdam(params, lr=1e-3, weight_decay=1e-6)
+        n_steps = 9                                    # N_sma crosses 5 between steps 5 and 6
+        grads = [[torch.randn(*sh, generator=g) * (3.0 if k % 3 == 0 else 0.05) for sh in shapes] for k in range(n_steps)]
+        arrs = {}
+        for i, t in enumerate(p0):
+            arrs[f"p0.{i}"] = t
+        for k in range(n_steps):
+            for p, gr in zip(params, grads[k]):
+                p.grad = gr.clone()
+            total = torch.nn.utils.clip_grad_norm_(params, 1.0)     # Lightning gradient_clip_val 1.0, algorithm norm
+            opt.step()
+            arrs[f"norm.{k}"] = total
+            for i, (p, gr) in enumerate(zip(params, grads[k])):
+                arrs[f"g.{k}.{i}"] = gr
+                arrs[f"p.{k}.{i}"] = p.detach().clone()
+        save("radam_tiny.npz", **t2n(arrs))
+
 
 if __name__ == "__main__":
     main()

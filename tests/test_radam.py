@@ -1,0 +1,89 @@
+"""Optimizer step.  CPU: the oracle's RAdam + norm-clip restatement against vectors
+captured from the reference's radam.RAdam and torch's clip_grad_norm_ (tests/golden/make_golden.py,
+section "radam").  GPU: the fused flat HIP step against the same vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "radam_tiny.npz")
+N_STEPS, N_PARAMS = 9, 4
+
+
+def _load():
+    g = np.load(GOLD)
+    return {k: torch.from_numpy(g[k]) for k in g.files}
+
+
+def test_oracle_radam_matches_reference_vectors():
+    from oracle import radmmm_oracle as O
+    g = _load()
+    ps = [g[f"p0.{i}"].clone() for i in range(N_PARAMS)]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    branches = set()
+    for k in range(N_STEPS):
+        grads = [g[f"g.{k}.{i}"] for i in range(N_PARAMS)]
+        total, clipped = O.clip_grad_norm(grads, 1.0)
+        assert abs(float(total) - float(g[f"norm.{k}"])) < 1e-6 * float(g[f"norm.{k}"])
+        branches.add(O.radam_scalars(k + 1, 1e-3, 0.9, 0.999)[0] >= 5)
+        for i in range(N_PARAMS):
+            O.radam_step(ps[i], clipped[i], ms[i], vs[i], k + 1, lr=1e-3, weight_decay=1e-6)
+            assert torch.allclose(ps[i], g[f"p.{k}.{i}"], rtol=1e-6, atol=1e-7), (k, i)
+    assert branches == {True, False}, "fixture must cover both the warm-up and the rectified branch"
+
+
+@pytest.mark.gpu
+def test_flat_radam_matches_reference_vectors():
+    from rad_mmm_amd.optim import FlatRAdam
+    g = _load()
+    dev = "cuda:0"
+    params = [(f"flows.0.p{i}" if i < 2 else f"other.p{i}", torch.nn.Parameter(g[f"p0.{i}"].clone().to(dev)))
+              for i in range(N_PARAMS)]
+    opt = FlatRAdam(params, lr=1e-3, weight_decay=1e-6)
+    assert len(opt.buckets) == 2
+    for k in range(N_STEPS):
+        for i, (_, p) in enumerate(params):
+            p.grad = g[f"g.{k}.{i}"].to(dev)
+        total = opt.clip_grad_norm(1.0)
+        assert abs(float(total) - float(g[f"norm.{k}"])) < 1e-5 * float(g[f"norm.{k}"])
+        opt.step()
+        for i, (_, p) in enumerate(params):
+            assert torch.allclose(p.detach().cpu(), g[f"p.{k}.{i}"], rtol=2e-6, atol=2e-7), (k, i)
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["step"] == N_STEPS
+
+
+@pytest.mark.gpu
+def test_flat_radam_with_bucket_reducer_shares_gradient_flats():
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.optim import FlatRAdam
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    ref.load_state_dict(mod.state_dict())
+    red = BucketedGradReducer(mod)
+    opt = FlatRAdam(mod.named_parameters(), lr=1e-2, reducer=red)
+    assert all(not b["own_g"] for b in opt.buckets)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import radmmm_oracle as O
+    ms = [torch.zeros_like(p) for p in ref.parameters()]
+    vs = [torch.zeros_like(p) for p in ref.parameters()]
+    x = torch.randn(11, 7, device=dev)
+    for k in range(3):
+        red.prepare()
+        mod(x).square().sum().backward()
+        red.finish()
+        opt.step()
+        ref.zero_grad()
+        ref(x).square().sum().backward()
+        with torch.no_grad():
+            for p, m, v in zip(ref.parameters(), ms, vs):
+                O.radam_step(p.data, p.grad, m, v, k + 1, lr=1e-2)
+    for p, q in zip(mod.parameters(), ref.parameters()):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 1e-5
