@@ -675,3 +675,59 @@ def radam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float 
     else:
         p.add_(m, alpha=-step_size)
     return p
+
+
+# --------------------------------------------------------------------------
+# decoder.infer: z -> mel, affine flows
+# --------------------------------------------------------------------------
+def length_regulate(x: Tensor, dur: Tensor) -> Tensor:
+    """LengthRegulator.forward (common.py:208-237): x [B, T_txt, C], dur [B, T_txt] ints ->
+    [B, max_b sum(dur_b), C], frame i repeated dur[i] times, zero padded."""
+    outs = [torch.repeat_interleave(x_i, d_i.long(), dim=0) for x_i, d_i in zip(x, dur)]
+    T = max(o.shape[0] for o in outs)
+    return torch.stack([F.pad(o, (0, 0, 0, T - o.shape[0])) for o in outs])
+
+
+def inv1x1_lus_inverse(p: Params, prefix: str, z: Tensor) -> Tensor:
+    """common.py:532-541."""
+    return F.conv1d(z, torch.inverse(lus_weight(p, prefix).float())[..., None])
+
+
+def inv1x1_whiten_inverse(p: Params, prefix: str, z: Tensor) -> Tensor:
+    """common.py:599-607."""
+    z = F.conv1d(z, torch.inverse(whiten_weight(p, prefix).float())[..., None])
+    return z + p[prefix + "input_mean"].unsqueeze(0)
+
+
+def fold_time(z: Tensor, g: int) -> Tensor:
+    """inverse of squeeze_time (nn.Fold with kernel (g,1), decoders.py:123-126,245-246):
+    [B, C*g, T'] -> [B, C, T'*g] with out[b, c, l*g+k] = z[b, c*g+k, l]."""
+    B, Cg, T = z.shape
+    return z.reshape(B, Cg // g, g, T).permute(0, 1, 3, 2).reshape(B, Cg // g, T * g)
+
+
+def decoder_infer(p: Params, cfg: DecoderConfig, spk: Tensor, txt_enc: Tensor, residual: Tensor, dur: Tensor,
+                  out_lens: Tensor, f0: Optional[Tensor] = None, energy: Optional[Tensor] = None,
+                  accent: Optional[Tensor] = None) -> Tensor:
+    """RADMMMFlow.infer (decoders.py:207-248) with the noise `residual` [B, n_mel*g, T'] (already
+    multiplied by sigma) supplied by the caller; affine flows only (n_splines == 0)."""
+    assert cfg.n_splines == 0
+    g = cfg.n_group_size
+    ctx_t = length_regulate(txt_enc.transpose(1, 2), dur).transpose(1, 2)
+    ctx = preprocess_context(p, cfg, ctx_t, spk, out_lens, f0, energy, accent)
+    exits = list(cfg.exit_steps())
+    ne = cfg.n_early_size
+    mel = residual[:, len(exits) * ne:]
+    remaining = residual[:, : len(exits) * ne]
+    ul = torch.div(out_lens, g, rounding_mode="floor").long()
+    mask = lengths_to_mask(ul)[:, None].to(residual.dtype)
+    for i in reversed(range(cfg.n_flows)):
+        pre = f"flows.{i}."
+        mel = affine_coupling_inverse(p, pre + "coupling_tfn.", mel, ctx, mask, cfg.n_conv_layers_per_step,
+                                      cfg.scaling_fn, cfg.affine_activation, cfg.use_partial_padding)
+        mel = inv1x1_whiten_inverse(p, pre + "invtbl_conv.", mel) if i == 0 else inv1x1_lus_inverse(p, pre + "invtbl_conv.", mel)
+        if exits and i == exits[-1]:
+            exits.pop()
+            mel = torch.cat((remaining[:, len(exits) * ne:], mel), 1)
+            remaining = remaining[:, : len(exits) * ne]
+    return fold_time(mel, g) if g > 1 else mel

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradmmm_hip.so")
+LIB_PATH = os.environ.get("RADMMM_LIB_PATH") or os.path.join(_HERE, "libradmmm_hip.so")   # override: A/B builds of the same ABI
 
 ACT_NONE, ACT_SOFTPLUS, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 SCALE = {"tanh": 0, "exp": 1, "sigmoid": 2, "translate": 3}

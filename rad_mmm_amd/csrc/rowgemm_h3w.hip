@@ -75,7 +75,13 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
 // order is pinned with sched_group_barrier; without it the scheduler keeps a single ds_read in
 // flight and every MFMA group waits for LDS (measured: 39 % MFMA busy inside a workgroup).
 constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100, SGB_DSW = 0x200;
-constexpr int LOOKAHEAD = 2;
+#ifndef H3_LOOKAHEAD
+#define H3_LOOKAHEAD 2
+#endif
+#ifndef H3_DPI
+#define H3_DPI 2        // DMA pieces issued per pipeline item
+#endif
+constexpr int LOOKAHEAD = H3_LOOKAHEAD, DPI = H3_DPI;
 
 template <int MB, int T>
 __device__ __forceinline__ void pin_items() {
@@ -309,8 +315,8 @@ __device__ __forceinline__ void pin_items_dma() {
     __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
     if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
-    if constexpr (2 * T + 1 < MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2, 0);
-    if constexpr (2 * T + 1 == MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
+    constexpr int lo = DPI * T, hi = (DPI * (T + 1) < MB + 8) ? DPI * (T + 1) : MB + 8;
+    if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, hi - lo, 0);
     pin_items_dma<MB, T + 1>();
   }
 }
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   using G = Geo<MB>;
   constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NP = MB + 8;   // NG: 16-row groups of an A array; NP: DMA pieces per wave
   constexpr bool DO_LOAD = !(ABL & 1), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
-  static_assert(MB >= 4 && MB <= 8 && D <= MB, "pipeline shape");
+  static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP, "pipeline shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -486,8 +492,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
       if (t + D == MB) read_b(buf, 1);
       mfma_item(t);
       if constexpr (DO_LOAD) {
-        if (2 * t < NP) dma_piece(buf ^ 1, 2 * t, l_tap, l_kb);
-        if (2 * t + 1 < NP) dma_piece(buf ^ 1, 2 * t + 1, l_tap, l_kb);
+#pragma unroll
+        for (int q = 0; q < DPI; ++q)
+          if (DPI * t + q < NP) dma_piece(buf ^ 1, DPI * t + q, l_tap, l_kb);
       }
     }
     pin_items_dma<MB, 0>();

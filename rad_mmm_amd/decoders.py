@@ -169,8 +169,81 @@ class RADMMMFlow(nn.Module):
     def remove_norms(self):
         raise NotImplementedError("inference-only helper; out of scope (SURVEY.md §8f4)")
 
-    def infer(self, *a, **k):
-        raise NotImplementedError("decoder.infer (inverse flows) is out of scope for this path (SURVEY.md §3.5)")
+    @staticmethod
+    def length_regulator(x, dur):
+        """LengthRegulator.forward (reference common.py:208-237) for the whole batch on the device:
+        x [B, T_txt, C], dur [B, T_txt] (integers) -> [B, max_b sum(dur_b), C]; text frame i is
+        repeated dur[i] times, shorter utterances are zero padded."""
+        B, Tt, C = x.shape
+        dur = dur.long().clamp_min(0)
+        cum = torch.cumsum(dur, 1)
+        total = cum[:, -1]
+        Tmax = int(total.max())
+        t = torch.arange(Tmax, device=x.device)[None, :].expand(B, -1).contiguous()
+        idx = torch.searchsorted(cum, t, right=True).clamp_max(Tt - 1)
+        out = torch.gather(x, 1, idx[:, :, None].expand(-1, -1, C))
+        return out * (t < total[:, None])[:, :, None].to(x.dtype)
+
+    @torch.no_grad()
+    def infer(self, spk_vec, txt_enc, sigma, dur=None, f0=None, energy_avg=None, out_lens=None, accent_vecs=None,
+              residual=None):
+        """z -> mel (reference decoders.py:207-248): length-regulate the text encoding, build the
+        context, then run the flows backwards (coupling inverse, inverse 1x1 conv, early-exit
+        channels re-attached) and fold.  `residual` [B, n_mel*g, T'] optionally supplies the noise
+        (already scaled by sigma) instead of sampling it.  Affine flows only: the spline coupling's
+        inverse branch (splines.py:327-339) is not built."""
+        if any(f.use_spline for f in self.flows):
+            raise NotImplementedError("infer: inverse of the spline coupling is not built (affine flows only)")
+        g = self.n_group_size
+        if out_lens is None:
+            out_lens = dur.sum(1)
+        out_lens = out_lens.to(txt_enc.device).long()
+        ctx_t = self.length_regulator(txt_enc.transpose(1, 2).float(), dur).transpose(1, 2)
+        sl = SequenceLength(out_lens)
+        cond = self.preprocess_context_cl(ctx_t, spk_vec.float(), sl, f0, energy_avg, accent_vecs)
+        B, Tg, D = cond.shape
+        C0 = self.n_mel_channels * g
+        if residual is None:
+            residual = torch.randn(B, C0, Tg, device=txt_enc.device) * sigma
+        r = residual.float().transpose(1, 2).reshape(B * Tg, C0)
+        cond2 = cond.reshape(B * Tg, D)
+        lens32 = torch.div(out_lens, g, rounding_mode="floor").to(torch.int32)
+        exits = list(self.exit_steps)
+        ne = self.n_early_size
+        z = r[:, len(exits) * ne:]
+        remaining = r[:, : len(exits) * ne]
+        for i in reversed(range(len(self.flows))):
+            flow = self.flows[i]
+            C = flow.n_mel_channels
+            h = C // 2
+            assert z.shape[1] == C
+            zp = F.pad(z, (0, ZLD - C)).contiguous()
+            # coupling inverse from ONE forward evaluation of the fused step with an identity channel mix:
+            # it returns y1 = s*z1 + b and log s for the given z0, hence b = y1 - s*z1 and x1 = (z1 - b) / s
+            eye = F.pad(torch.eye(C, device=z.device), (0, ZLD - C, 0, ZLD - C)).contiguous()
+            y, log_s = flow.coupling_tfn.run(zp, cond2, lens32, eye, torch.zeros(ZLD, device=z.device), B, Tg,
+                                             self.gemm_precision, {})
+            sc = torch.exp(log_s)
+            z1 = zp[:, h:C]
+            b = y[:, h:C] - sc * z1
+            zc = torch.cat((zp[:, :h], (z1 - b) / sc), 1)
+            # inverse 1x1 conv (+ the whitening layer's mean), common.py:532-541 / 599-607
+            conv = flow.invtbl_conv
+            Winv = getattr(conv, "_W_inverse", None)
+            if Winv is None:
+                Winv = torch.linalg.inv(conv.weight().float())
+                if conv.cache_inverse:
+                    conv._W_inverse = Winv
+            z = zc @ Winv.t()
+            mean = conv.mean()
+            if mean is not None:
+                z = z + mean.reshape(1, C)
+            if exits and i == exits[-1]:
+                exits.pop()
+                z = torch.cat((remaining[:, len(exits) * ne:], z), 1)
+                remaining = remaining[:, : len(exits) * ne]
+        mel = z.reshape(B, Tg, C0 // g, g).permute(0, 2, 1, 3).reshape(B, C0 // g, Tg * g)
+        return {"mel": mel.contiguous()}
 
     def _squeeze_cl(self, x: torch.Tensor) -> torch.Tensor:
         """[B, C, T] -> channels-last grouped [B, T//g, C*g] with channel c*g+k

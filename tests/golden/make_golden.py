@@ -353,6 +353,47 @@ def main():
                   use_bn=True)
         run_decoder("cfg5_small", mm, 2, 64, True, set())
 
+    # ------------------------------------------------------------------ decoder.infer (inverse flows, f4)
+    if want("infer"):
+        # decoders.py:221 allocates the noise with torch.cuda.FloatTensor; on this GPU-less box the CPU
+        # type stands in (same normal_() stream from torch's CPU generator, seeded below)
+        torch.cuda.FloatTensor = torch.FloatTensor
+        for tag, nfl, T_txt in (("cfg1", 2, 9), ("cfg2_small", 8, 7)):
+            cfg_kwargs = dict(radtts, n_flows=nfl)
+            cfg = O.DecoderConfig(**cfg_kwargs)
+            dec = decoders.RADMMMFlow(use_accent=True, **cfg_kwargs)
+            shapes = {n: tuple(p.shape) for n, p in dec.state_dict().items()}
+            # end_scale 0.002: the coupling scales stay in (0.7, 1.3); with the forward fixtures' 0.02 a random
+            # (untrained) model has scales near 0 and the inverse of noise overflows
+            proc = O.procedural_decoder_state(shapes, end_scale=0.002)
+            dec.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()})
+            dec.eval()
+            g = torch.Generator().manual_seed(99 + nfl)
+            B = 2
+            dur = torch.randint(1, 6, (B, T_txt), generator=g)
+            dur[1, -2:] = 0                                    # shorter second utterance
+            for b in range(B):                                 # even frame counts (group size 2)
+                if int(dur[b].sum()) % 2:
+                    dur[b, 0] += 1
+            out_lens = dur.sum(1)
+            Tmax = int(out_lens.max())
+            txt_enc = torch.randn(B, cfg.n_text_dim, T_txt, generator=g)
+            spk = torch.randn(B, cfg.n_speaker_dim, generator=g)
+            acc = torch.randn(B, cfg.n_accent_dim, generator=g)
+            f0 = torch.rand(B, Tmax, generator=g) * 6
+            en = torch.rand(B, Tmax, generator=g)
+            for b in range(B):
+                f0[b, int(out_lens[b]):] = 0
+                en[b, int(out_lens[b]):] = 0
+            torch.manual_seed(4242)
+            with torch.no_grad():
+                out = dec.infer(spk, txt_enc, 0.8, dur=dur, f0=f0, energy_avg=en, out_lens=out_lens, accent_vecs=acc)
+            arrs = {"dur": dur, "out_lens": out_lens, "txt_enc": txt_enc, "spk": spk, "accent": acc, "f0": f0,
+                    "energy": en, "sigma": 0.8, "seed": 4242, "end_scale": 0.002, "mel": out["mel"]}
+            for k, v in cfg_kwargs.items():
+                arrs["cfg." + k] = np.asarray(v)
+            save(f"infer_{tag}.npz", **t2n(arrs))
+
     # ------------------------------------------------------------------ RAdam + global-norm clip (f3)
     if want("radam"):
         import radam as ref_radam

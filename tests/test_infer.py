@@ -1,0 +1,84 @@
+"""decoder.infer (inverse flows).  CPU: the oracle's restatement against mel captured
+from the reference's RADMMMFlow.infer (tests/golden/make_golden.py, section "infer"; same CPU noise
+stream).  GPU: rad_mmm_amd.decoders.RADMMMFlow.infer against the same vectors, plus the
+forward -> infer round trip."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+HERE = os.path.dirname(__file__)
+
+
+def _case(tag):
+    g = np.load(os.path.join(HERE, "golden", f"infer_{tag}.npz"))
+    cfg_kwargs = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    t = {k: torch.from_numpy(np.asarray(g[k])) for k in ("dur", "out_lens", "txt_enc", "spk", "accent", "f0", "energy", "mel")}
+    torch.manual_seed(int(g["seed"]))
+    Tg = int(t["out_lens"].max()) // int(cfg_kwargs["n_group_size"])
+    C = int(cfg_kwargs["n_mel_channels"]) * int(cfg_kwargs["n_group_size"])
+    residual = torch.FloatTensor(t["spk"].shape[0], C, Tg).normal_() * float(g["sigma"])
+    return cfg_kwargs, t, residual, float(g["end_scale"])
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small"])
+def test_oracle_infer_matches_reference(tag):
+    from oracle import radmmm_oracle as O
+    cfg_kwargs, t, residual, end_scale = _case(tag)
+    cfg = O.DecoderConfig(**cfg_kwargs)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in O.procedural_decoder_state(O.decoder_state_shapes(cfg), end_scale=end_scale).items()}
+    with torch.no_grad():
+        mel = O.decoder_infer(sd, cfg, t["spk"], t["txt_enc"], residual, t["dur"], t["out_lens"], t["f0"], t["energy"], t["accent"])
+    assert mel.shape == t["mel"].shape
+    assert rel_err(mel, t["mel"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small"])
+def test_hip_infer_matches_reference(tag):
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.decoders import RADMMMFlow
+    cfg_kwargs, t, residual, end_scale = _case(tag)
+    cfg = S.DecoderConfig(**cfg_kwargs)
+    dev = "cuda:0"
+    dec = RADMMMFlow(use_accent=True, **cfg_kwargs)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                         S.procedural_decoder_state(S.decoder_state_shapes(cfg), end_scale=end_scale).items()})
+    dec = dec.to(dev).eval()
+    d = {k: v.to(dev) for k, v in t.items()}
+    with torch.no_grad():
+        out = dec.infer(d["spk"], d["txt_enc"], 0.8, dur=d["dur"], f0=d["f0"], energy_avg=d["energy"],
+                        out_lens=d["out_lens"], accent_vecs=d["accent"], residual=residual.to(dev))
+    assert rel_err(out["mel"].cpu(), t["mel"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_infer_inverts_forward():
+    """z = forward(mel); infer with residual = z must return mel (valid frames)."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    cfg_kwargs = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+                      n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+                      scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+                      n_conv_layers_per_step=4, n_flows=4)
+    cfg = S.DecoderConfig(**cfg_kwargs)
+    dev = "cuda:0"
+    dec = RADMMMFlow(use_accent=True, **cfg_kwargs)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                         S.procedural_decoder_state(S.decoder_state_shapes(cfg), end_scale=0.002).items()})
+    dec = dec.to(dev).eval()
+    B, T = 3, 64
+    b = {k: torch.from_numpy(v).to(dev) for k, v in S.synthetic_batch(B, T, cfg, seed=5, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    with torch.no_grad():
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        dur = torch.ones(B, T, dtype=torch.long, device=dev)           # context already at frame rate
+        back = dec.infer(b["spk"], b["context"], 0.0, dur=dur, f0=b["f0"], energy_avg=b["energy"], out_lens=b["lengths"],
+                         accent_vecs=b["accent"], residual=out["z_mel"])
+    for i in range(B):
+        n = int(b["lengths"][i]) // 2 * 2
+        assert rel_err(back["mel"][i, :, :n].cpu(), b["mel"][i, :, :n].cpu()) < 1e-4
