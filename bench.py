@@ -411,7 +411,11 @@ def main():
                          # loads) + WRITE_SIZE 1.024e5 KiB; algorithmic operand + output bytes: 1.78e8
                          "traffic": (2.235e5 * 2 + 1.024e5) * 1024 if (h3 and N == 12800) else None,
                          "traffic_source": "profiles/r01_pmc_h3d.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
-                         if (h3 and N == 12800) else None},
+                         if (h3 and N == 12800) else None,
+                         # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
+                         # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
+                         "peak_measured_random_operands": 1620.0 if h3 else None,
+                         "frac_of_measured_peak": (achieved / 1620.0) if h3 else None},
             "step_flops": {"algorithmic_tflop_per_step": fl * B * T / 1e12,
                            "achieved_tflops_per_gpu": fl * B * T / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_fp32_mfma_peak": fl * B * T / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
