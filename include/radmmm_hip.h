@@ -353,6 +353,16 @@ int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32
 int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens, void* wtpack,
                     float* P, float* dcbuf, int B, int T, int H, const float* gscale, radmmm_stream_t stream);
 
+/* Masked InstanceNorm1d (+ ReLU) on channels-last rows (next-row f1, the text encoder's
+ * nn.InstanceNorm1d(affine=True) applied per utterance, common.py:439-441,476-484): statistics over the
+ * frames t < lens[b] of item b (biased variance, eps as torch), zeros at frames >= lens[b].
+ * x, y, gy, gx [B*T][ld]; mean, rstd [B][C]; dw_part, db_part [B][C] (sum over B = parameter gradients). */
+int radmmm_instnorm_fwd(const float* x, int ldx, const float* weight, const float* bias, float* y, int ldy, float* mean,
+                        float* rstd, const int32_t* lens, int B, int T, int C, float eps, int relu, radmmm_stream_t stream);
+int radmmm_instnorm_bwd(const float* gy, int ldg, const float* x, int ldx, const float* y, int ldy, const float* weight,
+                        const float* mean, const float* rstd, float* gx, int ldgx, float* dw_part, float* db_part,
+                        const int32_t* lens, int B, int T, int C, int relu, radmmm_stream_t stream);
+
 /* Optimizer step on flat fp32 buffers (next-row f3): the reference's vendored RAdam (radam.py:63-142)
  * with the global-norm clip of configs/RADMMM_train_config.yaml:7-8 folded in as a device scalar.
  * step_size / use_denom (N_sma >= 5) come from the host's step count as radam.py:101-123. */

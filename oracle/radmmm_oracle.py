@@ -731,3 +731,38 @@ def decoder_infer(p: Params, cfg: DecoderConfig, spk: Tensor, txt_enc: Tensor, r
             mel = torch.cat((remaining[:, len(exits) * ne:], mel), 1)
             remaining = remaining[:, : len(exits) * ne]
     return fold_time(mel, g) if g > 1 else mel
+
+
+# --------------------------------------------------------------------------
+# text Encoder
+# --------------------------------------------------------------------------
+def spectral_weight(orig: Tensor, u: Tensor, v: Tensor) -> Tensor:
+    """torch.nn.utils.spectral_norm in eval mode (no power iteration): W / sigma, sigma = u^T W v."""
+    return orig / torch.dot(u, torch.mv(orig, v))
+
+
+def encoder_forward(p: Params, prefix: str, x: Tensor, in_lens: Tensor, n_conv: int = 3) -> Tensor:
+    """common.Encoder.forward in eval mode (common.py:461-493): per utterance, n_conv x
+    [weight-normed PartialConv1d k5 on the valid frames -> InstanceNorm1d(affine) -> ReLU], then the
+    packed bi-LSTM over the padded batch.  x [B, C, L] -> [B, max(in_lens), C].  The LSTM's recurrent
+    weights may be stored plain or spectrally normalised (`*_orig`, `*_u`, `*_v`)."""
+    outs = []
+    for b in range(x.shape[0]):
+        n = int(in_lens[b])
+        cur = x[b: b + 1, :, :n]
+        mask = torch.ones(1, 1, n, dtype=x.dtype)
+        for i in range(n_conv):
+            pre = f"{prefix}convolutions.{i}."
+            w = weight_norm_fold(p[pre + "0.conv.weight_v"], p[pre + "0.conv.weight_g"])
+            cur = partial_conv1d(cur, mask, w, p[pre + "0.conv.bias"], 1)
+            cur = F.instance_norm(cur, weight=p[pre + "1.weight"], bias=p[pre + "1.bias"], eps=1e-5)
+            cur = torch.relu(cur)
+        outs.append(cur[0].transpose(0, 1))
+    xp = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True)
+    lp = dict(p)
+    for suf in ("", "_reverse"):
+        key = f"{prefix}lstm.weight_hh_l0{suf}"
+        if key not in lp:
+            lp[key] = spectral_weight(p[key + "_orig"], p[key + "_u"], p[key + "_v"])
+    C = x.shape[1]
+    return lstm_bidir_packed(lp, prefix + "lstm.", xp, in_lens, C // 2)

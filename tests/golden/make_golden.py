@@ -353,6 +353,35 @@ def main():
                   use_bn=True)
         run_decoder("cfg5_small", mm, 2, 64, True, set())
 
+    # ------------------------------------------------------------------ text Encoder (f1)
+    if want("encoder"):
+        for tag, norm in (("plain", None), ("spectral", "spectral")):
+            torch.manual_seed(31)
+            enc = common.Encoder(encoder_n_convolutions=3, encoder_embedding_dim=32, encoder_kernel_size=5,
+                                 lstm_norm_fn=norm)
+            with torch.no_grad():
+                for n, p in enc.named_parameters():
+                    if n.endswith(".1.weight"):
+                        p.copy_(1.0 + 0.3 * torch.randn_like(p))
+                    elif n.endswith(".1.bias"):
+                        p.copy_(0.2 * torch.randn_like(p))
+            enc.eval()                                       # dropout off; spectral norm uses the stored u, v
+            g = torch.Generator().manual_seed(8)
+            lens = torch.tensor([11, 7, 2, 9])
+            x = torch.randn(4, 32, 11, generator=g)
+            for b in range(4):
+                x[b, :, int(lens[b]):] = 0
+            x.requires_grad_(True)
+            out = enc(x, lens)
+            gw = torch.randn(out.shape, generator=g)
+            (out * gw).sum().backward()
+            arrs = {"x": x, "lens": lens, "out": out, "gw": gw, "grad.x": x.grad}
+            for n, t in enc.state_dict().items():
+                arrs["sd." + n] = t
+            for n, p in enc.named_parameters():
+                arrs["gradp." + n] = p.grad
+            save(f"encoder_{tag}.npz", **t2n(arrs))
+
     # ------------------------------------------------------------------ decoder.infer (inverse flows, f4)
     if want("infer"):
         # decoders.py:221 allocates the noise with torch.cuda.FloatTensor; on this GPU-less box the CPU
