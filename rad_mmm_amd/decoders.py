@@ -130,9 +130,8 @@ class RADMMMFlow(nn.Module):
         import os
         # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA) or "h3" (split-f16 x3, fp32-class accuracy)
         self.gemm_precision = os.environ.get("RADMMM_PRECISION", "h3")
-        # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen);
-        # weight/spectral-normed variants (no shipped config uses them) stay on torch
-        self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if (use_context_lstm and context_lstm_norm is None) else "miopen"
+        # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen)
+        self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if use_context_lstm else "miopen"
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
                                  os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
@@ -275,6 +274,8 @@ class RADMMMFlow(nn.Module):
         if self.lstm_impl == "hip":
             # fused per-step HIP recurrence (csrc/lstm.hip); packed-sequence semantics via the lengths
             from .lstm import bilstm
+            for hook in self.context_lstm._forward_pre_hooks.values():     # weight/spectral norm: materialise weight_hh_l0*
+                hook(self.context_lstm, ())
             full = int(ul.min()) == Tg
             lens32 = None if full else torch.div(seq_lens.lengths, g, rounding_mode="floor").to(torch.int32)
             return bilstm(self.context_lstm, x.contiguous(), lens32).contiguous()

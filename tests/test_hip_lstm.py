@@ -49,3 +49,33 @@ def test_bilstm_matches_torch(B, T, I, H, lens):
     assert rel_err(xd.grad.cpu(), gx_ref) < 5e-5
     for n, p in dl.named_parameters():
         assert rel_err(p.grad.cpu(), ref_grads[n]) < 5e-5, n
+
+
+@pytest.mark.parametrize("norm", ["spectral", "weight"])
+def test_decoder_context_lstm_with_normed_recurrent_weights(norm, monkeypatch):
+    """context_lstm_norm != None: the HIP recurrence (weights materialised from torch's hooks) must
+    agree with torch.nn.LSTM (MIOpen) on the same module, outputs and gradients."""
+    import numpy as np
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=1,
+              context_lstm_norm=norm)
+    torch.manual_seed(3)
+    dec = RADMMMFlow(use_accent=True, **kw).to(DEV).train()      # MIOpen's RNN backward needs training mode
+    sd0 = {k: v.clone() for k, v in dec.state_dict().items()}      # spectral norm's power iteration updates u each call
+    cfg = S.DecoderConfig(**{k: v for k, v in kw.items() if k != "context_lstm_norm"})
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(3, 40, cfg, seed=2, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    outs = {}
+    for impl in ("hip", "miopen"):
+        dec.lstm_impl = impl
+        dec.load_state_dict(sd0)
+        dec.zero_grad()
+        y = dec.preprocess_context_cl(b["context"], b["spk"], sl, b["f0"], b["energy"], b["accent"])
+        (y * y).sum().backward()
+        outs[impl] = (y.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in dec.context_lstm.named_parameters()})
+    assert rel_err(outs["hip"][0], outs["miopen"][0]) < 2e-5
+    for n in outs["hip"][1]:
+        assert rel_err(outs["hip"][1][n], outs["miopen"][1][n]) < 1e-4, n
