@@ -572,16 +572,19 @@ int launch(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int
 
 namespace radmmm {
 
-// Row-block count per workgroup: minimise (rounds of the CUs) x (MFMA rows per workgroup + fixed
-// per-workgroup cost in the same unit); ties go to the larger tile (fewer operand re-reads).
+// Row-block count per workgroup.  Cost model fitted to measurements at M = 12 800 and 32 000
+// (DESIGN.md §4.2): a workgroup costs (MB + 1.5) units (MFMA work ~ MB, the 256-row B tile and
+// the fixed parts ~ 1.5); the grid runs `full` rounds of all CUs plus a tail round which, because the
+// chip is power bound, runs faster when few CUs are busy: 0.65 + 0.35 * (tail workgroups / CUs).
 int pick_h3w_mb(int M, int N, int slots) {
   const int ntn = (N + BN - 1) / BN;
   int best = 4;
   double best_cost = 1e300;
   for (int mb = 4; mb <= 7; ++mb) {   // MB = 8 compiles with spills; kept for experiments via RADMMM_H3W_MB
     const long long wg = (long long)((M + 32 * mb - 1) / (32 * mb)) * ntn;
-    const double rounds = (double)((wg + slots - 1) / slots);
-    const double cost = rounds * (mb + 0.75);
+    const long long full = wg / slots, tail = wg % slots;
+    const double rounds = (double)full + (tail ? 0.65 + 0.35 * (double)tail / slots : 0.0);
+    const double cost = rounds * (mb + 1.5);
     if (cost <= best_cost + 1e-9) {
       best_cost = cost;
       best = mb;
