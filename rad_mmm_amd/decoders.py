@@ -74,7 +74,7 @@ class FlowStep(nn.Module):
         log_det_W = conv.log_det()
         if self.use_spline:
             n_valid = int(seq_lens.lengths_host.sum())
-            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid)
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box)
         else:
             z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box)
         return z_out, log_det_W, log_s

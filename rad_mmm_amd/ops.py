@@ -7,6 +7,7 @@ DESIGN.md.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -366,8 +367,18 @@ class ConvNormFn(torch.autograd.Function):
         return None, gx, g_v, g_g, g_bias, None
 
 
-def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none"):
-    meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act])
+def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none", scale_box=None):
+    """scale_box: dict shared by the convs of one backward pass (gradient scale of the split-f16 path,
+    fixed by the first node that runs; without it every conv's backward syncs once for its own)."""
+    meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act],
+                scale_box=scale_box if scale_box is not None else {})
+    Cout, Cin, taps = v.shape
+    # split-f16 path for the frame-rate convs (FiLM stacks: N = B*T' rows); text-rate convs (encoder,
+    # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
+    min_rows = int(os.environ.get("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
+    if (os.environ.get("RADMMM_PRECISION", "h3") == "h3" and Cin % 32 == 0 and (taps // 2) * dil <= 16
+            and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
+        return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
     return ConvNormFn.apply(meta, x, v, g, bias, lens)
 
 
@@ -697,3 +708,68 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
         return (None, g_zin, g_cond, None, g_W_eff, g_b_eff, g_start_v, g_start_g, g_start_b, g_end_w, g_end_b,
                 *g_in, *g_res)
+
+
+class ConvNormH3Fn(torch.autograd.Function):
+    """ConvNormFn on the split-f16 GEMM path: same contract, Cin % 32 == 0.  The input is
+    split on the fly, the weight gradient runs on transposed zero-gapped split copies, the bias gradient
+    comes out of the transposing pass; Cout is padded to a multiple of 32 for the data gradient's K."""
+
+    @staticmethod
+    def forward(ctx, meta, x, v, g, bias, lens):
+        B, T, dil = meta["B"], meta["T"], meta["dil"]
+        partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
+        Cout, Cin, taps = v.shape
+        N = B * T
+        assert x.shape[0] == N and x.shape[1] >= Cin and x.is_contiguous()
+        xh, xl = split_f16(x, Cin, 1.0, Cin)
+        Wh, Wl, inv = split_weight(v, g, Cin)
+        ldy = round_up(Cout, 4)
+        y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
+        rowgemm_h3(Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin, b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
+                   C=y, ldc=ldy, M=N, N=Cout, K=Cin, taps=taps, dil=dil, sign=1, T=T, lens=lens,
+                   a_mask_mode=1 if partial else 0, bias=bias, pconv=1 if partial else 0, ratio_taps=taps, ratio_dil=dil,
+                   postmask=1 if mask_out else 0, act=act)
+        ctx.meta = meta
+        ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
+        ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
+                              inv if inv is not None else v, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        meta = ctx.meta
+        B, T, dil = meta["B"], meta["T"], meta["dil"]
+        partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
+        x, v, g, lens, Wh, Wl, inv, y = ctx.saved_tensors
+        lens = lens if ctx.has_lens else None
+        Cout, Cin, taps = v.shape
+        N = B * T
+        gy = gy.contiguous()
+        ldy = y.shape[1]
+        SG = grad_scale(meta["scale_box"], gy)
+        Kp = round_up(Cout, 32)
+        rowscale = 2 if partial else (1 if mask_out else 0)
+        gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
+        gph, gpl = _halves(N, Kp, like=y)
+        if Kp != Cout:
+            gph[:, Cout:].zero_()
+            gpl[:, Cout:].zero_()
+        check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
+                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, stream()), "dact_mul")
+        gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
+                                           colsum=(2 if partial else 0, lens, taps, dil))
+        x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
+        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG)
+        if ctx.has_g:
+            g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin)
+        else:
+            g_v, g_g = slabs.sum(0).permute(1, 2, 0).contiguous(), None
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.zeros_like(x) if x.shape[1] != Cin else torch.empty_like(x)
+            WTh, WTl = transpose_split(Wh, Wl, Cout, Cin, Kp)                   # [taps][Cin][Kp]
+            rowgemm_h3(Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp, b_tap_stride_h=WTh.stride(0),
+                       acc_scale=1.0 / (SG * W_SCALE), C=gx, ldc=x.shape[1], M=N, N=Cin, K=Kp, taps=taps, dil=dil, sign=-1,
+                       T=T, lens=lens, a_mask_mode=0, premask=1 if partial else 0)
+        return None, gx, g_v, g_g, g_bias if ctx.has_bias else None, None

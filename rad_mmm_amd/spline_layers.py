@@ -86,10 +86,10 @@ class FiLMResBlock(nn.Module):
         self.use_bn = use_bn
         self.bn = MaskedBatchNorm1d(out_channels) if use_bn else None
 
-    def forward_cl(self, x, cond, lens32, B, T, n_valid):
+    def forward_cl(self, x, cond, lens32, B, T, n_valid, scale_box=None):
         pp = self.use_partial_padding
         cn = lambda m, t, act: ops.conv_norm(t, m.conv.weight_v, m.conv.weight_g, m.conv.bias, lens32, B, T,
-                                             dil=m.dilation, partial=pp, mask_out=True, act=act)
+                                             dil=m.dilation, partial=pp, mask_out=True, act=act, scale_box=scale_box)
         x1r = cn(self.input_conv, x, "leaky_relu")            # act(x1) is all that is used downstream
         c1 = cn(self.cond_conv, cond, "none")
         h2 = cn(self.hidden_conv, x1r, "none")
@@ -127,11 +127,11 @@ class FiLMStack(nn.Module):
                                                n_hidden_channels, kernel_size=kernel_size,
                                                dilation=2 ** i if use_dilation else 1, use_bn=use_bn))
 
-    def forward_cl(self, x, cond, lens32, B, T, n_valid):
+    def forward_cl(self, x, cond, lens32, B, T, n_valid, scale_box=None):
         for blk in self.in_layers:
-            x = blk.forward_cl(x, cond, lens32, B, T, n_valid)
+            x = blk.forward_cl(x, cond, lens32, B, T, n_valid, scale_box)
         return ops.conv_norm(x, self.end.weight, None, self.end.bias, None, B, T, dil=1, partial=False, mask_out=False,
-                             act="none")
+                             act="none", scale_box=scale_box)
 
 
 class PQSplineFn(torch.autograd.Function):
@@ -180,7 +180,7 @@ class SplineTransformationLayer(nn.Module):
                                          self.half_mel_channels * self.n_bins, n_layers, use_dilation=with_dilation,
                                          kernel_size=kernel_size, use_bn=use_bn)
 
-    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid):
+    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box=None):
         """[1x1 mix -> FiLM predictor -> spline] on channels-last rows; returns z_out [N, ZLD] and
         log_s [N, 1] (common.py:1040-1090)."""
         ZLD = ops.ZLD
@@ -193,7 +193,7 @@ class SplineTransformationLayer(nn.Module):
             z0[:, h:] = 0
         D = cond_cl.shape[1]
         cond = cond_cl if D % 4 == 0 else torch.nn.functional.pad(cond_cl, (0, (-D) % 4))
-        q = self.param_predictor.forward_cl(z0, cond.contiguous(), lens32, B, T, n_valid)
+        q = self.param_predictor.forward_cl(z0, cond.contiguous(), lens32, B, T, n_valid, scale_box)
         nb = h * self.n_bins
         q = q[:, :nb].contiguous() if q.shape[1] != nb else q
         x = ((z1[:, h: 2 * h] - self.left) / (self.right - self.left)).contiguous()

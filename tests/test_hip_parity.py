@@ -185,6 +185,36 @@ def test_wgrad_h3(R, Cin, Cout, dil, Tn, lens):
         assert torch.equal(x1h[:, :-1].cpu(), xh[:, 1:].cpu())
 
 
+@pytest.mark.parametrize("Cin,Cout,taps,dil,partial,wn", [(32, 40, 5, 2, True, True), (64, 21, 1, 1, False, False),
+                                                         (96, 64, 5, 1, True, True), (32, 32, 3, 1, False, True)])
+def test_conv_norm_h3_matches_fp32_path(R, Cin, Cout, taps, dil, partial, wn, monkeypatch):
+    """ConvNormH3Fn (split-f16 conv, odd/even shifts, K padding of the data gradient, plain and
+    weight-normed weights) against ConvNormFn (fp32 MFMA path, itself pinned to the oracle above)."""
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B, Tn = 3, 40
+    lens = _lens_dev([40, 26, 7])
+    ld = Cin + 4
+    x = torch.randn(B * Tn, ld, generator=g).to(DEV)
+    x[:, Cin:] = 0
+    v = (torch.randn(Cout, Cin, taps, generator=g) * 0.2).to(DEV)
+    gg = (torch.rand(Cout, 1, 1, generator=g) + 0.5).to(DEV) if wn else None
+    b = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(B * Tn, (Cout + 3) // 4 * 4, generator=g).to(DEV) * 1e-2
+    res = {}
+    for mode, rows in (("h3", "0"), ("fp32", "1000000000")):
+        monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", rows)
+        xs = x.clone().requires_grad_(True)
+        vs = v.clone().requires_grad_(True)
+        gs = gg.clone().requires_grad_(True) if wn else None
+        bs = b.clone().requires_grad_(True)
+        y = ops.conv_norm(xs, vs, gs, bs, lens, B, Tn, dil=dil, partial=partial, mask_out=True, act="leaky_relu")
+        (y * gy).sum().backward()
+        res[mode] = [y.detach(), xs.grad[:, :Cin], vs.grad, bs.grad] + ([gs.grad] if wn else [])
+    for a, r in zip(res["h3"], res["fp32"]):
+        assert rel_err(a.cpu(), r.cpu()) < 2e-5
+
+
 def test_weightnorm_bwd(R):
     from oracle import radmmm_oracle as O
     from rad_mmm_amd import ops
@@ -317,7 +347,10 @@ def _build_decoder(g, precision="fp32"):
 
 @pytest.mark.parametrize("tag,precision", [("cfg1", "fp32"), ("cfg2_small", "fp32"), ("cfg5_small", "fp32"),
                                            ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3")])
-def test_decoder_golden(R, golden, tag, precision):
+def test_decoder_golden(R, golden, tag, precision, monkeypatch):
+    # "h3": also route the (small) FiLM convs through ConvNormH3Fn, which by default only takes frame-rate sizes
+    monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", "0" if precision == "h3" else "1000000000")
+    monkeypatch.setenv("RADMMM_PRECISION", precision)
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
     cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture;
     cfg5_small = config-5 architecture (RADMMM dims, 2 spline + 2 affine flows, masked batch-norm)."""
