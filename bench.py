@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="radtts",
                     help="radtts = BASELINE configs[1] (headline); radmmm_splines = configs[4] architecture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true",
+                    help="skip the extra leg that times the 16-bit (single fp16 product) throughput mode")
     ap.add_argument("--optimizer", action="store_true",
                     help="also run the fused global-norm clip + RAdam update inside the timed step (NOT the BASELINE metric, "
                          "which is fwd+bwd only; reported with config.includes_optimizer = true)")
@@ -423,6 +425,27 @@ def main():
                          "achieved": by * B * T / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": by * B * T / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        if world == 1 and h3 and not args.no_throughput_mode:
+            # BASELINE's config label for this workload says "bf16": the same kernels with ONE fp16 MFMA product per
+            # fp32 product (operands rounded to fp16, fp32 accumulate).  Reported beside, never as, `value`: this mode is
+            # outside north_star's 1e-4 parity bar.
+            dec.gemm_precision = "f16"
+            os.environ["RADMMM_PRECISION"] = "f16"
+            for _ in range(2):
+                l16 = step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                l16 = step()
+            torch.cuda.synchronize()
+            dt16 = (time.perf_counter() - t1) / 5
+            l16 = float(l16.detach())
+            res["throughput_mode"] = {"dtype": "f16 operands (single MFMA product), fp32 accumulate", "steps": 5,
+                                      "ms_per_step": dt16 * 1e3, "value": B * T / dt16, "unit": "mel-frames/s",
+                                      "loss_mel": l16, "loss_rel_diff_vs_parity_mode": abs(l16 - loss_val) / abs(loss_val),
+                                      "within_parity_bar": False}
+            dec.gemm_precision = "h3"
+            os.environ["RADMMM_PRECISION"] = "h3"
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd)
     if use_dist:

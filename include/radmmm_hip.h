@@ -113,6 +113,8 @@ typedef struct {
   const void* Ah; const void* Al; int lda_h;
   const void* Bh; const void* Bl; int ldb_h; int64_t b_tap_stride_h;
   float acc_scale;
+  int nprod;                  /* 0 or 3: split products Ah.Bh + Ah.Bl + Al.Bh (fp32-class accuracy);
+                                 1: Ah.Bh only = plain fp16 operands, fp32 accumulate (16-bit throughput mode) */
 } radmmm_rowgemm_h3_desc;
 
 int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);
@@ -336,7 +338,8 @@ int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, rad
 int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);
 int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void* Xl, const void* X1h,
                     const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
-                    int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream);
+                    int Nc, int taps, int dil, int splits, float acc_scale, int nprod /* 3 or 1, as radmmm_rowgemm_h3_desc */,
+                    radmmm_stream_t stream);
 
 /* Bidirectional single-layer LSTM, recurrent part (reference: the decoder's context LSTM,
  * models/radmmm.py:141-146 = torch.nn.LSTM(bidirectional, batch_first) on a packed batch; gate order

@@ -55,6 +55,7 @@ class RowGemmH3Desc(C.Structure):
         ("Ah", C.c_void_p), ("Al", C.c_void_p), ("lda_h", C.c_int),
         ("Bh", C.c_void_p), ("Bl", C.c_void_p), ("ldb_h", C.c_int), ("b_tap_stride_h", C.c_int64),
         ("acc_scale", C.c_float),
+        ("nprod", C.c_int),
     ]
 
 
@@ -111,7 +112,7 @@ def _load() -> C.CDLL:
         "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
-        "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, p],
+        "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],
         "radmmm_h3gemm_nt": [p, p, i, p, p, i, p, i, i, i, i, f, p],
@@ -183,7 +184,7 @@ def rowgemm(**kw) -> None:
     check(lib.radmmm_rowgemm_f32(C.byref(d), stream()), "radmmm_rowgemm_f32")
 
 
-_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale"}
+_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale", "nprod"}
 
 
 def rowgemm_h3(**kw) -> None:

@@ -308,16 +308,25 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgem
 // beyond M / N, frames outside the utterance or masked) get an out-of-range buffer offset and
 // the DMA writes zeros.  The tile for step s + 1 is issued, two pieces per item, early in step s into
 // the other LDS stage and has the rest of the step to land; the barrier's vmcnt(0) retires it.
-template <int MB, int T>
+// PR = MFMA products per fp32 product: 3 (split-f16, fp32-class accuracy) or 1 (plain fp16 operands:
+// the hi halves only -- the "16-bit throughput mode", half the operand traffic and a third of the MFMAs)
+template <int MB, int PR>
+struct Pieces {
+  static constexpr int A = PR == 3 ? MB : (2 * MB + 3) / 4;   // DMA pieces of A per wave
+  static constexpr int B = PR == 3 ? 8 : 4;
+  static constexpr int N = A + B;
+};
+
+template <int MB, int T, int PR>
 __device__ __forceinline__ void pin_items_dma() {
-  constexpr int NT = 2 * MB;
+  constexpr int NT = 2 * MB, NPT = Pieces<MB, PR>::N;
   if constexpr (T < NT - LOOKAHEAD) {
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
-    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
-    constexpr int lo = DPI * T, hi = (DPI * (T + 1) < MB + 8) ? DPI * (T + 1) : MB + 8;
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 2 : 1, 0);
+    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR, 0);
+    constexpr int lo = DPI * T, hi = (DPI * (T + 1) < NPT) ? DPI * (T + 1) : NPT;
     if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, hi - lo, 0);
-    pin_items_dma<MB, T + 1>();
+    pin_items_dma<MB, T + 1, PR>();
   }
 }
 
@@ -332,13 +341,14 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
-template <int MB, int ABL = 0>
+template <int MB, int ABL = 0, int PR = 3>
 __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
                                                               const int b_bytes) {
   using G = Geo<MB>;
-  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NP = MB + 8;   // NG: 16-row groups of an A array; NP: DMA pieces per wave
+  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB;                // NG: 16-row groups of an A array
+  constexpr int NPA = Pieces<MB, PR>::A, NP = Pieces<MB, PR>::N;        // DMA pieces per wave
   constexpr bool DO_LOAD = !(ABL & 1), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
-  static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP, "pipeline shape");
+  static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP && (PR == 1 || PR == 3), "pipeline shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -355,23 +365,26 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   // DMA pieces of one wave per step: MB pieces of A (the 4*MB 16-row groups of {Ah, Al} dealt round
   // robin to the 4 waves) + 8 pieces of B (4 groups of Bh, 4 of Bl).  This lane's row and chunk:
   const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  int a_t[MB], a_lim[MB], a_base[MB], a_vo[MB], a_dst[MB], a_isl[MB], b_voff[4], b_dst[4];
+  int a_t[NPA], a_lim[NPA], a_base[NPA], a_vo[NPA], a_dst[NPA], a_isl[NPA], b_voff[4], b_dst[4];
 #pragma unroll
-  for (int k = 0; k < MB; ++k) {
+  for (int k = 0; k < NPA; ++k) {
     const int c = 4 * k + wave;                       // wave-uniform
-    a_isl[k] = c >= NG ? 1 : 0;
-    const int j = c >= NG ? c - NG : c;
+    // PR == 3: the 4*MB groups of {Ah, Al}; PR == 1: the 2*MB groups of Ah, the surplus (odd MB) is a
+    // zero-writing piece into the dump area behind the stages
+    a_isl[k] = (PR == 3 && c >= NG) ? 1 : 0;
+    const bool real = PR == 3 || c < NG;
+    const int j = a_isl[k] ? c - NG : c;
     const int r = m0 + 16 * j + d_row;
     a_t[k] = 0;
     a_lim[k] = -1;
     a_base[k] = 0;
-    if (r < p.M) {
+    if (real && r < p.M) {
       const int b = r / p.T;
       a_t[k] = r - b * p.T;
       a_lim[k] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
       a_base[k] = (b * p.T * q.lda_h + d_chunk * 8) * 2;
     }
-    a_dst[k] = a_isl[k] * G::A_BYTES + j * 1024;
+    a_dst[k] = real ? a_isl[k] * G::A_BYTES + j * 1024 : -1;
     a_vo[k] = OOB;
   }
 #pragma unroll
@@ -391,19 +404,20 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   auto set_tap = [&](int tap) __attribute__((always_inline)) {
     const int s = p.sign * (tap - p.taps / 2) * p.dil;
 #pragma unroll
-    for (int k = 0; k < MB; ++k) {
+    for (int k = 0; k < NPA; ++k) {
       const int ts = a_t[k] + s;
       const int ok = -(int)((ts >= 0) & (ts < a_lim[k]));        // all ones when the frame is readable
       a_vo[k] = ((a_base[k] + ts * q.lda_h * 2) & ok) | (OOB & ~ok);
     }
   };
-  // piece w of 0 .. MB+7 of tile (tap, kb) into stage `buf`
+  // piece w of 0 .. NP-1 of tile (tap, kb) into stage `buf`
   auto dma_piece = [&](int buf, int w, int tap, int kb) __attribute__((always_inline)) {
     const int sbase = buf * G::STAGE;
-    if (w < MB) {
-      dma16(a_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + sbase + a_dst[w]), a_vo[w] + kb * (BK * 2));
+    if (w < NPA) {
+      const int dst = a_dst[w] < 0 ? 2 * G::STAGE + wave * 1024 : sbase + a_dst[w];
+      dma16((PR == 3 && a_isl[w]) ? rAl : rAh, (lds_u32_ptr)(sm + dst), a_vo[w] + kb * (BK * 2));
     } else {
-      const int k = (w - MB) & 3, arr = (w - MB) >> 2;
+      const int k = (w - NPA) & 3, arr = (w - NPA) >> 2;
       const int vo = b_voff[k] + (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
       dma16(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + sbase + b_dst[k] + arr * G::B_BYTES), vo);
     }
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     const int fo = (t >= MB) ? f_off1 : f_off0;
     const int i = t >= MB ? t - MB : t;
     fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
-    fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+    if constexpr (PR == 3) fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
   };
   auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
     if constexpr (!DO_READ) return;
@@ -461,12 +475,15 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
-      bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+      if constexpr (PR == 3) bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
     }
   };
   auto mfma_item = [&](int t) __attribute__((always_inline)) {
     const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
-    if constexpr (DO_MFMA) {
+    if constexpr (DO_MFMA && PR == 1) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+    } else if constexpr (DO_MFMA) {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
           if (DPI * t + q < NP) dma_piece(buf ^ 1, DPI * t + q, l_tap, l_kb);
       }
     }
-    pin_items_dma<MB, 0>();
+    pin_items_dma<MB, 0, PR>();
     // every read of stage `buf` has been issued: retire them and this wave's DMA, meet the other
     // waves, then fetch the first fragments of the next step while the last D items' MFMAs run
     __builtin_amdgcn_sched_barrier(0);
@@ -508,8 +525,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
 #pragma unroll
     for (int t = NT - D; t < NT; ++t) mfma_item(t);
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6 * D, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 + 2 * D : 2 + D, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR * D, 0);
   }
   __syncthreads();                                   // stray fragment reads / DMA of the clamped extra tile
 
@@ -530,11 +547,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
 }
 
-template <int MB, int ABL = 0>
+template <int MB, int ABL = 0, int PR = 3>
 int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = Geo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL, PR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_h3d<%d>): %s", MB, hipGetErrorString(e));
@@ -545,7 +562,7 @@ int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL, PR>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_h3d");
 }
 
@@ -623,6 +640,15 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
       }
     }
 #endif
+    if (d.nprod == 1) {                                // 16-bit throughput mode: hi halves only
+      switch (mb) {
+        case 4: return launch_dma<4, 0, 1>(d, stream, a_bytes, b_bytes);
+        case 5: return launch_dma<5, 0, 1>(d, stream, a_bytes, b_bytes);
+        case 6: return launch_dma<6, 0, 1>(d, stream, a_bytes, b_bytes);
+        case 7: return launch_dma<7, 0, 1>(d, stream, a_bytes, b_bytes);
+        default: return launch_dma<8, 0, 1>(d, stream, a_bytes, b_bytes);
+      }
+    }
     switch (mb) {
       case 4: return launch_dma<4>(d, stream, a_bytes, b_bytes);
       case 5: return launch_dma<5>(d, stream, a_bytes, b_bytes);

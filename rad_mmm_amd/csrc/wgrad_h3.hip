@@ -46,7 +46,7 @@ struct Geo {
   static constexpr int A_BYTES = BMR * ROWB;
   static constexpr int B_BYTES = BN * ROWB;
   static constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
-  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int SMEM = 2 * STAGE + 4096;      // + dump area of the surplus A piece (PR == 1, odd MB)
 };
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset) {
@@ -55,16 +55,24 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
-template <int MB, int T>
+// PR: MFMA products per fp32 product, 3 (split) or 1 (hi halves only), see rowgemm_h3w.hip
+template <int MB, int PR>
+struct Pieces {
+  static constexpr int A = PR == 3 ? MB : (2 * MB + 3) / 4;
+  static constexpr int B = PR == 3 ? 8 : 4;
+  static constexpr int N = A + B;
+};
+
+template <int MB, int T, int PR>
 __device__ __forceinline__ void pin_items() {
-  constexpr int NT = 2 * MB;
+  constexpr int NT = 2 * MB, NPT = Pieces<MB, PR>::N;
   if constexpr (T < NT - LOOKAHEAD) {
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
-    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
-    if constexpr (2 * T + 1 < MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2, 0);
-    if constexpr (2 * T + 1 == MB + 8) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
-    pin_items<MB, T + 1>();
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 2 : 1, 0);
+    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR, 0);
+    constexpr int lo = 2 * T, hi = (2 * (T + 1) < NPT) ? 2 * (T + 1) : NPT;
+    if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, hi - lo, 0);
+    pin_items<MB, T + 1, PR>();
   }
 }
 
@@ -100,10 +108,10 @@ __device__ __forceinline__ void store_blocks(const f32x16 (&acc)[MB][2], float* 
   }
 }
 
-template <int MB>
+template <int MB, int PR = 3>
 __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
   using G = Geo<MB>;
-  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NP = MB + 8;
+  constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB, NPA = Pieces<MB, PR>::A, NP = Pieces<MB, PR>::N;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,15 +136,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
   const int nsteps = step_hi - step_lo;
 
   const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  int a_vo[MB], a_dst[MB], a_isl[MB], b_vo[4], b_dst[4];
+  int a_vo[NPA], a_dst[NPA], a_isl[NPA], b_vo[4], b_dst[4];
 #pragma unroll
-  for (int k = 0; k < MB; ++k) {
+  for (int k = 0; k < NPA; ++k) {
     const int c = 4 * k + wave;
-    a_isl[k] = c >= NG ? 1 : 0;
-    const int j = c >= NG ? c - NG : c;
+    a_isl[k] = (PR == 3 && c >= NG) ? 1 : 0;
+    const bool real = PR == 3 || c < NG;               // PR == 1, odd MB: surplus piece -> zeros into the dump area
+    const int j = a_isl[k] ? c - NG : c;
     const int r = m0 + 16 * j + d_row;
-    a_vo[k] = r < a.Mc ? (r * a.ldk + d_chunk * 8 + a.k0) * 2 : OOB;
-    a_dst[k] = a_isl[k] * G::A_BYTES + j * 1024;
+    a_vo[k] = (real && r < a.Mc) ? (r * a.ldk + d_chunk * 8 + a.k0) * 2 : OOB;
+    a_dst[k] = real ? a_isl[k] * G::A_BYTES + j * 1024 : -1;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -155,10 +164,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
   auto dma_piece = [&](int buf, int w, int step) __attribute__((always_inline)) {
     const int sbase = buf * G::STAGE;
     const int koff = step * (BK * 2);
-    if (w < MB) {
-      dma16(a_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + sbase + a_dst[w]), a_vo[w] + koff);
+    if (w < NPA) {
+      const int dst = a_dst[w] < 0 ? 2 * G::STAGE + wave * 1024 : sbase + a_dst[w];
+      dma16((PR == 3 && a_isl[w]) ? rAl : rAh, (lds_u32_ptr)(sm + dst), a_vo[w] + koff);
     } else {
-      const int k = (w - MB) & 3, arr = (w - MB) >> 2;
+      const int k = (w - NPA) & 3, arr = (w - NPA) >> 2;
       dma16(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + sbase + b_dst[k] + arr * G::B_BYTES), b_vo[k] + koff);
     }
   };
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
     const int fo = (t >= MB) ? f_off1 : f_off0;
     const int i = t >= MB ? t - MB : t;
     fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
-    fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+    if constexpr (PR == 3) fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
   };
   auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
     const unsigned char* sB = sm + bsel * G::STAGE + 2 * G::A_BYTES + wave * 64 * ROWB;
@@ -188,15 +198,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
-      bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+      if constexpr (PR == 3) bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
     }
   };
   auto mfma_item = [&](int t) __attribute__((always_inline)) {
     const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
-    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
-    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
-    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
-    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
+    if constexpr (PR == 3) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
+    }
     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
   };
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
         if (2 * t < NP) dma_piece(buf ^ 1, 2 * t, nxt);
         if (2 * t + 1 < NP) dma_piece(buf ^ 1, 2 * t + 1, nxt);
       }
-      pin_items<MB, 0>();
+      pin_items<MB, 0, PR>();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
@@ -228,8 +240,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
       for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
 #pragma unroll
       for (int t = NT - D; t < NT; ++t) mfma_item(t);
-      __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
-      __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6 * D, 0);
+      __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 + 2 * D : 2 + D, 0);
+      __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR * D, 0);
     }
     __syncthreads();
   }
@@ -239,11 +251,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_h3_kernel(const WgradH3Args a) {
   store_blocks<MB, 0>(acc, reinterpret_cast<float*>(sm), P, a.ldp, a.Mc, a.Nc, a.acc_scale, m0, n0, tid, lane, wave, vec_ok);
 }
 
-template <int MB>
+template <int MB, int PR = 3>
 int launch_wgrad(const WgradH3Args& a, hipStream_t stream) {
   using G = Geo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel<MB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h3_kernel<MB, PR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(wgrad_h3<%d>): %s", MB, hipGetErrorString(e));
@@ -253,7 +265,7 @@ int launch_wgrad(const WgradH3Args& a, hipStream_t stream) {
   }();
   if (once) return once;
   const int ntm = (a.Mc + G::BMR - 1) / G::BMR, ntn = (a.Nc + BN - 1) / BN;
-  hipLaunchKernelGGL(wgrad_h3_kernel<MB>, dim3(ntm * ntn * a.taps * a.splits), dim3(256), G::SMEM, stream, a);
+  hipLaunchKernelGGL((wgrad_h3_kernel<MB, PR>), dim3(ntm * ntn * a.taps * a.splits), dim3(256), G::SMEM, stream, a);
   return radmmm::check_launch("wgrad_h3");
 }
 
@@ -366,7 +378,7 @@ extern "C" int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps) {
 
 extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void* Xl, const void* X1h,
                                const void* X1l, int ldk, int k0, int Kt, float* P, int ldp, int64_t split_stride, int Mc,
-                               int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream) {
+                               int Nc, int taps, int dil, int splits, float acc_scale, int nprod, radmmm_stream_t stream) {
   RADMMM_REQUIRE(GYh && GYl && Xh && Xl && P, "wgrad_h3: null pointer");
   RADMMM_REQUIRE(Mc > 0 && Nc > 0 && taps >= 1 && dil >= 1 && splits >= 1 && Kt > 0 && Kt % BK == 0 && ldk % 8 == 0 && k0 % 8 == 0 &&
                      ldk >= k0 + Kt + (taps / 2) * dil && k0 >= (taps / 2) * dil,
@@ -384,6 +396,15 @@ extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh,
   a.Mc = Mc; a.Nc = Nc; a.taps = taps; a.dil = dil; a.splits = splits; a.acc_scale = acc_scale;
   a.a_bytes = (int)a_bytes; a.b_bytes = (int)b_bytes;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nprod == 1) {                                    // 16-bit throughput mode: hi halves only
+    switch (wgrad_mb(Mc)) {
+      case 8: return launch_wgrad<8, 1>(a, st);
+      case 7: return launch_wgrad<7, 1>(a, st);
+      case 6: return launch_wgrad<6, 1>(a, st);
+      case 5: return launch_wgrad<5, 1>(a, st);
+      default: return launch_wgrad<4, 1>(a, st);
+    }
+  }
   switch (wgrad_mb(Mc)) {
     case 8: return launch_wgrad<8>(a, st);
     case 7: return launch_wgrad<7>(a, st);

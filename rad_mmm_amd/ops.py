@@ -376,7 +376,9 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     # split-f16 path for the frame-rate convs (FiLM stacks: N = B*T' rows); text-rate convs (encoder,
     # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
     min_rows = int(os.environ.get("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
-    if (os.environ.get("RADMMM_PRECISION", "h3") == "h3" and Cin % 32 == 0 and (taps // 2) * dil <= 16
+    prec = os.environ.get("RADMMM_PRECISION", "h3")
+    meta["nprod"] = 1 if prec == "f16" else 3
+    if (prec in ("h3", "f16") and Cin % 32 == 0 and (taps // 2) * dil <= 16
             and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
         return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
     return ConvNormFn.apply(meta, x, v, g, bias, lens)
@@ -518,7 +520,7 @@ def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False
     return (oh, ol, o1h, o1l, Kt), sums
 
 
-def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale):
+def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     """gy_t / x_t: results of transpose_split_act -> P [S, taps, Mc, ldp] fp32 slabs."""
     gh, gl, _, _, Kt = gy_t
     xh, xl, x1h, x1l, Kt2 = x_t
@@ -529,7 +531,7 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale):
     if ldp != Nc:
         P.zero_()
     check(lib.radmmm_wgrad_h3(ptr(gh), ptr(gl), ptr(xh), ptr(xl), ptr(x1h), ptr(x1l), Kt + 2 * _TS_FRONT, _TS_FRONT, Kt, ptr(P), ldp, P.stride(0),
-                              Mc, Nc, taps, dil, S, acc_scale, stream()), "wgrad_h3")
+                              Mc, Nc, taps, dil, S, acc_scale, nprod, stream()), "wgrad_h3")
     return P
 
 
@@ -552,6 +554,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 *layer_params):
         B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
         act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
+        NPR = meta.get("nprod", 3)               # MFMA products per fp32 product: 3 = split-f16, 1 = fp16 throughput mode
         h = C // 2
         N = B * T
         Wc = start_v.shape[0]
@@ -578,7 +581,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
 
         H = [_empty(N, Wc, like=z_in)]
         Hh, Hl = _halves(N, Wc, like=z_in)
-        rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, acc_scale=inv_ws, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
+        rowgemm_h3(nprod=NPR, Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, acc_scale=inv_ws, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
                    T=T, bias=start_b, Ch=Hh, Cl=Hl, ldch=Wc, ch_scale=1.0)
         OUT = _empty(N, Wc, like=z_in)
         OUTh, OUTl = _halves(N, Wc, like=z_in)
@@ -588,7 +591,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             Hn = _empty(N, Wc, like=z_in)
             Hnh, Hnl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
+            rowgemm_h3(nprod=NPR, Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
                        acc_scale=inv_ws, C=Hn, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, T=T, lens=lens,
                        a_mask_mode=1 if partial else 0, bias=in_p[3 * j + 2], pconv=1 if partial else 0, ratio_taps=kt,
                        ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, ldch=Wc, ch_scale=1.0)
@@ -596,12 +599,12 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             Hh, Hl = Hnh, Hnl
             Rj = _empty(N, Wc, like=z_in)
             last = j == nl - 1
-            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, acc_scale=inv_ws, C=Rj, ldc=Wc, M=N, N=Wc,
+            rowgemm_h3(nprod=NPR, Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, acc_scale=inv_ws, C=Rj, ldc=Wc, M=N, N=Wc,
                        K=Wc, T=T, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
                        C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0)
             R.append(Rj)
         O = _empty(N, ZLD, like=z_in)
-        rowgemm_h3(Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, acc_scale=inv_ws, C=O, ldc=ZLD, M=N, N=C, K=Wc,
+        rowgemm_h3(nprod=NPR, Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, acc_scale=inv_ws, C=O, ldc=ZLD, M=N, N=C, K=Wc,
                    T=T, bias=end_b)
         z_out = _empty(N, ZLD, like=z_in)
         log_s = _empty(N, h, like=z_in)
@@ -616,6 +619,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zout, g_logs):
         meta, nl = ctx.meta, ctx.nl
+        NPR = meta.get("nprod", 3)
         B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
         act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
         sv = ctx.saved_tensors
@@ -651,7 +655,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         gOh, gOl = split_f16(gO, ZLD, SG, ZLD)
         WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD)                    # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
-        rowgemm_h3(Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, acc_scale=inv_acc, C=gOUT, ldc=Wc, M=N, N=Wc,
+        rowgemm_h3(nprod=NPR, Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, acc_scale=inv_acc, C=gOUT, ldc=Wc, M=N, N=Wc,
                    K=ZLD, T=T)
         g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
@@ -666,19 +670,19 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                       ptr(gQl), Wc, SG, stream()), "dact_mul")
             gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
             x_t = transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
-            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG)
+            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, NPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
             WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc)
             g_conv = _empty(N, Wc, like=z_in)
             gch, gcl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, acc_scale=inv_acc, C=g_conv, ldc=Wc, M=N,
+            rowgemm_h3(nprod=NPR, Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, acc_scale=inv_acc, C=g_conv, ldc=Wc, M=N,
                        N=Wc, K=Wc, T=T, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
                        rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
             if (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
                                                             colsum=(2 if partial else 0, lens, kt, d))
                 x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
-                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG)
+                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG, NPR)
             else:
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
@@ -687,18 +691,18 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             G = _empty(N, Wc, like=z_in)
             if j == 0:
                 Gh, Gl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
+            rowgemm_h3(nprod=NPR, Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
                        acc_scale=inv_acc, C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens,
                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
                        ldch=Wc, ch_scale=SG)
         perm = (h, D, 0)
         gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
         x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
-        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG)
+        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, NPR)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
         WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc)                      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)
-        rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, acc_scale=inv_acc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc,
+        rowgemm_h3(nprod=NPR, Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, acc_scale=inv_acc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc,
                    T=T)
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
@@ -719,6 +723,7 @@ class ConvNormH3Fn(torch.autograd.Function):
     def forward(ctx, meta, x, v, g, bias, lens):
         B, T, dil = meta["B"], meta["T"], meta["dil"]
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
+        NPR = meta.get("nprod", 3)
         Cout, Cin, taps = v.shape
         N = B * T
         assert x.shape[0] == N and x.shape[1] >= Cin and x.is_contiguous()
@@ -726,7 +731,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         Wh, Wl, inv = split_weight(v, g, Cin)
         ldy = round_up(Cout, 4)
         y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
-        rowgemm_h3(Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin, b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
+        rowgemm_h3(nprod=NPR, Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin, b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
                    C=y, ldc=ldy, M=N, N=Cout, K=Cin, taps=taps, dil=dil, sign=1, T=T, lens=lens,
                    a_mask_mode=1 if partial else 0, bias=bias, pconv=1 if partial else 0, ratio_taps=taps, ratio_dil=dil,
                    postmask=1 if mask_out else 0, act=act)
@@ -743,6 +748,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
         x, v, g, lens, Wh, Wl, inv, y = ctx.saved_tensors
         lens = lens if ctx.has_lens else None
+        NPR = meta.get("nprod", 3)
         Cout, Cin, taps = v.shape
         N = B * T
         gy = gy.contiguous()
@@ -760,7 +766,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
                                            colsum=(2 if partial else 0, lens, taps, dil))
         x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
-        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG)
+        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, NPR)
         if ctx.has_g:
             g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin)
         else:
@@ -769,7 +775,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gx = torch.zeros_like(x) if x.shape[1] != Cin else torch.empty_like(x)
             WTh, WTl = transpose_split(Wh, Wl, Cout, Cin, Kp)                   # [taps][Cin][Kp]
-            rowgemm_h3(Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp, b_tap_stride_h=WTh.stride(0),
+            rowgemm_h3(nprod=NPR, Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp, b_tap_stride_h=WTh.stride(0),
                        acc_scale=1.0 / (SG * W_SCALE), C=gx, ldc=x.shape[1], M=N, N=Cin, K=Kp, taps=taps, dil=dil, sign=-1,
                        T=T, lens=lens, a_mask_mode=0, premask=1 if partial else 0)
         return None, gx, g_v, g_g, g_bias if ctx.has_bias else None, None

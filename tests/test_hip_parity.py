@@ -185,6 +185,31 @@ def test_wgrad_h3(R, Cin, Cout, dil, Tn, lens):
         assert torch.equal(x1h[:, :-1].cpu(), xh[:, 1:].cpu())
 
 
+def test_decoder_f16_throughput_mode_is_close(R, golden, monkeypatch):
+    """precision "f16" (single fp16 product per fp32 product: the 16-bit throughput mode of DESIGN §4.4) runs
+    the same kernels with the hi halves only; it is NOT inside the 1e-4 bar -- this pins how far outside."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", "f16")
+    g = golden("decoder_cfg2_small.npz")
+    dec, cfg, sd = _build_decoder(g, "f16")
+    b = T(O.synthetic_batch(int(g["B"]), int(g["T"]), cfg, 1234, bool(g["ragged"])))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+    crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)
+    lm = crit(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    zerr = rel_err(out["z_mel"].detach().cpu(), torch.from_numpy(np.asarray(g["z_mel"])))
+    lerr = abs(float(lm) - float(g["loss_mel"])) / abs(float(g["loss_mel"]))
+    assert 1e-7 < zerr < 5e-3 and lerr < 2e-3, (zerr, lerr)
+    for n, p in dec.named_parameters():
+        k = "gradnorm." + n
+        if k in g and float(g[k]) > 1e-6:
+            assert abs(float(p.grad.norm()) - float(g[k])) < 2e-2 * float(g[k]), n
+
+
 @pytest.mark.parametrize("Cin,Cout,taps,dil,partial,wn", [(32, 40, 5, 2, True, True), (64, 21, 1, 1, False, False),
                                                          (96, 64, 5, 1, True, True), (32, 32, 3, 1, False, True)])
 def test_conv_norm_h3_matches_fp32_path(R, Cin, Cout, taps, dil, partial, wn, monkeypatch):
