@@ -236,6 +236,9 @@ int radmmm_fused_add_tanh_sigmoid_multiply(const float* a, const float* b, int l
  * ------------------------------------------------------------------------------------ */
 int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int ldq, float* y, int ldy,
                          float* logj_sum, int rows, int h, int K, radmmm_stream_t stream);
+/* inverse direction of the same transform (splines.py:327-339; no log-jacobian): x from y, both in [0,1) units */
+int radmmm_pq_spline_inv(const float* y, int ldy, const float* q, int ldq, float* x, int ldx, int rows, int h, int K,
+                         radmmm_stream_t stream);
 int radmmm_pq_spline_bwd(const float* x, int ldx, const float* q, int ldq, const float* gy,
                          int ldgy, const float* glogj, float* gx, int ldgx, float* gq, int ldgq,
                          int rows, int h, int K, radmmm_stream_t stream);

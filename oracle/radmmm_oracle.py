@@ -347,6 +347,24 @@ def spline_coupling_forward(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask
     return torch.cat((z0, z1o), 1), log_s
 
 
+def spline_coupling_inverse(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Tensor,
+                            n_layers: int, n_bins: int = 32, bound: float = 3.0,
+                            use_bn: bool = True) -> Tensor:
+    """SplineTransformationLayer.forward(inverse=True), eval mode.  common.py:1040-1090."""
+    B, C, T = z.shape
+    h = C // 2
+    z0, z1 = z[:, :h], z[:, h:]
+    z1n = (z1 + bound) / (2 * bound)
+    q = film_stack_forward(p, prefix + "param_predictor.", z0, ctx, mask, n_layers, use_bn, training=False)
+    nb = 2 * n_bins + 1
+    y = z1n.permute(0, 2, 1).reshape(B * T, h)
+    qt = q.permute(0, 2, 1).reshape(B * T, h, nb)
+    x, _ = unbounded_piecewise_quadratic_transform(y.float(), qt[:, :, :nb // 2].float(), qt[:, :, nb // 2:].float(),
+                                                   inverse=True)
+    z1o = x.reshape(B, T, h).permute(0, 2, 1) * (2 * bound) - bound
+    return torch.cat((z0, z1o), 1)
+
+
 # --------------------------------------------------------------------------
 # decoder
 # --------------------------------------------------------------------------
@@ -710,8 +728,8 @@ def decoder_infer(p: Params, cfg: DecoderConfig, spk: Tensor, txt_enc: Tensor, r
                   out_lens: Tensor, f0: Optional[Tensor] = None, energy: Optional[Tensor] = None,
                   accent: Optional[Tensor] = None) -> Tensor:
     """RADMMMFlow.infer (decoders.py:207-248) with the noise `residual` [B, n_mel*g, T'] (already
-    multiplied by sigma) supplied by the caller; affine flows only (n_splines == 0)."""
-    assert cfg.n_splines == 0
+    multiplied by sigma) supplied by the caller; eval mode (spline flows use the batch-norm running
+    statistics)."""
     g = cfg.n_group_size
     ctx_t = length_regulate(txt_enc.transpose(1, 2), dur).transpose(1, 2)
     ctx = preprocess_context(p, cfg, ctx_t, spk, out_lens, f0, energy, accent)
@@ -723,8 +741,12 @@ def decoder_infer(p: Params, cfg: DecoderConfig, spk: Tensor, txt_enc: Tensor, r
     mask = lengths_to_mask(ul)[:, None].to(residual.dtype)
     for i in reversed(range(cfg.n_flows)):
         pre = f"flows.{i}."
-        mel = affine_coupling_inverse(p, pre + "coupling_tfn.", mel, ctx, mask, cfg.n_conv_layers_per_step,
-                                      cfg.scaling_fn, cfg.affine_activation, cfg.use_partial_padding)
+        if i < cfg.n_splines:
+            mel = spline_coupling_inverse(p, pre + "coupling_tfn.", mel, ctx, mask, cfg.n_conv_layers_per_step,
+                                          use_bn=cfg.use_bn)
+        else:
+            mel = affine_coupling_inverse(p, pre + "coupling_tfn.", mel, ctx, mask, cfg.n_conv_layers_per_step,
+                                          cfg.scaling_fn, cfg.affine_activation, cfg.use_partial_padding)
         mel = inv1x1_whiten_inverse(p, pre + "invtbl_conv.", mel) if i == 0 else inv1x1_lus_inverse(p, pre + "invtbl_conv.", mel)
         if exits and i == exits[-1]:
             exits.pop()

@@ -106,6 +106,7 @@ def _load() -> C.CDLL:
         "radmmm_wgrad_h3_tiles": [i, i, i],
         "radmmm_instnorm_fwd": [p, i, p, p, p, i, p, p, p, i, i, i, f, i, p],
         "radmmm_instnorm_bwd": [p, i, p, i, p, i, p, p, p, p, i, p, p, p, i, i, i, i, p],
+        "radmmm_pq_spline_inv": [p, i, p, i, p, i, i, i, i, p],
         "radmmm_sumsq": [p, i64, p, p],
         "radmmm_radam_step": [p, p, p, p, i64, p, f, f, f, f, f, i, p],
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],

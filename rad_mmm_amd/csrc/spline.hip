@@ -97,6 +97,65 @@ __global__ __launch_bounds__(SP_THREADS) void pq_spline_fwd_kernel(
   }
 }
 
+// Inverse branch (splines.py:306-307, 327-339): locate the bin by the cdf, solve the quadratic for
+// alpha (larger root), x = alpha * w_b + W_{b-1}; elements outside [0, 1) pass through
+// (splines.py:241-265).  No log-jacobian in this direction.
+__global__ __launch_bounds__(SP_THREADS) void pq_spline_inv_kernel(
+    const float* __restrict__ y, int ldy, const float* __restrict__ q, float* __restrict__ x, int ldx, int rows, int h,
+    int K) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nb = 2 * K + 1;
+  const long long total = (long long)rows * h;
+  const long long e0 = (long long)blockIdx.x * SP_THREADS;
+  const int ne = (int)((total - e0) < SP_THREADS ? (total - e0) : SP_THREADS);
+  const float* src = q + e0 * nb;
+  for (int i = threadIdx.x; i < ne * nb; i += SP_THREADS) sm[i] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x < ne) {
+    const long long e = e0 + threadIdx.x;
+    const int r = (int)(e / h), c = (int)(e - (long long)r * h);
+    const float yv = y[(long long)r * ldy + c];
+    const float eps = 1.1920928955078125e-07f;
+    float xo = yv;
+    if (yv >= 0.f && yv < 1.f) {
+      float* P = sm + threadIdx.x * nb;
+      float mw = -INFINITY, mv = -INFINITY;
+      for (int j = 0; j < K; ++j) mw = fmaxf(mw, P[j]);
+      for (int j = 0; j <= K; ++j) mv = fmaxf(mv, P[K + j]);
+      float Z = 0.f;
+      for (int j = 0; j < K; ++j) {
+        const float ex = expf(P[j] - mw);
+        P[j] = ex;
+        Z += ex;
+      }
+      for (int j = 0; j < K; ++j) P[j] = P[j] / Z;
+      for (int j = 0; j <= K; ++j) P[K + j] = expf(P[K + j] - mv) + 1e-8f;
+      float A = 0.f;
+      for (int j = 0; j < K; ++j) A += (P[K + j] + P[K + j + 1]) / 2.f * P[j];
+      float wc = 0.f, cdf = 0.f, w_l = 0.f, c_l = 0.f;
+      int b = K - 1;
+      bool found = false;
+      for (int j = 0; j < K; ++j) {
+        const float wl_j = wc, cl_j = cdf;
+        wc += P[j];
+        cdf += (P[K + j] / A + P[K + j + 1] / A) / 2.f * P[j];
+        const float edge = (j == K - 1) ? 1.f : cdf;             // cdf[..., -1] = 1 (splines.py:300)
+        if (!found && edge >= yv) {
+          found = true;
+          b = j;
+          w_l = wl_j;
+          c_l = cl_j;
+        }
+      }
+      const float w_b = P[b], v_b = P[K + b] / A, v_r = P[K + b + 1] / A;
+      const float qa = (v_r - v_b) * w_b / 2.f, qb = v_b * w_b, qc = c_l - yv;
+      const float alpha = (-qb + sqrtf(qb * qb - 4.f * qa * qc)) / (2.f * qa);
+      xo = fminf(fmaxf(alpha * w_b + w_l, eps), 1.f - eps);
+    }
+    x[(long long)r * ldx + c] = xo;
+  }
+}
+
 // logj_sum[r] = sum_c logj_elem[r*h + c]   (torch.sum(log_s, 1), common.py:1068)
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ v, float* __restrict__ out,
                                                      int rows, int h) {
@@ -215,6 +274,19 @@ extern "C" int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int
   hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0,
                      static_cast<hipStream_t>(stream), logj_elem, logj_sum, rows, h);
   return radmmm::check_launch("pq_spline_fwd");
+}
+
+extern "C" int radmmm_pq_spline_inv(const float* y, int ldy, const float* q, int ldq, float* x, int ldx, int rows, int h,
+                                    int K, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(y && q && x, "pq_spline_inv: null pointer");
+  RADMMM_REQUIRE(rows > 0 && h > 0 && K >= 1 && K <= SP_KMAX, "pq_spline_inv: bad dims");
+  RADMMM_REQUIRE(ldq == h * (2 * K + 1), "pq_spline_inv: q must be dense (ldq == h*(2K+1))");
+  const long long total = (long long)rows * h;
+  const int nblk = (int)((total + SP_THREADS - 1) / SP_THREADS);
+  const size_t smem = (size_t)SP_THREADS * (2 * K + 1) * sizeof(float);
+  hipLaunchKernelGGL(pq_spline_inv_kernel, dim3(nblk), dim3(SP_THREADS), smem, static_cast<hipStream_t>(stream), y, ldy, q,
+                     x, ldx, rows, h, K);
+  return radmmm::check_launch("pq_spline_inv");
 }
 
 extern "C" int radmmm_pq_spline_bwd(const float* x, int ldx, const float* q, int ldq, const float* gy,

@@ -189,10 +189,10 @@ class RADMMMFlow(nn.Module):
         """z -> mel (reference decoders.py:207-248): length-regulate the text encoding, build the
         context, then run the flows backwards (coupling inverse, inverse 1x1 conv, early-exit
         channels re-attached) and fold.  `residual` [B, n_mel*g, T'] optionally supplies the noise
-        (already scaled by sigma) instead of sampling it.  Affine flows only: the spline coupling's
-        inverse branch (splines.py:327-339) is not built."""
-        if any(f.use_spline for f in self.flows):
-            raise NotImplementedError("infer: inverse of the spline coupling is not built (affine flows only)")
+        (already scaled by sigma) instead of sampling it.  Spline flows run the inverse branch of the
+        piecewise-quadratic transform (splines.py:327-339) and need eval() (running batch-norm statistics)."""
+        if self.training and any(f.use_spline for f in self.flows):
+            raise RuntimeError("infer with spline flows needs eval() (masked batch-norm running statistics)")
         g = self.n_group_size
         if out_lens is None:
             out_lens = dur.sum(1)
@@ -217,15 +217,19 @@ class RADMMMFlow(nn.Module):
             h = C // 2
             assert z.shape[1] == C
             zp = F.pad(z, (0, ZLD - C)).contiguous()
+            if flow.use_spline:
+                n_valid = int(torch.div(sl.lengths_host, g, rounding_mode="floor").sum())
+                zc = flow.coupling_tfn.inverse_cl(zp, cond2, lens32, B, Tg, n_valid)
             # coupling inverse from ONE forward evaluation of the fused step with an identity channel mix:
             # it returns y1 = s*z1 + b and log s for the given z0, hence b = y1 - s*z1 and x1 = (z1 - b) / s
-            eye = F.pad(torch.eye(C, device=z.device), (0, ZLD - C, 0, ZLD - C)).contiguous()
-            y, log_s = flow.coupling_tfn.run(zp, cond2, lens32, eye, torch.zeros(ZLD, device=z.device), B, Tg,
-                                             self.gemm_precision, {})
-            sc = torch.exp(log_s)
-            z1 = zp[:, h:C]
-            b = y[:, h:C] - sc * z1
-            zc = torch.cat((zp[:, :h], (z1 - b) / sc), 1)
+            if not flow.use_spline:
+                eye = F.pad(torch.eye(C, device=z.device), (0, ZLD - C, 0, ZLD - C)).contiguous()
+                y, log_s = flow.coupling_tfn.run(zp, cond2, lens32, eye, torch.zeros(ZLD, device=z.device), B, Tg,
+                                                 self.gemm_precision, {})
+                sc = torch.exp(log_s)
+                z1 = zp[:, h:C]
+                b = y[:, h:C] - sc * z1
+                zc = torch.cat((zp[:, :h], (z1 - b) / sc), 1)
             # inverse 1x1 conv (+ the whitening layer's mean), common.py:532-541 / 599-607
             conv = flow.invtbl_conv
             Winv = getattr(conv, "_W_inverse", None)

@@ -109,7 +109,11 @@ class FiLMResBlock(nn.Module):
                     bn.running_mean.mul_(1 - f).add_(f * mean)
                     bn.running_var.mul_(1 - f).add_(f * var * n_valid / (n_valid - 1))
             else:
-                raise NotImplementedError("eval-mode masked batch-norm (running statistics) is inference-only")
+                # eval mode (maskedbatchnorm1d.py:110-118): running statistics, no update; the fused kernel
+                # takes mean / invstd as inputs, so only their source changes (inference path: no autograd
+                # through the statistics is needed)
+                mean = bn.running_mean
+                invstd = torch.rsqrt(bn.running_var + bn.eps)
         return FiLMPostFn.apply(h2, c1, x1r, bn.weight if self.use_bn else None, bn.bias if self.use_bn else None,
                                 mean, invstd, lens32, T, n_valid, self.use_bn)
 
@@ -179,6 +183,26 @@ class SplineTransformationLayer(nn.Module):
         self.param_predictor = FiLMStack(self.half_mel_channels, n_context_dim, 512,
                                          self.half_mel_channels * self.n_bins, n_layers, use_dilation=with_dilation,
                                          kernel_size=kernel_size, use_bn=use_bn)
+
+    @torch.no_grad()
+    def inverse_cl(self, z_cl, cond_cl, lens32, B, T, n_valid):
+        """common.py:1040-1090 with inverse=True on channels-last rows [N, C]: z0 passes through,
+        z1 -> spline^-1 with parameters predicted from z0."""
+        C = self.n_mel_channels
+        h = self.half_mel_channels
+        z = z_cl[:, :C]
+        z0 = torch.nn.functional.pad(z[:, :h], (0, (-h) % 4)).contiguous()
+        D = cond_cl.shape[1]
+        cond = cond_cl if D % 4 == 0 else torch.nn.functional.pad(cond_cl, (0, (-D) % 4))
+        q = self.param_predictor.forward_cl(z0, cond.contiguous(), lens32, B, T, n_valid)
+        nb = h * self.n_bins
+        q = q[:, :nb].contiguous() if q.shape[1] != nb else q
+        y = ((z[:, h: 2 * h] - self.bottom) / (self.top - self.bottom)).contiguous()
+        x = torch.empty_like(y)
+        check(lib.radmmm_pq_spline_inv(ptr(y), h, ptr(q), q.shape[1], ptr(x), h, y.shape[0], h, self.K, stream()),
+              "pq_spline_inv")
+        z1 = x * (self.right - self.left) + self.left
+        return torch.cat((z[:, :h], z1, z[:, 2 * h:]), 1)
 
     def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box=None):
         """[1x1 mix -> FiLM predictor -> spline] on channels-last rows; returns z_out [N, ZLD] and

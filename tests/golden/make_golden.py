@@ -387,8 +387,11 @@ def main():
         # decoders.py:221 allocates the noise with torch.cuda.FloatTensor; on this GPU-less box the CPU
         # type stands in (same normal_() stream from torch's CPU generator, seeded below)
         torch.cuda.FloatTensor = torch.FloatTensor
-        for tag, nfl, T_txt in (("cfg1", 2, 9), ("cfg2_small", 8, 7)):
+        for tag, nfl, T_txt in (("cfg1", 2, 9), ("cfg2_small", 8, 7), ("cfg5_small", 4, 8)):
             cfg_kwargs = dict(radtts, n_flows=nfl)
+            if tag == "cfg5_small":      # RADMMM / 16 kHz dims, 2 spline + 2 affine flows (eval: running BN stats)
+                cfg_kwargs = dict(radtts, n_text_dim=520, use_accent_emb_for_decoder=False, n_flows=4, n_splines=2,
+                                  use_bn=True)
             cfg = O.DecoderConfig(**cfg_kwargs)
             dec = decoders.RADMMMFlow(use_accent=True, **cfg_kwargs)
             shapes = {n: tuple(p.shape) for n, p in dec.state_dict().items()}

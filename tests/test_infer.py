@@ -13,6 +13,18 @@ from conftest import rel_err
 HERE = os.path.dirname(__file__)
 
 
+def _close(a, ref, spline):
+    """max-norm relative error for affine flows.  The spline inverse solves
+    alpha = (-b + sqrt(b^2 - 4ac)) / 2a as the reference does (splines.py:333-336); where a bin is nearly linear
+    (a -> 0) that expression cancels and amplifies last-bit differences between ANY two fp32 evaluations (the CPU
+    oracle on another host differs from the fixture by 9e-4 in a handful of elements), so spline cases are judged
+    by the bulk of the elements plus a loose cap on the outliers."""
+    err = (a - ref).abs() / ref.abs().max()
+    if not spline:
+        return float(err.max()) < 1e-4
+    return float((err > 1e-4).float().mean()) < 5e-3 and float(err.max()) < 1e-2
+
+
 def _case(tag):
     g = np.load(os.path.join(HERE, "golden", f"infer_{tag}.npz"))
     cfg_kwargs = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
@@ -24,20 +36,23 @@ def _case(tag):
     return cfg_kwargs, t, residual, float(g["end_scale"])
 
 
-@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small"])
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small", "cfg5_small"])
 def test_oracle_infer_matches_reference(tag):
     from oracle import radmmm_oracle as O
     cfg_kwargs, t, residual, end_scale = _case(tag)
     cfg = O.DecoderConfig(**cfg_kwargs)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in O.procedural_decoder_state(O.decoder_state_shapes(cfg), end_scale=end_scale).items()}
     with torch.no_grad():
-        mel = O.decoder_infer(sd, cfg, t["spk"], t["txt_enc"], residual, t["dur"], t["out_lens"], t["f0"], t["energy"], t["accent"])
+        mel = O.decoder_infer(sd, cfg, t["spk"], t["txt_enc"], residual, t["dur"], t["out_lens"], t["f0"], t["energy"],
+                              t["accent"] if cfg.use_accent_emb_for_decoder else None)
     assert mel.shape == t["mel"].shape
-    assert rel_err(mel, t["mel"]) < 1e-5
+    assert _close(mel, t["mel"], cfg.n_splines > 0)
+    if not cfg.n_splines:
+        assert rel_err(mel, t["mel"]) < 1e-5
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small"])
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2_small", "cfg5_small"])
 def test_hip_infer_matches_reference(tag):
     from rad_mmm_amd import synthetic as S
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -51,8 +66,9 @@ def test_hip_infer_matches_reference(tag):
     d = {k: v.to(dev) for k, v in t.items()}
     with torch.no_grad():
         out = dec.infer(d["spk"], d["txt_enc"], 0.8, dur=d["dur"], f0=d["f0"], energy_avg=d["energy"],
-                        out_lens=d["out_lens"], accent_vecs=d["accent"], residual=residual.to(dev))
-    assert rel_err(out["mel"].cpu(), t["mel"]) < 1e-4
+                        out_lens=d["out_lens"], accent_vecs=d["accent"] if cfg.use_accent_emb_for_decoder else None,
+                        residual=residual.to(dev))
+    assert _close(out["mel"].cpu(), t["mel"], cfg.n_splines > 0)
 
 
 @pytest.mark.gpu
