@@ -788,3 +788,49 @@ def encoder_forward(p: Params, prefix: str, x: Tensor, in_lens: Tensor, n_conv: 
             lp[key] = spectral_weight(p[key + "_orig"], p[key + "_u"], p[key + "_v"])
     C = x.shape[1]
     return lstm_bidir_packed(lp, prefix + "lstm.", xp, in_lens, C // 2)
+
+
+# --------------------------------------------------------------------------
+# attribute predictors
+# --------------------------------------------------------------------------
+def dap_tx_data(x: Tensor, target_scale: float, target_offset: float, log_target: bool) -> Tensor:
+    """AttributePredictor.tx_data without target normalisation (attribute_predictors.py:100-104)."""
+    x = x * target_scale + target_offset
+    return torch.log(x + 1) if log_target else x
+
+
+def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Tensor, n_layers: int) -> Tensor:
+    """ConvLSTMLinearDAP.forward in eval mode (attribute_predictors.py:172-192, common.py:281-333):
+    bottleneck = leaky_relu(mask * weight-normed conv k3 (text_enc)); cat speaker; per utterance
+    n_layers x relu(weight-normed conv k3) on the valid frames; packed spectral-normed bi-LSTM;
+    linear.  text_enc [B, C, T] -> x_hat [B, out_dim, T']."""
+    T = text_enc.shape[2]
+    mask = lengths_to_mask(lens, T)[:, None].to(text_enc.dtype)
+    pre = prefix + "bottleneck_layer.projection_fn.conv."
+    w = weight_norm_fold(p[pre + "weight_v"], p[pre + "weight_g"])
+    k = w.shape[-1]
+    ctx = F.leaky_relu(F.conv1d(text_enc, w, p[pre + "bias"], padding=(k - 1) // 2) * mask)
+    ctx = torch.cat((ctx, spk[:, :, None].expand(-1, -1, T)), 1)
+    outs = []
+    for b in range(ctx.shape[0]):
+        cur = ctx[b: b + 1, :, : int(lens[b])]
+        for i in range(n_layers):
+            q = f"{prefix}feat_pred_fn.convolutions.{i}.conv."
+            w = weight_norm_fold(p[q + "weight_v"], p[q + "weight_g"])
+            cur = torch.relu(F.conv1d(cur, w, p[q + "bias"], padding=(w.shape[-1] - 1) // 2))
+        outs.append(cur[0].transpose(0, 1))
+    xp = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True)
+    lp = dict(p)
+    lpre = prefix + "feat_pred_fn.bilstm."
+    for suf in ("", "_reverse"):
+        key = f"{lpre}weight_hh_l0{suf}"
+        if key not in lp:
+            lp[key] = spectral_weight(p[key + "_orig"], p[key + "_u"], p[key + "_v"])
+    y = lstm_bidir_packed(lp, lpre, xp, lens, xp.shape[2] // 2)
+    return F.linear(y, p[prefix + "feat_pred_fn.dense.weight"], p[prefix + "feat_pred_fn.dense.bias"]).transpose(1, 2)
+
+
+def attribute_regression_loss(x_hat: Tensor, x: Tensor, lens: Tensor) -> Tensor:
+    """AttributeRegressionLoss (loss.py:233-250): masked mean squared error."""
+    mask = lengths_to_mask(lens, x.shape[2])[:, None]
+    return F.mse_loss(x_hat[mask], x[mask], reduction="sum") / mask.sum()

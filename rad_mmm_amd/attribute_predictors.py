@@ -1,0 +1,174 @@
+"""Attribute predictors (reference attribute_predictors.py:27-197 + common.ConvLSTMLinear,
+common.py:240-333): f0 / energy / duration / voiced predictors of config 4.
+The reference runs the conv backbone in a per-utterance Python loop on slices; here the padded
+batch goes through each layer in one launch (input masked to the utterance length = the zero
+padding a conv over the slice sees), the spectral-normed bi-LSTM runs on the fused HIP recurrence,
+only the final Linear and the target transforms are torch.  Same constructor arguments,
+state_dict names and output dict {'x_hat', 'x'}."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .common import SequenceLength, _WNConv
+from .lstm import bilstm
+
+
+class _ConvHolder(nn.Module):
+    def __init__(self, cin, cout, k, gain="linear"):
+        super().__init__()
+        self.conv = _WNConv(cin, cout, k, w_init_gain=gain)
+
+
+def _rows(x):
+    """[B, C, T] -> channels-last rows [B*T, round_up(C, 4)]"""
+    B, C, T = x.shape
+    y = x.float().permute(0, 2, 1)
+    if C % 4:
+        y = F.pad(y, (0, (-C) % 4))
+    return y.reshape(B * T, -1).contiguous()
+
+
+class BottleneckLayer(nn.Module):
+    def __init__(self, in_dim, reduction_factor=16, norm="weightnorm", non_linearity="leakyrelu", kernel_size=3,
+                 use_partial_padding=True):
+        super().__init__()
+        if norm != "weightnorm":
+            raise Exception("BottleneckLayer: only norm='weightnorm' is built (the reference's default)")
+        self.reduction_factor = reduction_factor
+        self.out_dim = int(in_dim / reduction_factor)
+        self.leaky = non_linearity == "leakyrelu"
+        if reduction_factor > 1:
+            self.projection_fn = _ConvHolder(in_dim, self.out_dim, kernel_size)
+
+    def forward_rows(self, x_rows, lens32, B, T):
+        if self.reduction_factor <= 1:
+            return x_rows
+        c = self.projection_fn.conv
+        # ConvNorm without partial padding: conv of the padded batch as it is, then * mask (common.py:179-191)
+        return ops.conv_norm(x_rows, c.weight_v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
+                             act="leaky_relu" if self.leaky else "relu")
+
+
+class ConvLSTMLinear(nn.Module):
+    def __init__(self, in_dim=None, out_dim=None, n_layers=2, n_channels=256, kernel_size=3, p_dropout=0.1,
+                 lstm_type: Optional[str] = "bilstm", use_linear=True, use_weight_norm=True):
+        super().__init__()
+        if lstm_type != "bilstm" or not use_linear or not use_weight_norm:
+            raise Exception("ConvLSTMLinear: only lstm_type='bilstm', use_linear, use_weight_norm is built")
+        self.out_dim = out_dim
+        self.p_dropout = p_dropout
+        self.convolutions = nn.ModuleList(
+            [_ConvHolder(in_dim if i == 0 else n_channels, n_channels, kernel_size, "relu") for i in range(n_layers)])
+        self.bilstm = nn.LSTM(n_channels, n_channels // 2, 1, batch_first=True, bidirectional=True)
+        self.bilstm = nn.utils.spectral_norm(self.bilstm, "weight_hh_l0")
+        self.bilstm = nn.utils.spectral_norm(self.bilstm, "weight_hh_l0_reverse")
+        self.dense = nn.Linear(n_channels, out_dim)
+
+    def forward_rows(self, h, lens32, B, T):
+        """h [B*T, ld] channels-last context -> x_hat [B, out_dim, T]"""
+        valid = (torch.arange(T, device=h.device)[None, :] < lens32[:, None]).reshape(B * T, 1)
+        h = h * valid                                  # a conv over x[:, :len] sees zeros beyond len
+        for holder in self.convolutions:
+            c = holder.conv
+            h = ops.conv_norm(h, c.weight_v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
+                              act="relu")
+            h = F.dropout(h, self.p_dropout, self.training)
+        for hook in self.bilstm._forward_pre_hooks.values():        # materialise the spectral-normed weight_hh_l0*
+            hook(self.bilstm, ())
+        C = self.convolutions[-1].conv.weight_v.shape[0]
+        y = bilstm(self.bilstm, h[:, :C].reshape(B, T, C).contiguous(), lens32)
+        return self.dense(y).transpose(1, 2)
+
+
+class AttributePredictor(nn.Module):
+    """target transforms of attribute_predictors.py:54-133"""
+
+    def __init__(self, target_scale=1, target_offset=0, log_target=False, normalize_target=False,
+                 normalization_type=None):
+        super().__init__()
+        self.target_scale, self.target_offset, self.log_target = target_scale, target_offset, log_target
+        self.normalize_target, self.normalization_type = normalize_target, normalization_type
+
+    def tx_data(self, x, x_mean=None, x_std=None):
+        if self.normalize_target:
+            assert self.normalization_type is not None
+            if self.normalization_type == "norm_lin_space":
+                xr = x - x_mean[:, None].expand(-1, x.shape[1]) / x_std[:, None].expand(-1, x.shape[1])
+                return torch.log(xr + 10) / 3
+            if self.normalization_type == "norm_log_space":
+                xr = (x - x_mean[:, None, None].expand(-1, 1, x.shape[2])) / x_std[:, None, None].expand(-1, 1, x.shape[2])
+                return (xr + 5) / 10
+            return x
+        x = x * self.target_scale + self.target_offset
+        return torch.log(x + 1) if self.log_target else x
+
+    def inv_tx_data(self, x, x_mean=None, x_std=None):
+        if self.normalize_target:
+            if self.normalization_type == "norm_lin_space" and x_mean is not None and x_std is not None:
+                return (torch.exp(x * 3) - 10) * x_std + x_mean
+            if self.normalization_type == "norm_log_space" and x_mean is not None and x_std is not None:
+                x = x * 10 - 5
+                return x * x_std[:, None, None].expand(-1, 1, x.shape[2]) + x_mean[:, None, None].expand(-1, 1, x.shape[2])
+            return x
+        if self.log_target:
+            x = torch.exp(x) - 1
+        return (x - self.target_offset) / self.target_scale
+
+
+class ConvLSTMLinearDAP(AttributePredictor):
+    def __init__(self, n_speaker_dim=16, n_accent_dim=0, in_dim=512, out_dim=1, reduction_factor=16, n_backbone_layers=2,
+                 n_hidden=256, kernel_size=3, p_dropout=0.25, target_scale=1, target_offset=0, log_target=False,
+                 lstm_type: Optional[str] = "bilstm", use_speaker_embedding=True, use_accent_embedding=False,
+                 normalize_target=False, normalization_type=None):
+        super().__init__(target_scale, target_offset, log_target, normalize_target, normalization_type)
+        self.use_speaker_embedding = bool(use_speaker_embedding)
+        self.use_accent_embedding = bool(use_accent_embedding)
+        self.bottleneck_layer = BottleneckLayer(in_dim=in_dim, reduction_factor=reduction_factor)
+        d = self.bottleneck_layer.out_dim + (n_speaker_dim if use_speaker_embedding else 0) \
+            + (n_accent_dim if use_accent_embedding else 0)
+        self.feat_pred_fn = ConvLSTMLinear(in_dim=d, out_dim=out_dim, n_layers=n_backbone_layers, n_channels=n_hidden,
+                                           kernel_size=kernel_size, p_dropout=p_dropout, lstm_type=lstm_type)
+
+    def forward(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
+        if not text_enc.is_cuda:
+            raise RuntimeError("rad_mmm_amd.attribute_predictors runs on an MI355X only (no CPU path)")
+        if x_target is not None:
+            x_target = self.tx_data(x_target, x_mean, x_std)
+        B, _, T = text_enc.shape
+        lens32 = lens.lengths.to(torch.int32).contiguous()
+        h = self.bottleneck_layer.forward_rows(_rows(text_enc), lens32, B, T)
+        parts = [h[:, : self.bottleneck_layer.out_dim].reshape(B, T, -1)]
+        if self.use_speaker_embedding:
+            parts.append(spk_emb.float()[:, None, :].expand(-1, T, -1))
+        if self.use_accent_embedding:
+            parts.append(accent_emb.float()[:, None, :].expand(-1, T, -1))
+        ctx = torch.cat(parts, 2)
+        if ctx.shape[2] % 4:
+            ctx = F.pad(ctx, (0, (-ctx.shape[2]) % 4))
+        x_hat = self.feat_pred_fn.forward_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T)
+        return {"x_hat": x_hat, "x": x_target}
+
+    def infer(self, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
+        res = self.forward(None, text_enc, spk_emb, lens, accent_emb=accent_emb)
+        return self.inv_tx_data(res["x_hat"], x_mean, x_std)
+
+
+class AttributeRegressionLoss(nn.Module):
+    """loss.py:233-250: masked MSE -> {prefix + 'loss': (value, weight)}"""
+
+    def __init__(self, prefix: Optional[str] = None, weight=1.0):
+        super().__init__()
+        self.prefix, self.weight = prefix, weight
+
+    def forward(self, model_output, in_lens, out_lens, global_step, mask=None):
+        target, prediction = model_output["x"], model_output["x_hat"]
+        if mask is None:
+            mask = out_lens.mask.unsqueeze(1)
+        mask = mask.bool()
+        loss = F.mse_loss(prediction[mask], target[mask], reduction="sum") / mask.sum()
+        return {self.prefix + "loss": (loss, self.weight)}

@@ -382,6 +382,35 @@ def main():
                 arrs["gradp." + n] = p.grad
             save(f"encoder_{tag}.npz", **t2n(arrs))
 
+    # ------------------------------------------------------------------ attribute predictor (f2)
+    if want("dap"):
+        import attribute_predictors as ref_ap
+        torch.manual_seed(17)
+        dap = ref_ap.ConvLSTMLinearDAP(n_speaker_dim=16, in_dim=32, out_dim=1, reduction_factor=4, n_backbone_layers=2,
+                                       n_hidden=16, kernel_size=3, p_dropout=0.25, target_scale=2.0, target_offset=0.5,
+                                       log_target=True, lstm_type="bilstm", use_speaker_embedding=True)
+        dap.eval()
+        g = torch.Generator().manual_seed(5)
+        lens = torch.tensor([13, 9, 2, 13])
+        sl = common.SequenceLength(lens)
+        txt = torch.randn(4, 32, 13, generator=g)
+        for b in range(4):
+            txt[b, :, int(lens[b]):] = 0
+        txt.requires_grad_(True)
+        spk = torch.randn(4, 16, generator=g)
+        target = torch.rand(4, 1, 13, generator=g) * 3
+        out = dap(target, txt, spk, sl)
+        crit = ref_loss.AttributeRegressionLoss(prefix="f0_", weight=1.0)
+        loss = crit(out, None, sl, 0)["f0_loss"][0]
+        loss.backward()
+        arrs = {"txt": txt, "spk": spk, "lens": lens, "target": target, "x_hat": out["x_hat"], "x": out["x"], "loss": loss,
+                "grad.txt": txt.grad}
+        for n, t in dap.state_dict().items():
+            arrs["sd." + n] = t
+        for n, p in dap.named_parameters():
+            arrs["gradp." + n] = p.grad
+        save("dap_tiny.npz", **t2n(arrs))
+
     # ------------------------------------------------------------------ decoder.infer (inverse flows, f4)
     if want("infer"):
         # decoders.py:221 allocates the noise with torch.cuda.FloatTensor; on this GPU-less box the CPU
