@@ -78,6 +78,7 @@ def main():
     cwd = os.getcwd()
     os.chdir("/tmp")
     import torch
+    import torch.nn.functional as F
     torch.set_num_threads(8)
     import common
     import splines
@@ -381,6 +382,88 @@ def main():
             for n, p in enc.named_parameters():
                 arrs["gradp." + n] = p.grad
             save(f"encoder_{tag}.npz", **t2n(arrs))
+
+    # ------------------------------------------------------------------ training_step glue (a17)
+    if want("tts_step"):
+        # tts_lightning_modules needs pytorch_lightning (absent), so the step is composed here from the reference's
+        # own components in the order of TTSModel.training_step (tts_lightning_modules.py:643-750)
+        n_text = 32
+        kw = dict(radtts, n_text_dim=n_text, n_flows=2)
+        dec = decoders.RADMMMFlow(use_accent=True, **kw)
+        enc = common.Encoder(3, n_text, 5, lstm_norm_fn=None)
+        mods = torch.nn.ModuleDict(dict(
+            text_embeddings=torch.nn.Embedding(40, n_text), text_encoder=enc,
+            speaker_embeddings=torch.nn.Embedding(3, 16), accent_embeddings=torch.nn.Embedding(2, 8),
+            attention=common.ConvAttention(80, n_text), decoder=dec))
+        shapes = {n: tuple(p.shape) for n, p in mods.state_dict().items()}
+        proc = O.procedural_decoder_state(shapes)
+        mods.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()})
+        mods.train()
+        for m in mods.modules():                      # deterministic step: no dropout
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        enc_drop = F.dropout
+        g = torch.Generator().manual_seed(21)
+        B, T, L = 2, 48, 9
+        out_lens = torch.tensor([48, 36])
+        in_lens = torch.tensor([9, 6])
+        batch = {"mel": torch.randn(B, 80, T, generator=g) * 1.2 - 5.0, "speaker_ids": torch.tensor([0, 2]),
+                 "accent_ids": torch.tensor([1, 0]), "text": torch.randint(0, 40, (B, L), generator=g),
+                 "input_lengths": in_lens, "output_lengths": out_lens,
+                 "attn_prior": torch.rand(B, T, L, generator=g) * 0.9 + 0.05, "f0": torch.rand(B, T, generator=g) * 6,
+                 "energy_avg": torch.rand(B, T, generator=g)}
+        for b in range(B):
+            batch["mel"][b, :, int(out_lens[b]):] = 0
+            batch["f0"][b, int(out_lens[b]):] = 0
+            batch["energy_avg"][b, int(out_lens[b]):] = 0
+            batch["text"][b, int(in_lens[b]):] = 0
+        crit = ref_loss.RADMMMLoss(sigma=1.0, kl_loss_start_iter=5)
+        crit.n_group_size = dec.n_group_size
+        arrs = {("batch." + k): v for k, v in batch.items()}
+        real_dropout = F.dropout
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: x      # Encoder calls F.dropout(x, 0.5, self.training)
+        try:
+            for tag, step, binarize in (("soft", 0, False), ("hard", 10, True)):
+                mods.zero_grad()
+                il, ol = common.SequenceLength(in_lens), common.SequenceLength(out_lens)
+                mel = (batch["mel"] + 5) / 2
+                spk = mods["speaker_embeddings"](batch["speaker_ids"])
+                acc = mods["accent_embeddings"](batch["accent_ids"])
+                emb = mods["text_embeddings"](batch["text"]).transpose(1, 2)
+                txt_enc = mods["text_encoder"](emb, il.lengths).transpose(1, 2)
+                attn_mask = common.get_mask_from_lengths(il.lengths)[..., None] == 0
+                attn_soft, attn_logprob = mods["attention"](mel, emb, ol.lengths, attn_mask, key_lens=il.lengths,
+                                                            attn_prior=batch["attn_prior"])
+                if binarize:
+                    hard = torch.zeros_like(attn_soft)
+                    a_np = attn_soft.data.cpu().numpy()
+                    for i in range(B):
+                        hard[i, 0, :out_lens[i], :in_lens[i]] = torch.tensor(
+                            alignment.mas_width1(a_np[i, 0, :out_lens[i], :in_lens[i]]))
+                    attn = hard
+                else:
+                    attn = attn_soft
+                context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
+                outputs = mods["decoder"](mel, spk, context, ol, f0=batch["f0"], energy_avg=batch["energy_avg"],
+                                          accent_vecs=acc)
+                outputs.update(attn=attn, attn_soft=attn_soft, attn_logprob=attn_logprob)
+                ld = crit(outputs, il, ol, step)
+                loss = None
+                for k, (v, w) in ld.items():
+                    loss = v * w if loss is None else loss + v * w
+                    arrs[f"{tag}.{k}"] = v if torch.is_tensor(v) else torch.tensor(float(v))
+                loss.backward()
+                arrs[f"{tag}.loss"] = loss
+                arrs[f"{tag}.attn"] = attn
+                arrs[f"{tag}.context"] = context
+                for n, p in mods.named_parameters():
+                    if p.grad is not None and (n.startswith(("text_", "speaker_", "accent_", "attention")) or "context_lstm" in n):
+                        arrs[f"{tag}.gradnorm.{n}"] = p.grad.norm()
+        finally:
+            F.dropout = real_dropout
+        for k, v in kw.items():
+            arrs["cfg." + k] = np.asarray(v)
+        save("tts_step.npz", **t2n(arrs))
 
     # ------------------------------------------------------------------ attribute predictor (f2)
     if want("dap"):
