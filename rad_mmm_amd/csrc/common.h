@@ -38,6 +38,12 @@ inline int check_launch(const char* what) {
 __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- device helpers -------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for the
+// write acknowledgements of every global store issued so far (stores count in vmcnt on gfx9): in an
+// epilogue that alternates "stage a block in LDS / store it" that costs one HBM write round trip (2-5 us)
+// per block.  Use only where no global-memory hand-off between the waves depends on the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float softplus_f(float x) {
   // torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x)) = max(x, 0) + log1p(exp(-|x|)).
   // Hardware exp2/log2 (v_exp_f32 / v_log_f32, 1 ulp) instead of libm's expf/log1pf: ~12 VALU

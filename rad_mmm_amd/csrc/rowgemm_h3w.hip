@@ -39,32 +39,102 @@ struct Geo {
   static constexpr int AI = (MB + 1) / 2;        // A rows staged per thread (64 rows per pass)
 };
 
+// Fast path of the fused epilogue for one thread's 4 columns of one row: everything that does not
+// depend on the row (column validity, bias, base pointers) is hoisted by the caller, all accesses are
+// 16-byte (8-byte for the fp16 copies) and the option flags are wave-uniform branches.  Preconditions
+// (checked once per workgroup): EpilogueCtx::vec_ok, N % 4 == 0.  Same arithmetic and order as
+// radmmm::epilogue_store4_pre.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// hi = fp16(s x) (saturated), lo = fp16(s x - hi) for 4 values, kept in vector registers (arrays whose
+// address is taken for a wide store end up in scratch)
+__device__ __forceinline__ void pack_split(float x0, float x1, float x2, float x3, float s, f16x4& hi, f16x4& lo) {
+  const float t0 = fminf(fmaxf(x0 * s, -60000.f), 60000.f), t1 = fminf(fmaxf(x1 * s, -60000.f), 60000.f);
+  const float t2 = fminf(fmaxf(x2 * s, -60000.f), 60000.f), t3 = fminf(fmaxf(x3 * s, -60000.f), 60000.f);
+  hi[0] = (_Float16)t0; hi[1] = (_Float16)t1; hi[2] = (_Float16)t2; hi[3] = (_Float16)t3;
+  lo[0] = (_Float16)(t0 - (float)hi[0]); lo[1] = (_Float16)(t1 - (float)hi[1]);
+  lo[2] = (_Float16)(t2 - (float)hi[2]); lo[3] = (_Float16)(t3 - (float)hi[3]);
+}
+
+// all indices are 32-bit element offsets from the (wave-uniform) base pointers: M * ld < 2^31 is checked
+// by the host, and a scalar base + 32-bit vector offset keeps the epilogue's VGPR demand small enough
+// not to push accumulators into scratch
+__device__ __forceinline__ void epilogue_row_fast(const radmmm_rowgemm_desc& p, int row, int col, float4 a4, float maskv,
+                                                  float ratio, float b0, float b1, float b2, float b3) {
+  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), dsv = addv, c2v = addv;
+  if (p.add) addv = *reinterpret_cast<const float4*>(p.add + (unsigned)(row * p.ldadd + col));
+  if (p.dact) dsv = *reinterpret_cast<const float4*>(p.dact_src + (unsigned)(row * p.lddact + col));
+  if (p.C2 && p.c2_accum) c2v = *reinterpret_cast<const float4*>(p.C2 + (unsigned)(row * p.ldc2 + col));
+  const float pre = (p.pconv ? ratio : 1.f) * (p.premask ? maskv : 1.f);
+  const float post = (p.postmask ? maskv : 1.f);
+  const float rsc = p.rowscale == 1 ? maskv : (p.rowscale == 2 ? maskv * ratio : 1.f);
+  auto one = [&](float acc, float bias, float add, float ds) __attribute__((always_inline)) {
+    float x = (acc * pre + bias + add) * post;
+    if (p.dact) x *= radmmm::dact_from_out(ds, p.dact);
+    return radmmm::act_apply(x * rsc, p.act);
+  };
+  const float v0 = one(a4.x, b0, addv.x, dsv.x), v1 = one(a4.y, b1, addv.y, dsv.y);
+  const float v2 = one(a4.z, b2, addv.z, dsv.z), v3 = one(a4.w, b3, addv.w, dsv.w);
+  c2v.x += v0; c2v.y += v1; c2v.z += v2; c2v.w += v3;
+  if (p.Ch) {
+    f16x4 hi, lo;
+    pack_split(v0, v1, v2, v3, p.ch_scale, hi, lo);
+    const unsigned o = (unsigned)(row * p.ldch + col);
+    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.Ch) + o) = hi;
+    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.Cl) + o) = lo;
+  }
+  if (p.C2h) {
+    f16x4 hi, lo;
+    pack_split(c2v.x, c2v.y, c2v.z, c2v.w, p.c2h_scale, hi, lo);
+    const unsigned o = (unsigned)(row * p.ldc2h + col);
+    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.C2h) + o) = hi;
+    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.C2l) + o) = lo;
+  }
+  *reinterpret_cast<float4*>(p.C + (unsigned)(row * p.ldc + col)) = make_float4(v0, v1, v2, v3);
+  if (p.C2) *reinterpret_cast<float4*>(p.C2 + (unsigned)(row * p.ldc2 + col)) = c2v;
+}
+
 // Epilogue of row block I (compile-time index: a runtime-indexed accumulator array would live in
 // scratch): the four waves park their 32x64 pieces in LDS, then all threads run the fused epilogue
 // on coalesced float4 rows.
-template <int MB, int I>
+template <int MB, int I, bool FAST>
 __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], float* smf, const float2* rowf,
                                                 const radmmm_rowgemm_desc& p, const radmmm::EpilogueCtx& ec, float sc,
                                                 int m0, int n0, int tid, int lane, int wave, const float (&biasv)[4]) {
   if constexpr (I < MB) {
-    if (I > 0) __syncthreads();            // the previous block has been read out
+    if (I > 0) radmmm::lds_barrier();      // the previous block has been read out (its global stores stay in flight)
     float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[I][j][e] * sc;
-    __syncthreads();
+    radmmm::lds_barrier();
     if (m0 + I * 32 < p.M) {
       const int c4 = (tid & 63) * 4;
-#pragma unroll 4
-      for (int k = 0; k < 8; ++k) {
-        const int rl = k * 4 + (tid >> 6);
-        const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
-        const float2 rf = rowf[I * 32 + rl];
-        radmmm::epilogue_store4_pre(p, ec, m0 + I * 32 + rl, n0 + c4, a4, rf.x, rf.y, biasv);
+      if constexpr (FAST) {
+        if (n0 + c4 < p.N) {
+#pragma unroll 2
+          for (int k = 0; k < 8; ++k) {
+            const int rl = k * 4 + (tid >> 6);
+            const int row = m0 + I * 32 + rl;
+            if (row < p.M) {
+              const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
+              const float2 rf = rowf[I * 32 + rl];
+              epilogue_row_fast(p, row, n0 + c4, a4, rf.x, rf.y, biasv[0], biasv[1], biasv[2], biasv[3]);
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+          const int rl = k * 4 + (tid >> 6);
+          const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
+          const float2 rf = rowf[I * 32 + rl];
+          radmmm::epilogue_store4_pre(p, ec, m0 + I * 32 + rl, n0 + c4, a4, rf.x, rf.y, biasv);
+        }
       }
     }
-    epilogue_blocks<MB, I + 1>(acc, smf, rowf, p, ec, sc, m0, n0, tid, lane, wave, biasv);
+    epilogue_blocks<MB, I + 1, FAST>(acc, smf, rowf, p, ec, sc, m0, n0, tid, lane, wave, biasv);
   }
 }
 
@@ -98,7 +168,7 @@ __device__ __forceinline__ void pin_items() {
 
 // ABL: ablation bits for bottleneck hunting (results are wrong when != 0): 1 no global loads,
 // 2 no staging stores, 4 no fragment reads, 8 no MFMAs inside the K loop.
-template <int MB, int ABL = 0>
+template <int MB, int ABL = 0, bool FASTEPI = false>
 __global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
                                                               const int b_bytes) {
   using G = Geo<MB>;
@@ -297,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgem
 #pragma unroll
     for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
   }
-  epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
+  epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -341,7 +411,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
-template <int MB, int ABL = 0, int PR = 3>
+template <int MB, int ABL = 0, int PR = 3, bool FASTEPI = false>
 __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
                                                               const int b_bytes) {
   using G = Geo<MB>;
@@ -544,14 +614,14 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
 #pragma unroll
     for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
   }
-  epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
+  epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
 }
 
-template <int MB, int ABL = 0, int PR = 3>
+template <int MB, int ABL = 0, int PR = 3, bool FASTEPI = false>
 int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = Geo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL, PR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL, PR, FASTEPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_h3d<%d>): %s", MB, hipGetErrorString(e));
@@ -562,7 +632,7 @@ int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL, PR>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL, PR, FASTEPI>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_h3d");
 }
 
@@ -636,26 +706,38 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
         case 8: return launch_dma<7, 8>(d, stream, a_bytes, b_bytes);
         case 12: return launch_dma<7, 12>(d, stream, a_bytes, b_bytes);
         case 13: return launch_dma<7, 13>(d, stream, a_bytes, b_bytes);
+        case 15: return launch_dma<7, 15>(d, stream, a_bytes, b_bytes);
         default: break;
       }
     }
 #endif
+    // lean epilogue (16-byte accesses, 32-bit element offsets) when every output / side input allows it
+    const radmmm_rowgemm_desc& p = d.base;
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto fits = [&](long long ld) { return (long long)p.M * ld < 0x7fffffffLL; };
+    const bool fast = p.N % 4 == 0 && p.ldc % 4 == 0 && a16(p.C) && fits(p.ldc) &&
+                      (!p.add || (p.ldadd % 4 == 0 && a16(p.add) && fits(p.ldadd))) &&
+                      (!p.dact || (p.lddact % 4 == 0 && a16(p.dact_src) && fits(p.lddact))) &&
+                      (!p.C2 || (p.ldc2 % 4 == 0 && a16(p.C2) && fits(p.ldc2))) &&
+                      (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && (reinterpret_cast<uintptr_t>(p.Ch) & 7) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(p.Cl) & 7) == 0)) &&
+                      (!p.C2h || (p.ldc2h % 4 == 0 && fits(p.ldc2h) && (reinterpret_cast<uintptr_t>(p.C2h) & 7) == 0 &&
+                                  (reinterpret_cast<uintptr_t>(p.C2l) & 7) == 0));
+#define RADMMM_H3D_CASE(MBV, PRV)                                                       \
+  case MBV:                                                                             \
+    return fast ? launch_dma<MBV, 0, PRV, true>(d, stream, a_bytes, b_bytes)            \
+                : launch_dma<MBV, 0, PRV, false>(d, stream, a_bytes, b_bytes);
     if (d.nprod == 1) {                                // 16-bit throughput mode: hi halves only
       switch (mb) {
-        case 4: return launch_dma<4, 0, 1>(d, stream, a_bytes, b_bytes);
-        case 5: return launch_dma<5, 0, 1>(d, stream, a_bytes, b_bytes);
-        case 6: return launch_dma<6, 0, 1>(d, stream, a_bytes, b_bytes);
-        case 7: return launch_dma<7, 0, 1>(d, stream, a_bytes, b_bytes);
-        default: return launch_dma<8, 0, 1>(d, stream, a_bytes, b_bytes);
+        RADMMM_H3D_CASE(4, 1) RADMMM_H3D_CASE(5, 1) RADMMM_H3D_CASE(6, 1) RADMMM_H3D_CASE(7, 1)
+        default: return fast ? launch_dma<8, 0, 1, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 0, 1, false>(d, stream, a_bytes, b_bytes);
       }
     }
     switch (mb) {
-      case 4: return launch_dma<4>(d, stream, a_bytes, b_bytes);
-      case 5: return launch_dma<5>(d, stream, a_bytes, b_bytes);
-      case 6: return launch_dma<6>(d, stream, a_bytes, b_bytes);
-      case 7: return launch_dma<7>(d, stream, a_bytes, b_bytes);
-      default: return launch_dma<8>(d, stream, a_bytes, b_bytes);
+      RADMMM_H3D_CASE(4, 3) RADMMM_H3D_CASE(5, 3) RADMMM_H3D_CASE(6, 3) RADMMM_H3D_CASE(7, 3)
+      default: return fast ? launch_dma<8, 0, 3, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 0, 3, false>(d, stream, a_bytes, b_bytes);
     }
+#undef RADMMM_H3D_CASE
   }
 #ifdef RADMMM_ABLATION
   if (const char* e = getenv("RADMMM_H3W_ABL")) {

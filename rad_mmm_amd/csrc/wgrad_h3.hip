@@ -80,13 +80,13 @@ template <int MB, int I>
 __device__ __forceinline__ void store_blocks(const f32x16 (&acc)[MB][2], float* smf, float* P, int ldp, int Mc, int Nc,
                                              float sc, int m0, int n0, int tid, int lane, int wave, bool vec_ok) {
   if constexpr (I < MB) {
-    if (I > 0) __syncthreads();
+    if (I > 0) radmmm::lds_barrier();      // LDS only: the previous block's global stores stay in flight
     float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[I][j][e] * sc;
-    __syncthreads();
+    radmmm::lds_barrier();
     const int c4 = (tid & 63) * 4, col = n0 + c4;
 #pragma unroll 4
     for (int k = 0; k < 8; ++k) {
