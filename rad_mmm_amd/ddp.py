@@ -37,24 +37,37 @@ class BucketedGradReducer:
     """
 
     def __init__(self, module: torch.nn.Module, bucket_key: Callable[[str], str] = default_bucket_key,
-                 process_group=None):
+                 process_group=None, direct: Optional[Callable[[str], bool]] = None):
+        """direct(name) -> True for parameters whose backward node writes the gradient straight into the
+        bucket (rad_mmm_amd.ops.grad_out): those get .grad = None before backward, so autograd adopts the
+        bucket view instead of launching an add per tensor; default = the decoders' WN parameters."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized()      # reduce even at world size 1 (RCCL smoke test)
-        groups: "OrderedDict[str, List[torch.nn.Parameter]]" = OrderedDict()
+        if direct is None:
+            direct = lambda name: ".affine_param_predictor." in name
+        groups: "OrderedDict[str, List]" = OrderedDict()
         for name, p in module.named_parameters():
             if p.requires_grad:
-                groups.setdefault(bucket_key(name), []).append(p)
+                groups.setdefault(bucket_key(name), []).append((bool(direct(name)) and p.is_cuda, p))
         self.buckets: List[Dict] = []
         self._by_param: Dict[int, Dict] = {}
-        for key, params in groups.items():
+        self._views: Dict[int, torch.Tensor] = {}
+        self._direct: Dict[int, bool] = {}
+        for key, tagged in groups.items():
+            tagged = [t for t in tagged if t[0]] + [t for t in tagged if not t[0]]   # direct ones first: one fill covers the rest
+            params = [t[1] for t in tagged]
             n = sum(p.numel() for p in params)
+            n_direct = sum(p.numel() for d_, p in tagged if d_)
             flat = torch.zeros(n, device=params[0].device, dtype=params[0].dtype)
             off = 0
-            for p in params:
-                p.grad = flat[off: off + p.numel()].view_as(p)
+            for d_, p in tagged:
+                view = flat[off: off + p.numel()].view_as(p)
+                p.grad = view
+                self._views[id(p)] = view
+                self._direct[id(p)] = d_
                 off += p.numel()
-            b = dict(key=key, params=params, flat=flat, pending=len(params), handle=None)
+            b = dict(key=key, params=params, flat=flat, pending=len(params), handle=None, n_direct=n_direct)
             self.buckets.append(b)
             for p in params:
                 self._by_param[id(p)] = b
@@ -63,6 +76,10 @@ class BucketedGradReducer:
 
     def _make_hook(self, bucket):
         def hook(param):
+            view = self._views[id(param)]
+            if param.grad is not view and param.grad.data_ptr() != view.data_ptr():
+                view.copy_(param.grad)               # the node did not use the sink (or autograd cloned): one copy
+                param.grad = view
             bucket["pending"] -= 1
             if bucket["pending"] == 0 and self.active:
                 # RCCL stream waits for the kernels already queued on the compute stream, then
@@ -72,19 +89,33 @@ class BucketedGradReducer:
         return hook
 
     def prepare(self) -> None:
-        """Zero the flat buffers and re-arm the hooks (call before backward)."""
+        """Re-arm the hooks (call before backward): accumulate-style parameters get a zeroed .grad view,
+        direct ones .grad = None plus a registered sink (their node overwrites the bucket slice)."""
+        from . import ops
+        ops.GRAD_SINKS.clear()
         for b in self.buckets:
-            b["flat"].zero_()
+            if b["n_direct"] < b["flat"].numel():
+                b["flat"][b["n_direct"]:].zero_()
             b["pending"] = len(b["params"])
             b["handle"] = None
-            off = 0
             for p in b["params"]:
-                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * b["flat"].element_size():
-                    p.grad = b["flat"][off: off + p.numel()].view_as(p)
-                off += p.numel()
+                view = self._views[id(p)]
+                if self._direct[id(p)]:
+                    p.grad = None
+                    ops.GRAD_SINKS[p.data_ptr()] = view
+                elif p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                    p.grad = view
 
     def finish(self) -> None:
         """Wait for the outstanding reductions and turn sums into means (call after backward)."""
+        from . import ops
+        ops.GRAD_SINKS.clear()
+        for b in self.buckets:                # direct parameters that received no gradient this step
+            for p in b["params"]:
+                if p.grad is None:
+                    view = self._views[id(p)]
+                    view.zero_()
+                    p.grad = view
         if not self.active:
             return
         for b in self.buckets:

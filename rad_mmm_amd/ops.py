@@ -43,6 +43,22 @@ def pick_splits(tiles: int, rows: int, slots: int = 512) -> int:
 
 
 # ---------------------------------------------------------------------------------------
+# gradient sinks
+# ---------------------------------------------------------------------------------------
+# ddp.BucketedGradReducer keeps the gradients in flat buckets.  A backward node that asks grad_out(param)
+# for its output buffer writes the gradient straight into the bucket and returns that view; with
+# param.grad == None autograd's AccumulateGrad then adopts the view as .grad (no add kernel, no copy).
+GRAD_SINKS = {}          # parameter data_ptr -> destination view (registered per step by the reducer)
+
+
+def grad_out(param: torch.Tensor) -> torch.Tensor:
+    t = GRAD_SINKS.get(param.data_ptr())
+    if t is not None and t.shape == param.shape and t.dtype == param.dtype:
+        return t.view(t.shape)       # a fresh alias: AccumulateGrad only adopts a tensor nobody else references
+    return torch.empty_like(param)
+
+
+# ---------------------------------------------------------------------------------------
 # thin launch helpers
 # ---------------------------------------------------------------------------------------
 def weightnorm_fwd(v: torch.Tensor, g: torch.Tensor, ldw: Optional[int] = None,
@@ -61,8 +77,8 @@ def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0)):
     """dW_slabs [S, taps, Cout, ldw] -> (dv like v, dg like g)."""
     Cout, Cin, taps = v.shape
     S = dW_slabs.shape[0]
-    dv = torch.empty_like(v)
-    dg = torch.empty_like(g)
+    dv = grad_out(v)
+    dg = grad_out(g)
     check(lib.radmmm_weightnorm_bwd(ptr(v), ptr(g), ptr(inv), ptr(dW_slabs), S,
                                     dW_slabs.stride(0), ptr(dv), ptr(dg), Cout, Cin, taps, ldw,
                                     perm[0], perm[1], perm[2], stream()), "weightnorm_bwd")
@@ -70,9 +86,10 @@ def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0)):
 
 
 def colsum(X: torch.Tensor, cols: int, row_weight: int = 0, T: int = 1,
-           lens: Optional[torch.Tensor] = None, taps: int = 1, dil: int = 1, square: bool = False) -> torch.Tensor:
+           lens: Optional[torch.Tensor] = None, taps: int = 1, dil: int = 1, square: bool = False,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     rows, ld = X.shape
-    out = _empty(cols, like=X)
+    out = out if (out is not None and out.numel() == cols) else _empty(cols, like=X)
     scratch = _empty(int(lib.radmmm_colsum_scratch_floats(rows, cols)), like=X)
     check(lib.radmmm_colsum(ptr(X), ld, ptr(out), ptr(scratch), rows, cols, row_weight, T,
                             ptr(lens), taps, dil, 1 if square else 0, stream()), "colsum")
@@ -487,7 +504,7 @@ _TS_FRONT = 16           # leading zero columns / zero gap between utterances (>
 _ts_pool = {}
 
 
-def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None):
+def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None, sum_out=None):
     """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
     Buffers come from a small zero-initialised pool keyed by shape and role: the pads are never
     written, the data and the gaps are rewritten on every call (single stream => reuse is ordered).
@@ -511,7 +528,7 @@ def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False
     weight, wlens, taps, dil = colsum
     nparts = B * (-(-Tp // 64))
     part = _empty(nparts, C, like=x)
-    sums = _empty(C, like=x)
+    sums = sum_out if (sum_out is not None and sum_out.numel() == C) else _empty(C, like=x)
     assert mask_mode == 0 or wlens is lens or wlens is None
     check(lib.radmmm_transpose_split_act_colsum(ptr(x), x.shape[1], C, B, T, Tp, _TS_FRONT, ptr(lens if mask_mode else wlens),
                                                 mask_mode, scale, ptr(oh), ptr(ol), ptr(o1h), ptr(o1l), ldk, ptr(part),
@@ -613,6 +630,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.nl = nl
         ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
+                              start_b, end_b,
                               *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *layer_params)
         return z_out, log_s
 
@@ -623,8 +641,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
         act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
         sv = ctx.saved_tensors
-        z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel = sv[:15]
-        p = 15
+        z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel, start_b, end_b = sv[:17]
+        p = 17
         take = lambda n: sv[p: p + n]
         H = sv[p: p + nl + 1]; p += nl + 1
         R = sv[p: p + nl]; p += nl
@@ -650,8 +668,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         gz1 = _empty(N, ZLD, like=z_in)
         check(lib.radmmm_affine_coupling_bwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(g_zout), ptr(g_logs), ptr(gO), ptr(gz1),
                                              N, h, scaling, stream()), "affine_coupling_bwd")
-        g_end_b = colsum(gO, C)
-        g_end_w = wgrad_slabs(gO, C, OUT, Wc, Wc, T, None).sum(0).view(C, Wc, 1)
+        g_end_b = colsum(gO, C, out=grad_out(end_b))
+        g_end_w = grad_out(end_w)
+        torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
         gOh, gOl = split_f16(gO, ZLD, SG, ZLD)
         WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD)                    # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
@@ -668,7 +687,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
                                       ptr(gQl), Wc, SG, stream()), "dact_mul")
-            gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
+            gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
+                                                         sum_out=grad_out(res_p[3 * j + 2]))
             x_t = transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, NPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
@@ -680,7 +700,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
             if (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
-                                                            colsum=(2 if partial else 0, lens, kt, d))
+                                                            colsum=(2 if partial else 0, lens, kt, d),
+                                                            sum_out=grad_out(in_p[3 * j + 2]))
                 x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG, NPR)
             else:
@@ -696,7 +717,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
                        ldch=Wc, ch_scale=SG)
         perm = (h, D, 0)
-        gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1))
+        gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
+                                              sum_out=grad_out(start_b))
         x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
         slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, NPR)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)

@@ -40,6 +40,12 @@ class FlatRAdam:
         self.buckets: List[Dict] = []
         red_flats = {b["key"]: b for b in reducer.buckets} if reducer is not None else {}
         for key, params in groups.items():
+            gflat = None
+            if key in red_flats:
+                rb = red_flats[key]
+                assert sorted(id(q) for q in rb["params"]) == sorted(id(q) for q in params), "bucket contents differ"
+                params = list(rb["params"])             # the reducer's order (direct-write parameters first)
+                gflat = rb["flat"]
             n = sum(p.numel() for p in params)
             flat = torch.empty(n, device=params[0].device, dtype=torch.float32)
             off = 0
@@ -47,11 +53,6 @@ class FlatRAdam:
                 flat[off: off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat[off: off + p.numel()].view_as(p)          # parameter becomes a view of the flat buffer
                 off += p.numel()
-            gflat = None
-            if key in red_flats:
-                rb = red_flats[key]
-                assert [id(q) for q in rb["params"]] == [id(q) for q in params], "bucket layouts differ"
-                gflat = rb["flat"]
             self.buckets.append(dict(key=key, params=params, flat=flat, gflat=gflat, own_g=gflat is None,
                                      m=torch.zeros_like(flat), v=torch.zeros_like(flat)))
         dev = self.buckets[0]["flat"].device

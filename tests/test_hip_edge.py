@@ -146,3 +146,46 @@ def test_masked_reduce_with_empty_item():
     m = (torch.arange(9, device=DEV)[None] < lens[:, None])[:, None].float()
     assert abs(float(ops.masked_sum(x, lens)) - float((x * m).sum())) < 1e-5
     assert abs(float(ops.masked_sumsq(x, lens)) - float(((x * m) ** 2).sum())) < 1e-4
+
+
+def test_bucket_reducer_direct_gradients_match_plain_backward():
+    """BucketedGradReducer with direct-write parameters (ops.grad_out sinks, .grad adopted by autograd) must give
+    the same gradients as a plain backward, two steps in a row (second step: stale bucket contents)."""
+    import numpy as np
+    import torch
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in S.procedural_decoder_state(S.decoder_state_shapes(cfg)).items()}
+    dev = "cuda:0"
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    grads = {}
+    for mode in ("plain", "reducer"):
+        dec = RADMMMFlow(use_accent=True, **kw)
+        dec.load_state_dict(sd)
+        dec = dec.to(dev).train()
+        red = BucketedGradReducer(dec) if mode == "reducer" else None
+        for it in range(2):
+            b = {k: torch.from_numpy(v).to(dev) for k, v in S.synthetic_batch(3, 48, cfg, seed=7 + it, ragged=True).items()}
+            sl = SequenceLength(b["lengths"])
+            if red is not None:
+                red.prepare()
+            else:
+                dec.zero_grad(set_to_none=True)
+            out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+            crit(out, None, sl, 0)["loss_mel"][0].backward()
+            if red is not None:
+                red.finish()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in dec.named_parameters()}
+        if red is not None:
+            n_direct = sum(1 for n, p in dec.named_parameters() if red._direct[id(p)])
+            assert n_direct > 50
+            for n, p in dec.named_parameters():       # every .grad lives inside its bucket
+                assert p.grad.data_ptr() == red._views[id(p)].data_ptr(), n
+    for n in grads["plain"]:
+        assert torch.equal(grads["plain"][n], grads["reducer"][n]), n
