@@ -682,6 +682,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         Gh = Gl = None
         gQ = _empty(N, Wc, like=z_in)
         gQh, gQl = _halves(N, Wc, like=z_in)
+        x_prev = None
         for j in range(nl - 1, -1, -1):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
@@ -689,7 +690,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                       ptr(gQl), Wc, SG, stream()), "dact_mul")
             gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
                                                          sum_out=grad_out(res_p[3 * j + 2]))
-            x_t = transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
+            # H[j+1]'s transposed copy is still in the pool from layer j+1's in_layer weight gradient (made with
+            # the length mask, which only changes frames where gQ is exactly zero)
+            x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, NPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
             WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc)
@@ -704,7 +707,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                                             sum_out=grad_out(in_p[3 * j + 2]))
                 x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG, NPR)
+                x_prev = x_t if d % 2 == 0 else None
             else:
+                x_prev = None
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
             g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
