@@ -33,10 +33,12 @@ class FlatRAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         groups: "OrderedDict[str, List[torch.nn.Parameter]]" = OrderedDict()
+        self._order: List[torch.nn.Parameter] = []       # the caller's parameter order = the reference optimizer's indices
         for name, p in named_params:
             if p.requires_grad:
                 assert p.dtype == torch.float32 and p.is_cuda, "FlatRAdam: fp32 parameters on the GPU"
                 groups.setdefault(bucket_key(name), []).append(p)
+                self._order.append(p)
         self.buckets: List[Dict] = []
         red_flats = {b["key"]: b for b in reducer.buckets} if reducer is not None else {}
         for key, params in groups.items():
@@ -55,6 +57,12 @@ class FlatRAdam:
                 off += p.numel()
             self.buckets.append(dict(key=key, params=params, flat=flat, gflat=gflat, own_g=gflat is None,
                                      m=torch.zeros_like(flat), v=torch.zeros_like(flat)))
+        self._slot = {}                                    # id(param) -> (bucket, offset)
+        for b in self.buckets:
+            off = 0
+            for p in b["params"]:
+                self._slot[id(p)] = (b, off)
+                off += p.numel()
         dev = self.buckets[0]["flat"].device
         self._part = torch.empty(len(self.buckets), int(lib.radmmm_sumsq_scratch_floats()), device=dev)
         self._clip = torch.ones(1, device=dev)
@@ -114,30 +122,24 @@ class FlatRAdam:
 
     # -- reference-compatible state ---------------------------------------------------------------
     def state_dict(self):
-        state, idx = {}, 0
-        for b in self.buckets:
-            off = 0
-            for p in b["params"]:
-                n = p.numel()
-                state[idx] = {"step": self.step_count, "exp_avg": b["m"][off: off + n].view_as(p).clone(),
-                              "exp_avg_sq": b["v"][off: off + n].view_as(p).clone()}
-                off += n
-                idx += 1
+        state = {}
+        for idx, p in enumerate(self._order):
+            b, off = self._slot[id(p)]
+            n = p.numel()
+            state[idx] = {"step": self.step_count, "exp_avg": b["m"][off: off + n].view_as(p).clone(),
+                          "exp_avg_sq": b["v"][off: off + n].view_as(p).clone()}
         return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps,
-                                                  "weight_decay": self.weight_decay, "params": list(range(idx))}]}
+                                                  "weight_decay": self.weight_decay, "params": list(range(len(self._order)))}]}
 
     def load_state_dict(self, sd):
-        idx = 0
-        for b in self.buckets:
-            off = 0
-            for p in b["params"]:
-                n = p.numel()
-                st = sd["state"].get(idx)
-                if st is not None:
-                    b["m"][off: off + n].copy_(st["exp_avg"].reshape(-1))
-                    b["v"][off: off + n].copy_(st["exp_avg_sq"].reshape(-1))
-                    self.step_count = int(st["step"])
-                off += n
-                idx += 1
+        for idx, p in enumerate(self._order):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            b, off = self._slot[id(p)]
+            n = p.numel()
+            b["m"][off: off + n].copy_(st["exp_avg"].reshape(-1))
+            b["v"][off: off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(st["step"])
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
