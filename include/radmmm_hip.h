@@ -359,6 +359,22 @@ int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32
 int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens, void* wtpack,
                     float* P, float* dcbuf, int B, int T, int H, const float* gscale, radmmm_stream_t stream);
 
+/* Channel-mix matrix of the LUS invertible 1x1 conv (common.py:507-548, Invertible1x1ConvLUS.forward's
+ * W = P (L U) with L = tril(lower,-1) + diag(lower_diag), U = triu(upper,1) + diag(upper_diag), and
+ * log|det W| = sum log|upper_diag|) in one launch each way instead of ~16 small stock launches.
+ * P, lower, upper: row-major fp32 [c][c]; c <= 256.  fwd writes the whole zero-padded [ldw][ldw] matrix W
+ * with the c x c block at rows [0,c), columns [col_offset, col_offset+c) (what the flow step's first GEMM
+ * reads; an early exit is a column offset) and the scalar logdet (may be NULL).  bwd reads the same
+ * block of gW [ldw][ldw] and the device scalar g_logdet (may be NULL) and writes the full [c][c]
+ * g_lower (strictly lower, zeros elsewhere), g_upper (strictly upper) and g_upper_diag [c]. */
+int radmmm_lu_weight_fwd(const float* P, const float* lower, const float* lower_diag, const float* upper,
+                         const float* upper_diag, int c, float* W, int ldw, int col_offset, float* logdet,
+                         radmmm_stream_t stream);
+int radmmm_lu_weight_bwd(const float* P, const float* lower, const float* lower_diag, const float* upper,
+                         const float* upper_diag, int c, const float* gW, int ldw, int col_offset,
+                         const float* g_logdet, float* g_lower, float* g_upper, float* g_upper_diag,
+                         radmmm_stream_t stream);
+
 /* Masked InstanceNorm1d (+ ReLU) on channels-last rows (next-row f1, the text encoder's
  * nn.InstanceNorm1d(affine=True) applied per utterance, common.py:439-441,476-484): statistics over the
  * frames t < lens[b] of item b (biased variance, eps as torch), zeros at frames >= lens[b].

@@ -104,6 +104,8 @@ def _load() -> C.CDLL:
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
+        "radmmm_lu_weight_fwd": [p, p, p, p, p, i, p, i, i, p, p],
+        "radmmm_lu_weight_bwd": [p, p, p, p, p, i, p, i, i, p, p, p, p, p],
         "radmmm_instnorm_fwd": [p, i, p, p, p, i, p, p, p, i, i, i, f, i, p],
         "radmmm_instnorm_bwd": [p, i, p, i, p, i, p, p, p, p, i, p, p, p, i, i, i, i, p],
         "radmmm_pq_spline_inv": [p, i, p, i, p, i, i, i, i, p],

@@ -71,6 +71,13 @@ class Invertible1x1ConvLUS(nn.Module):
         Lm = torch.tril(self.lower, -1) + torch.diag(self.lower_diag)
         return self.p @ (Lm @ U)
 
+    def weight_and_log_det(self, ldw: int, col_offset: int):
+        """Zero-padded [ldw, ldw] channel-mix matrix reading input columns [col_offset, col_offset + c)
+        and log|det W|, one HIP launch each way (ops.LUWeightFn) -- what the training step uses;
+        `weight()` / `log_det()` are the stock-op restatement kept for inference-time inverses."""
+        from . import ops
+        return ops.LUWeightFn.apply(self.p, self.lower, self.lower_diag, self.upper, self.upper_diag, ldw, col_offset)
+
     def mean(self) -> Optional[torch.Tensor]:
         return None
 

@@ -40,12 +40,13 @@ class BucketedGradReducer:
                  process_group=None, direct: Optional[Callable[[str], bool]] = None):
         """direct(name) -> True for parameters whose backward node writes the gradient straight into the
         bucket (rad_mmm_amd.ops.grad_out): those get .grad = None before backward, so autograd adopts the
-        bucket view instead of launching an add per tensor; default = the decoders' WN parameters."""
+        bucket view instead of launching an add per tensor; default = the decoders' WN and 1x1-conv parameters
+        (a node that ignores the sink costs one copy in the hook, never a wrong result)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized()      # reduce even at world size 1 (RCCL smoke test)
         if direct is None:
-            direct = lambda name: ".affine_param_predictor." in name
+            direct = lambda name: ".affine_param_predictor." in name or ".invtbl_conv." in name
         groups: "OrderedDict[str, List]" = OrderedDict()
         for name, p in module.named_parameters():
             if p.requires_grad:

@@ -64,14 +64,24 @@ class FlowStep(nn.Module):
             b_eff = F.pad(-(W @ mean).squeeze(1), (0, ZLD - C))
         return W_eff.contiguous(), b_eff.contiguous()
 
+    def _zero_bias(self, like: torch.Tensor) -> torch.Tensor:
+        b = getattr(self, "_b0", None)
+        if b is None or b.device != like.device:
+            b = self._b0 = torch.zeros(ZLD, device=like.device, dtype=torch.float32)
+        return b
+
     def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
                    scale_box=None):
         conv = self.invtbl_conv
         if isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not bool(conv.initialized):
             conv.initialize(z_cl[:, col_offset:], seq_lens, T)
             print("initialized invertible conv")
-        W_eff, b_eff = self.effective_weight(col_offset)
-        log_det_W = conv.log_det()
+        if isinstance(conv, Invertible1x1ConvLUS):
+            W_eff, log_det_W = conv.weight_and_log_det(ZLD, col_offset)
+            b_eff = self._zero_bias(W_eff)
+        else:
+            W_eff, b_eff = self.effective_weight(col_offset)
+            log_det_W = conv.log_det()
         if self.use_spline:
             n_valid = int(seq_lens.lengths_host.sum())
             z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box)

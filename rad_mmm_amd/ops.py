@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad
+from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad, f32c
 
 ZLD = 160            # row pitch of every flow-variable matrix (n_mel*group padded, see decoders.py)
 
@@ -56,6 +56,36 @@ def grad_out(param: torch.Tensor) -> torch.Tensor:
     if t is not None and t.shape == param.shape and t.dtype == param.dtype:
         return t.view(t.shape)       # a fresh alias: AccumulateGrad only adopts a tensor nobody else references
     return torch.empty_like(param)
+
+
+class LUWeightFn(torch.autograd.Function):
+    """(W_eff [ldw, ldw], log|det W|) of the LUS invertible 1x1 conv (reference common.py:507-548): W = P (L U)
+    placed at columns [col_offset, col_offset + c) of a zero matrix; one launch each way (csrc/lu_weight.hip)."""
+
+    @staticmethod
+    def forward(ctx, p, lower, lower_diag, upper, upper_diag, ldw, col_offset):
+        c = upper_diag.shape[0]
+        p, lower_c, ld, upper_c, ud = f32c(p), f32c(lower), f32c(lower_diag), f32c(upper), f32c(upper_diag)
+        W = torch.empty(ldw, ldw, device=p.device, dtype=torch.float32)
+        logdet = torch.empty((), device=p.device, dtype=torch.float32)
+        check(lib.radmmm_lu_weight_fwd(ptr(p), ptr(lower_c), ptr(ld), ptr(upper_c), ptr(ud), c, ptr(W), ldw, col_offset,
+                                       ptr(logdet), stream()), "lu_weight_fwd")
+        ctx.save_for_backward(p, lower_c, ld, upper_c, ud)
+        ctx.params = (lower, upper, upper_diag)
+        ctx.dims = (c, ldw, col_offset)
+        return W, logdet
+
+    @staticmethod
+    def backward(ctx, gW, glogdet):
+        p, lower_c, ld, upper_c, ud = ctx.saved_tensors
+        lower, upper, upper_diag = ctx.params
+        c, ldw, col_offset = ctx.dims
+        gW = f32c(gW) if gW is not None else torch.zeros(ldw, ldw, device=p.device, dtype=torch.float32)
+        gl, gu, gd = grad_out(lower), grad_out(upper), grad_out(upper_diag)
+        check(lib.radmmm_lu_weight_bwd(ptr(p), ptr(lower_c), ptr(ld), ptr(upper_c), ptr(ud), c, ptr(gW), ldw, col_offset,
+                                       ptr(f32c(glogdet)) if glogdet is not None else None, ptr(gl), ptr(gu), ptr(gd),
+                                       stream()), "lu_weight_bwd")
+        return None, gl, None, gu, gd, None, None
 
 
 # ---------------------------------------------------------------------------------------
@@ -254,7 +284,7 @@ class AffineFlowStepFn(torch.autograd.Function):
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
         # invertible 1x1
-        g_b_eff = colsum(gz1, ZLD)
+        g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
         g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
         g_zin = _empty(N, ZLD, like=z_in)
         rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
@@ -735,7 +765,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                    T=T)
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
-        g_b_eff = colsum(gz1, ZLD)
+        g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
         g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
         g_zin = _empty(N, ZLD, like=z_in)
         rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)

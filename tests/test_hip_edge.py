@@ -189,3 +189,34 @@ def test_bucket_reducer_direct_gradients_match_plain_backward():
                 assert p.grad.data_ptr() == red._views[id(p)].data_ptr(), n
     for n in grads["plain"]:
         assert torch.equal(grads["plain"][n], grads["reducer"][n]), n
+
+
+@pytest.mark.parametrize("c,ldw,off", [(160, 160, 0), (154, 160, 6), (7, 12, 3)])
+def test_lu_weight_matches_oracle(c, ldw, off):
+    """ops.LUWeightFn (one launch each way) vs the oracle's stock-op W = P (L U), log|det|, and their
+    autograd gradients (reference common.py:507-548), incl. the column offset of an early exit."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(c)
+    Wr = torch.linalg.qr(torch.randn(c, c, generator=g))[0]
+    p, lower, upper = torch.linalg.lu(Wr)
+    prm = {"p": p, "lower": torch.tril(lower, -1) + torch.triu(torch.randn(c, c, generator=g)),   # junk above the
+           "lower_diag": torch.ones(c), "upper": torch.triu(upper, 1) + torch.tril(torch.randn(c, c, generator=g)),
+           "upper_diag": torch.diag(upper).clone()}                                                # diagonals is ignored
+    gW = torch.randn(ldw, ldw, generator=g)
+    gld = torch.randn((), generator=g)
+    ref = {k: v.clone().requires_grad_(k in ("lower", "upper", "upper_diag")) for k, v in prm.items()}
+    W_ref = O.lus_weight(ref, "")
+    ld_ref = torch.log(torch.abs(ref["upper_diag"])).sum()
+    ((W_ref * gW[:c, off:off + c]).sum() + ld_ref * gld).backward()
+    dev = {k: v.to(DEV).requires_grad_(k in ("lower", "upper", "upper_diag")) for k, v in prm.items()}
+    W, ld = ops.LUWeightFn.apply(dev["p"], dev["lower"], dev["lower_diag"], dev["upper"], dev["upper_diag"], ldw, off)
+    ((W * gW.to(DEV)).sum() + ld * gld.to(DEV)).backward()
+    W = W.detach().cpu()
+    assert rel_err(W[:c, off:off + c], W_ref.detach()) < 1e-5
+    blk = torch.zeros(ldw, ldw, dtype=torch.bool)
+    blk[:c, off:off + c] = True
+    assert torch.all(W[~blk] == 0)
+    assert abs(float(ld) - float(ld_ref)) < 1e-5 * max(1.0, abs(float(ld_ref)))
+    for k in ("lower", "upper", "upper_diag"):
+        assert rel_err(dev[k].grad.cpu(), ref[k].grad) < 1e-5, k
