@@ -51,7 +51,7 @@ struct LstmArgs {
   // backward
   const float* dy;              // [B*T][2H]
   const _Float16 *Wth, *Wtl;    // [2][NS][Hp/32][2][64][8] transposed slices, fragment-major (k' = gate*8 + unit-in-slice)
-  float* P;                     // [2 dirs][2 ping-pong][Bp/32][NS][32][Hp] partial recurrent gradients
+  float* P;                     // [2 dirs][2 ping-pong][Bp/32][Hp/8 consumer slices][NS producer slices][32][8] partial recurrent gradients
   float* dcbuf;                 // [2][Bp][H] carried cell gradient
   int Hp, NS;                   // Hp = H rounded up to 32, NS = ceil(H / 8)
   const float* gscale;          // device scalar: power-of-two scale applied to dG before the fp16 split
@@ -248,10 +248,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
   const int len = a.lens ? a.lens[bc] : a.T;
   float pv[MAXNS];
   {
-    const float* Pp = a.P + ((((long long)(d * 2 + ((s + 1) & 1)) * nbz + bz) * NS) * 32 + bl_) * Hp + uc;
-    const long long st = 32LL * Hp;
+    // consumer-major layout: the [32 x 8] blocks of all producer slices for this slice's 8 units are
+    // contiguous (1 KiB each), so every load of the workgroup is one fully used, coalesced request
+    const float* Pp = a.P + (((long long)(d * 2 + ((s + 1) & 1)) * nbz + bz) * (Hp >> 3) + j) * NS * 256 + tid;
 #pragma unroll
-    for (int jj = 0; jj < MAXNS; ++jj) pv[jj] = jj < NS ? Pp[jj * st] : 0.f;
+    for (int jj = 0; jj < MAXNS; ++jj) pv[jj] = jj < NS ? Pp[jj * 256] : 0.f;
   }
 #pragma unroll
   for (int w = MAXNS / 2; w >= 1; w >>= 1)
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
     ah[kb] = *reinterpret_cast<const f16x8*>(&sAh[fr][kb * 16 + fk]);
     al[kb] = *reinterpret_cast<const f16x8*>(&sAl[fr][kb * 16 + fk]);
   }
-  float* Po = a.P + (((long long)(d * 2 + (s & 1)) * nbz + bz) * NS + j) * 32 * Hp;
+  float* Po = a.P + ((long long)(d * 2 + (s & 1)) * nbz + bz) * NS * 32 * Hp + (long long)j * 256;
   const float inv = 1.f / gsc;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a, co
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        Po[(long long)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * Hp + tile * 32 + (lane & 31)] = acc[e] * inv;
+        Po[(long long)(tile * 4 + ((lane & 31) >> 3)) * NS * 256 + ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 8 +
+           (lane & 7)] = acc[e] * inv;                         // P[consumer slice][producer slice j][row][unit & 7]
     }
   }
 }
