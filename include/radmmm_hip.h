@@ -352,7 +352,9 @@ int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void
  *   which = 0 wsplit, 1 hsplit (fwd), 2 wtpack, 3 P, 4 dcbuf (bwd).
  * radmmm_lstm_bwd overwrites G with the pre-activation gradients dG; the input / weight / bias
  * gradients are plain GEMMs of dG (dW_ih = dG^T x, dx = dG W_ih, db = colsum dG, dW_hh[d] = dG_d^T h_prev).
- * gscale: device scalar, power of two bringing dG into fp16 range (e.g. 2^floor(log2(64 / max|dy|))). */
+ * gscale: device scalar, power of two bringing dG into fp16 range (e.g. 2^floor(log2(64 / max|dy|))).
+ * One launch per time step by default; RADMMM_LSTM_PERSISTENT=1 runs all steps in one launch with a grid
+ * barrier (counters in the tail of hsplit / dcbuf) when the grid fits one workgroup per CU. */
 int64_t radmmm_lstm_scratch_bytes(int B, int H, int which);
 int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32_t* lens, void* wsplit, void* hsplit,
                     int B, int T, int H, radmmm_stream_t stream);

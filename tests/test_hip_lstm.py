@@ -22,8 +22,11 @@ def _ref(lstm, x, lens):
 
 @pytest.mark.parametrize("B,T,I,H,lens", [(3, 7, 12, 8, None), (5, 19, 40, 21, [19, 7, 1, 12, 19]),
                                           (32, 50, 96, 524, None), (34, 23, 30, 70, [23] * 20 + [5] * 14)])
-def test_bilstm_matches_torch(B, T, I, H, lens):
+@pytest.mark.parametrize("persistent", ["0", "1"])
+def test_bilstm_matches_torch(B, T, I, H, lens, persistent, monkeypatch):
+    """persistent=1: the opt-in one-launch recurrence (grid barrier, sc1 exchange; csrc/lstm.hip)."""
     from rad_mmm_amd.lstm import bilstm
+    monkeypatch.setenv("RADMMM_LSTM_PERSISTENT", persistent)
     g = torch.Generator().manual_seed(B * 100 + H)
     lstm = nn.LSTM(I, H, num_layers=1, batch_first=True, bidirectional=True)
     with torch.no_grad():
