@@ -387,6 +387,18 @@ int radmmm_instnorm_bwd(const float* gy, int ldg, const float* x, int ldx, const
                         const float* mean, const float* rstd, float* gx, int ldgx, float* dw_part, float* db_part,
                         const int32_t* lens, int B, int T, int C, int relu, radmmm_stream_t stream);
 
+/* On-device data path (next-row f4): what the reference's CPU dataset workers compute per utterance.
+ * radmmm_betabinom_prior: data.py:90-102 (beta_binomial_prior_distribution) -> out [M][P] float64, row i the pmf
+ *   of BetaBinomial(P-1, scaling*(i+1), scaling*(M-i)).
+ * radmmm_prior_zoom_batch: BetaBinomialInterpolator.__call__ (data.py:76-88: scipy.ndimage.zoom order=1 of the
+ *   anchor prior at the rounded sizes, rows renormalised) for a whole batch, zero-padded as DataCollate does
+ *   (data.py:678-679,737-741).  items: DEVICE array [B][5] of int64 {anchor pointer (float64 [bh][bw]), bh, bw,
+ *   n_frames, n_tokens}; out [B][Tmax][Nmax] fp32, fully written.
+ * radmmm_energy_average: data.py:363-366 (+ :339-342 when scaled): mel [B][n_mel][T] -> out [B][T]. */
+int radmmm_betabinom_prior(int P, int M, double scaling, double* out, radmmm_stream_t stream);
+int radmmm_prior_zoom_batch(const int64_t* items, int B, float* out, int Tmax, int Nmax, radmmm_stream_t stream);
+int radmmm_energy_average(const float* mel, float* out, int B, int n_mel, int T, int scaled, radmmm_stream_t stream);
+
 /* Optimizer step on flat fp32 buffers (next-row f3): the reference's vendored RAdam (radam.py:63-142)
  * with the global-norm clip of configs/RADMMM_train_config.yaml:7-8 folded in as a device scalar.
  * step_size / use_denom (N_sma >= 5) come from the host's step count as radam.py:101-123. */

@@ -834,3 +834,70 @@ def attribute_regression_loss(x_hat: Tensor, x: Tensor, lens: Tensor) -> Tensor:
     """AttributeRegressionLoss (loss.py:233-250): masked mean squared error."""
     mask = lengths_to_mask(lens, x.shape[2])[:, None]
     return F.mse_loss(x_hat[mask], x[mask], reduction="sum") / mask.sum()
+
+
+# --------------------------------------------------------------------------
+# data path (SURVEY §8 f4): attention prior and energy average
+# --------------------------------------------------------------------------
+def beta_binomial_prior(phoneme_count: int, mel_count: int, scaling_factor: float = 0.05):
+    """data.py:90-102 (beta_binomial_prior_distribution): row i (1-based frame) is the pmf of
+    BetaBinomial(n = P-1, a = s*i, b = s*(M+1-i)) over the P tokens.  The reference calls
+    scipy.stats.betabinom (scipy 1.15, the image's pinned version); its published pmf is restated here:
+    pmf(k) = C(n, k) B(k + a, n - k + b) / B(a, b), evaluated in log space, float64 -> [M, P]."""
+    import numpy as np
+    from scipy.special import betaln, gammaln
+    P, M = int(phoneme_count), int(mel_count)
+    n = P - 1
+    k = np.arange(P, dtype=np.float64)[None, :]
+    i = np.arange(1, M + 1, dtype=np.float64)[:, None]
+    a, b = scaling_factor * i, scaling_factor * (M + 1 - i)
+    logc = gammaln(n + 1.0) - gammaln(k + 1.0) - gammaln(n - k + 1.0)
+    return np.exp(logc + betaln(k + a, n - k + b) - betaln(a, b))
+
+
+def prior_bank_shape(p_count: int, m_count: int, round_mel_len_to: int = 100, round_text_len_to: int = 20):
+    """data.py:72-79: sizes of the cached anchor prior; numpy's round = round-half-to-even, as Python's."""
+    rnd = lambda val, to: max(1, int(round((val + 1) / to))) * to
+    return rnd(p_count, round_text_len_to), rnd(m_count, round_mel_len_to)          # (bw, bh)
+
+
+def zoom_linear(x, out_rows: int, out_cols: int):
+    """scipy.ndimage.zoom(x, order=1, mode='nearest', grid_mode=False) as data.py:80 uses it, restated:
+    output index o samples the input at o * (n_in - 1) / (n_out - 1) (0 when n_out == 1), bilinear, float64."""
+    import numpy as np
+    def axis(n_in, n_out):
+        z = (n_in - 1) / (n_out - 1) if n_out > 1 else 1.0
+        c = np.arange(n_out, dtype=np.float64) * z
+        i0 = np.minimum(np.floor(c).astype(np.int64), n_in - 1)
+        f = c - i0
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        return i0, i1, f
+    r0, r1, fr = axis(x.shape[0], out_rows)
+    c0, c1, fc = axis(x.shape[1], out_cols)
+    top = x[r0][:, c0] * (1 - fc)[None, :] + x[r0][:, c1] * fc[None, :]
+    bot = x[r1][:, c0] * (1 - fc)[None, :] + x[r1][:, c1] * fc[None, :]
+    return top * (1 - fr)[:, None] + bot * fr[:, None]
+
+
+def interpolated_prior(p_count: int, m_count: int, scaling_factor: float = 0.05):
+    """BetaBinomialInterpolator.__call__ (data.py:76-88): anchor prior at the rounded sizes, bilinear zoom to
+    [m_count, p_count], rows renormalised.  float64."""
+    bw, bh = prior_bank_shape(p_count, m_count)
+    ret = zoom_linear(beta_binomial_prior(bw, bh, scaling_factor), m_count, p_count)
+    return ret / ret.sum(1, keepdims=True)
+
+
+def attention_prior_batch(in_lens, out_lens, scaling_factor: float = 0.05):
+    """The padded [B, max_frames, max_tokens] fp32 prior DataCollate builds (data.py:678-679,737-741)."""
+    import numpy as np
+    B = len(in_lens)
+    out = np.zeros((B, int(max(out_lens)), int(max(in_lens))), dtype=np.float32)
+    for b in range(B):
+        out[b, :int(out_lens[b]), :int(in_lens[b])] = interpolated_prior(int(in_lens[b]), int(out_lens[b]), scaling_factor)
+    return out
+
+
+def energy_average(mel, use_scaled_energy: bool = True):
+    """data.py:339-342,363-366: mean over the mel channels of [n_mel, T] (or [B, n_mel, T]), then (x + 20) / 20."""
+    e = mel.mean(-2)
+    return (e + 20.0) / 20.0 if use_scaled_energy else e

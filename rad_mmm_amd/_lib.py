@@ -104,6 +104,9 @@ def _load() -> C.CDLL:
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
+        "radmmm_betabinom_prior": [i, i, C.c_double, p, p],
+        "radmmm_prior_zoom_batch": [p, i, p, i, i, p],
+        "radmmm_energy_average": [p, p, i, i, i, i, p],
         "radmmm_lu_weight_fwd": [p, p, p, p, p, i, p, i, i, p, p],
         "radmmm_lu_weight_bwd": [p, p, p, p, p, i, p, i, i, p, p, p, p, p],
         "radmmm_instnorm_fwd": [p, i, p, p, p, i, p, p, p, i, i, i, f, i, p],

@@ -562,6 +562,37 @@ def main():
                 arrs[f"p.{k}.{i}"] = p.detach().clone()
         save("radam_tiny.npz", **t2n(arrs))
 
+    # ------------------------------------------------------------------ data path (f4): attention prior + energy
+    if want("prior"):
+        # data.py pulls in packages that take no part in this arithmetic (lmdb cache, pyin f0 extraction,
+        # praat augmentation, text cleaners); scipy.stats.betabinom / scipy.ndimage.zoom, which do, are the real ones
+        for name in ("lmdb", "parselmouth", "parselmouth.praat", "wave_transforms", "tts_text_processing",
+                     "tts_text_processing.text_processing"):
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+        sys.modules["librosa"].pyin = None
+        sys.modules["parselmouth.praat"].call = None
+        sys.modules["wave_transforms"].WaveAugmentations = None
+        sys.modules["tts_text_processing.text_processing"].TextProcessing = None
+        import data as ref_data
+        arrs = {}
+        pairs = [(7, 23), (1, 1), (2, 9), (39, 160), (61, 333), (150, 799), (12, 1000)]     # (n_tokens, n_frames)
+        interp = ref_data.BetaBinomialInterpolator()
+        for i, (p, m) in enumerate(pairs):
+            arrs[f"interp.{i}.pm"] = np.array([p, m])
+            arrs[f"interp.{i}.out"] = interp(p, m)
+        for i, (p, m, sc) in enumerate([(5, 9, 0.05), (20, 100, 0.05), (33, 47, 1.0), (1, 4, 0.05)]):
+            arrs[f"bank.{i}.pms"] = np.array([p, m, sc])
+            arrs[f"bank.{i}.out"] = ref_data.beta_binomial_prior_distribution(p, m, sc)
+        g = torch.Generator().manual_seed(5)
+        mel = torch.randn(80, 37, generator=g) * 2.0 - 5.0
+        arrs["energy.mel"] = mel
+        for scaled in (True, False):
+            ns = types.SimpleNamespace(use_scaled_energy=scaled)
+            ns.energy_avg_normalize = lambda x, ns=ns: ref_data.AudioDataset.energy_avg_normalize(ns, x)
+            arrs[f"energy.out.{int(scaled)}"] = ref_data.AudioDataset.get_energy_average(ns, mel)
+        save("prior.npz", **t2n(arrs))
+
 
 if __name__ == "__main__":
     main()
