@@ -683,7 +683,9 @@ int pick_h3w_mb(int M, int N, int slots) {
 int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   static const int slots = [] {
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
     return n > 0 ? n : 256;
   }();
   int mb = pick_h3w_mb(d.base.M, d.base.N, slots);
