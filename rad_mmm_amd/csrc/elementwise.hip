@@ -267,15 +267,23 @@ constexpr int CS_ROWS_PER_BLOCK = 64;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
     const float* __restrict__ X, int ldx, float* __restrict__ part, int rows, int cols,
     int row_weight, int T, const int* __restrict__ lens, int taps, int dil, int square) {
-  const int c = blockIdx.x * 1024 + threadIdx.x * 4;
+  // narrow inputs (cols < 1024: the 160-wide flow tensors) would leave most of the block idle with 64
+  // serial loads per thread: the spare threads become row lanes (thread = column group + ncg * row lane)
+  // whose partial sums are combined through LDS in a fixed order
+  __shared__ float4 sh[256];
+  const int span = min(cols - (int)blockIdx.x * 1024, 1024);
+  const int ncg = (span + 3) / 4, nrl = 256 / ncg;             // column groups of 4, row lanes
+  const int cg = threadIdx.x % ncg, rl = threadIdx.x / ncg;
+  const int c = blockIdx.x * 1024 + cg * 4;
   const int r0 = blockIdx.y * CS_ROWS_PER_BLOCK;
   int r1 = r0 + CS_ROWS_PER_BLOCK;
   if (r1 > rows) r1 = rows;
   const bool vec = (ldx % 4 == 0) && radmmm::aligned16(X) && c + 3 < cols;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (c < cols) {
-    for (int r = r0; r < r1; ++r) {
-      const float w = radmmm::colsum_row_weight(r, row_weight, T, lens, taps, dil);   // block-uniform
+  if (rl < nrl) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const float w = radmmm::colsum_row_weight(r, row_weight, T, lens, taps, dil);
       float4 v;
       if (vec) {
         v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
@@ -289,6 +297,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
       if (square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
       a0 = fmaf(w, v.x, a0); a1 = fmaf(w, v.y, a1); a2 = fmaf(w, v.z, a2); a3 = fmaf(w, v.w, a3);
     }
+  }
+  if (nrl > 1) {
+    sh[threadIdx.x] = make_float4(a0, a1, a2, a3);
+    __syncthreads();
+    if (rl == 0)
+      for (int k = 1; k < nrl; ++k) {
+        const float4 o = sh[k * ncg + cg];
+        a0 += o.x; a1 += o.y; a2 += o.z; a3 += o.w;
+      }
+  }
+  if (rl == 0) {
     float* o = part + (long long)blockIdx.y * cols + c;
     o[0] = a0;
     if (c + 1 < cols) o[1] = a1;
