@@ -60,3 +60,81 @@ def test_product_package_never_imports_oracle():
             assert "oracle" not in src.replace("# oracle", ""), fn
     bench = open(os.path.join(ROOT, "bench.py")).read() if os.path.exists(os.path.join(ROOT, "bench.py")) else ""
     assert "rad_mmm_amd" in bench or bench == ""
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HDR], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_structs_match_the_c_layout(tmp_path):
+    """sizeof / offsetof of every descriptor field as gcc lays the header's structs out == the ctypes mirrors."""
+    import subprocess
+    import rad_mmm_amd._lib as L
+    pairs = [("radmmm_rowgemm_desc", L.RowGemmDesc), ("radmmm_wgrad_desc", L.WgradDesc),
+             ("radmmm_rowgemm_h3_desc", L.RowGemmH3Desc)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HDR}"', "int main(void) {"]
+    for cname, mirror in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    r = subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.rsplit(" ", 1) for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, mirror in pairs:
+        assert int(got[cname]) == ctypes.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, f"{cname}.{fname}"
+
+
+def test_ctypes_signatures_have_the_declared_arity():
+    """Every function's ctypes argtypes list is as long as its parameter list in the header."""
+    import rad_mmm_amd._lib as L
+    src = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    protos = dict(re.findall(r"\b(radmmm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+    checked = 0
+    for name, params in protos.items():
+        fn = getattr(L.lib, name)
+        if fn.argtypes is None:
+            continue
+        params = params.strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(fn.argtypes) == n, (name, len(fn.argtypes), n)
+        checked += 1
+    assert checked >= 40
+
+
+def test_ctypes_signatures_have_the_declared_types():
+    """Per parameter: pointer / int / int64 / float / double class of the header == the ctypes argtype."""
+    import rad_mmm_amd._lib as L
+    src = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    protos = dict(re.findall(r"\b(radmmm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+
+    def c_class(p):
+        p = " ".join(p.split())
+        if "*" in p or "radmmm_stream_t" in p:
+            return "ptr"
+        for key, cls in (("int64_t", "i64"), ("double", "f64"), ("float", "f32"), ("int32_t", "i32"), ("int", "i32")):
+            if re.search(rf"\b{key}\b", p):
+                return cls
+        raise AssertionError(f"unclassified parameter {p!r}")
+
+    def py_class(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_longlong: "i64", ctypes.c_float: "f32",
+                ctypes.c_double: "f64"}[t]
+
+    for name, params in protos.items():
+        fn = getattr(L.lib, name)
+        if fn.argtypes is None or params.strip() in ("", "void"):
+            continue
+        want = [c_class(p) for p in params.split(",")]
+        got = [py_class(t) for t in fn.argtypes]
+        assert want == got, (name, want, got)
