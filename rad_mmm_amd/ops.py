@@ -593,6 +593,20 @@ def grad_scale(box, g: torch.Tensor) -> float:
     return box["S"]
 
 
+_SAT = 60000.0           # the split kernels clamp scale*x to +-60000 before the fp16 conversion
+
+
+def check_saturation(what: str, *his: torch.Tensor) -> None:
+    """RADMMM_CHECK_SATURATION=1 (debugging aid, one host sync per call): raise if a split gradient tensor hit the
+    fp16 clamp, i.e. a gradient element exceeded 2^12 x the first gradient's maximum this pass."""
+    if os.environ.get("RADMMM_CHECK_SATURATION", "0") != "1":
+        return
+    for hi in his:
+        if hi is not None and bool((hi.abs() >= _SAT).any()):
+            raise FloatingPointError(f"split-f16 gradient saturated in {what}: a gradient element exceeds 2^12 x the "
+                                     "first gradient's maximum of this backward pass")
+
+
 class AffineFlowStepH3Fn(torch.autograd.Function):
     """Same contract as AffineFlowStepFn; the WN convs run on radmmm_rowgemm_h3 (split-f16, fp32
     accumulate).  The 160-wide invertible 1x1, all weight gradients (contraction over frames) and
@@ -704,6 +718,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_end_w = grad_out(end_w)
         torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
         gOh, gOl = split_f16(gO, ZLD, SG, ZLD)
+        check_saturation("flow step: coupling gradient", gOh)
         WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD)                    # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
         rowgemm_h3(nprod=NPR, Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, acc_scale=inv_acc, C=gOUT, ldc=Wc, M=N, N=Wc,
@@ -753,6 +768,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                        acc_scale=inv_acc, C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens,
                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
                        ldch=Wc, ch_scale=SG)
+            check_saturation(f"flow step: WN layer {j}", gQh, gch, Gh if j == 0 else None)
         perm = (h, D, 0)
         gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
                                               sum_out=grad_out(start_b))

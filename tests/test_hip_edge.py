@@ -220,3 +220,34 @@ def test_lu_weight_matches_oracle(c, ldw, off):
     assert abs(float(ld) - float(ld_ref)) < 1e-5 * max(1.0, abs(float(ld_ref)))
     for k in ("lower", "upper", "upper_diag"):
         assert rel_err(dev[k].grad.cpu(), ref[k].grad) < 1e-5, k
+
+
+def test_saturation_check_flags_an_overflowing_gradient_scale(monkeypatch):
+    """RADMMM_CHECK_SATURATION=1: silent fp16 clamping of the split gradients becomes an error.  A normal step
+    passes; a gradient scale 2^30 too large must be reported."""
+    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=3, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    monkeypatch.setenv("RADMMM_CHECK_SATURATION", "1")
+
+    def step():
+        dec.zero_grad(set_to_none=True)
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+
+    step()                                                   # in range: no complaint
+    real = ops.grad_scale
+    monkeypatch.setattr(ops, "grad_scale", lambda box, g: real(box, g) * 2.0 ** 30)
+    with pytest.raises(FloatingPointError, match="saturated"):
+        step()
