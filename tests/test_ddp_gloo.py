@@ -108,4 +108,6 @@ def test_bucketed_reducer_world2_gloo():
 def test_bucket_key():
     from rad_mmm_amd.ddp import default_bucket_key
     assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.start.weight_v") == "flows.3"
+    assert default_bucket_key("decoder.flows.11.invtbl_conv.lower") == "decoder.flows.11"      # reducer around the whole step
+    assert default_bucket_key("f0_predictor.feat_pred.lstm.weight_hh_l0") == "misc"
     assert default_bucket_key("context_lstm.weight_ih_l0") == "misc"

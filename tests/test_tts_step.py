@@ -50,3 +50,83 @@ def test_training_step_matches_reference_components(tag, step, monkeypatch):
             ref = float(g[k])
             if ref > 1e-6:
                 assert abs(float(p.grad.norm()) - ref) < 2e-3 * ref, (n, float(p.grad.norm()), ref)
+
+
+def test_joint_step_with_attribute_predictors_through_the_bucket_reducer(monkeypatch):
+    """BASELINE configs[3]: decoder + f0 / energy / duration predictors in one step, every module's gradients in the
+    reducer's flat buckets (what the N-GPU run all-reduces).  The step's own pieces are pinned elsewhere
+    (test above, tests/test_attribute_predictors.py); here: the joint loss is the weighted sum of all parts, the
+    predictors receive gradients and do not leak any into the decoder / encoder (detached inputs,
+    tts_lightning_modules.py:300-369), and the bucketed gradients equal a plain backward bit for bit."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    import torch.nn.functional as F
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+
+    def build(with_predictors):
+        extra = {}
+        if with_predictors:
+            mk = lambda: ConvLSTMLinearDAP(n_speaker_dim=16, in_dim=32, out_dim=1, reduction_factor=4, n_backbone_layers=2,
+                                           n_hidden=32, kernel_size=3, p_dropout=0.0)
+            extra = dict(f0_predictor=mk(), f0_predictor_loss=AttributeRegressionLoss("f0_", 1.0),
+                         energy_predictor=mk(), energy_predictor_loss=AttributeRegressionLoss("energy_", 0.5),
+                         duration_predictor=mk(), duration_predictor_loss=AttributeRegressionLoss("duration_", 0.25))
+        torch.manual_seed(11)                      # predictors: torch init (no golden for them here), same in every build
+        m = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10, **extra)
+        names = [n for n in m.state_dict() if not n.startswith("decoder_criterion") and "_predictor" not in n]
+        proc = S.procedural_decoder_state({n: tuple(m.state_dict()[n].shape) for n in names})
+        m.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+        return m.to(dev).train()
+
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    batch["voiced_mask"] = (batch["f0"] > 0).float()
+    base = build(False)
+    loss0, _, _ = base.training_step(batch, global_step=0)
+    loss0.backward()
+
+    grads = {}
+    for mode in ("plain", "reducer"):
+        model = build(True)
+        red = BucketedGradReducer(model) if mode == "reducer" else None
+        for it in range(2):
+            if red is not None:
+                red.prepare()
+            else:
+                model.zero_grad(set_to_none=True)
+            loss, losses, _ = model.training_step(batch, global_step=0)
+            loss.backward()
+            if red is not None:
+                red.finish()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert {"f0_loss", "energy_loss", "duration_loss", "loss_mel"} <= set(losses)
+        total = sum(float(v) * w for v, w in losses.values())
+        assert abs(float(loss) - total) < 1e-5 * abs(total)
+        part = sum(float(losses[k][0]) * losses[k][1] for k in ("f0_loss", "energy_loss", "duration_loss"))
+        assert abs((float(loss) - part) - float(loss0)) < 1e-5 * abs(float(loss0))      # decoder part unchanged
+        for pred in ("f0_predictor", "energy_predictor", "duration_predictor"):
+            ps = [p for n, p in model.named_parameters() if n.startswith(pred + ".") and p.requires_grad]
+            assert ps and all(p.grad is not None for p in ps)
+            # (single tensors may be analytically zero: weight_g in front of a scale-invariant norm)
+            assert sum(int(float(p.grad.abs().max()) > 0) for p in ps) >= len(ps) // 2, pred
+        if red is not None:
+            keys = [b["key"] for b in red.buckets]
+            assert any(k.startswith("decoder.flows.") or k.startswith("flows.") for k in keys) and len(keys) >= 2, keys
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    assert p.grad.data_ptr() == red._views[id(p)].data_ptr(), n
+    # predictor inputs are detached: decoder / encoder gradients are the predictor-free step's, bit for bit
+    for n, p in base.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(grads["plain"][n], p.grad), n
+    for n in grads["plain"]:
+        assert torch.equal(grads["plain"][n], grads["reducer"][n]), n
