@@ -130,3 +130,64 @@ def test_joint_step_with_attribute_predictors_through_the_bucket_reducer(monkeyp
             assert torch.equal(grads["plain"][n], p.grad), n
     for n in grads["plain"]:
         assert torch.equal(grads["plain"][n], grads["reducer"][n]), n
+
+
+def test_joint_step_optimizer_update_matches_oracle(monkeypatch):
+    """Two full training steps of the joint model (decoder + encoder + attention + an f0 predictor): bucket
+    reducer -> global-norm clip 1.0 -> FlatRAdam on the reducer's flats, against the oracle's RAdam / clip applied
+    tensor by tensor to the same gradients (direct-write parameters sit first in their buckets: the per-tensor
+    mapping of the flat update is what this checks on the real parameter set)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.optim import FlatRAdam
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    import torch.nn.functional as F
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    torch.manual_seed(5)
+    pred = ConvLSTMLinearDAP(n_speaker_dim=16, in_dim=32, out_dim=1, reduction_factor=4, n_backbone_layers=2, n_hidden=32,
+                             kernel_size=3, p_dropout=0.0)
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10, f0_predictor=pred,
+                            f0_predictor_loss=AttributeRegressionLoss("f0_", 1.0))
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion") and "_predictor" not in n]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+    model = model.to(dev).train()
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    batch["voiced_mask"] = (batch["f0"] > 0).float()
+    red = BucketedGradReducer(model)
+    lr, wd = 1e-3, 1e-6
+    opt = FlatRAdam(model.named_parameters(), lr=lr, weight_decay=wd, reducer=red)
+    train = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    ref_p = {n: p.detach().clone() for n, p in train}
+    ref_m = {n: torch.zeros_like(p) for n, p in train}
+    ref_v = {n: torch.zeros_like(p) for n, p in train}
+    for k in range(2):
+        for n, p in train:                                   # both sides start the step from identical parameters
+            assert torch.equal(p.detach(), ref_p[n]) or k > 0
+        red.prepare()
+        loss, _, _ = model.training_step(batch, global_step=0)
+        loss.backward()
+        red.finish()
+        grads = {n: p.grad.detach().clone() for n, p in train}
+        with torch.no_grad():                                # oracle continues from the HIP parameters of this step
+            for n, p in train:
+                ref_p[n] = p.detach().clone()
+        total = opt.clip_grad_norm(1.0)
+        opt.step()
+        ref_total, clipped = O.clip_grad_norm([grads[n] for n, _ in train], 1.0)
+        assert abs(float(total) - float(ref_total)) < 1e-5 * float(ref_total)
+        for (n, p), gc in zip(train, clipped):
+            O.radam_step(ref_p[n], gc, ref_m[n], ref_v[n], k + 1, lr=lr, weight_decay=wd)
+            upd = (p.detach() - ref_p[n]).abs().max()
+            scale = lr                                        # an RAdam step moves every element by <= ~lr
+            assert float(upd) <= 2e-3 * scale + 1e-6 * float(p.detach().abs().max()), (k, n, float(upd))
