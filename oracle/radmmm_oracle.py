@@ -901,3 +901,33 @@ def energy_average(mel, use_scaled_energy: bool = True):
     """data.py:339-342,363-366: mean over the mel channels of [n_mel, T] (or [B, n_mel, T]), then (x + 20) / 20."""
     e = mel.mean(-2)
     return (e + 20.0) / 20.0 if use_scaled_energy else e
+
+
+# --------------------------------------------------------------------------
+# embedding regularisers and the voiced predictor's loss (caller row a17; configs/RADMMM_model_config.yaml:49-61)
+# --------------------------------------------------------------------------
+def variance_covariance_reg(embs: Tensor, gamma: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """VarianceCovarianceEmbeddingRegLoss.forward, loss.py:325-347 -> (variance loss, covariance loss)."""
+    n, d = embs.shape
+    std = torch.sqrt(embs.var(dim=0) + 1e-4)
+    std_loss = torch.relu(gamma - std).mean()
+    cen = embs - embs.mean(dim=0, keepdim=True)
+    cov = cen.t() @ cen / (n - 1)
+    mask = ~torch.eye(d, dtype=torch.bool)
+    return std_loss, (cov[mask] ** 2).sum() / d
+
+
+def min_cross_covariance(batch1: Tensor, batch2: Tensor, table1: Optional[Tensor], table2: Optional[Tensor]) -> Tensor:
+    """AttributeMinCrossCovarianceRegLoss.forward, loss.py:262-296."""
+    t1 = batch1 if table1 is None else table1
+    t2 = batch2 if table2 is None else table2
+    a = batch1 - t1.mean(dim=0, keepdim=True)
+    b = batch2 - t2.mean(dim=0, keepdim=True)
+    cross = a.t() @ b / (batch1.shape[0] - 1)
+    return (cross ** 2).sum() / (t1.shape[1] * t2.shape[1])
+
+
+def attribute_bce_loss(x_hat: Tensor, x: Tensor, mask: Tensor) -> Tensor:
+    """AttributeBCELoss.forward, loss.py:219-230: BCE-with-logits over the masked positions, sum / count."""
+    m = mask.bool()
+    return F.binary_cross_entropy_with_logits(x_hat[m], x[m], reduction="sum") / m.sum()

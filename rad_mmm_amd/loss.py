@@ -134,6 +134,73 @@ class RADMMMLoss(RADTTSLoss):
         self.cross_reg_loss_config = cross_reg_loss_config
 
 
+class AttributeBCELoss(nn.Module):
+    """loss.py:213-230 (the voiced predictor's loss): masked binary cross-entropy on logits, summed and divided by
+    the number of valid positions -> {prefix + 'loss': (value, weight)}.  A few KB of work: stock torch ops."""
+
+    def __init__(self, prefix: Optional[str] = None, weight=1.0):
+        super().__init__()
+        self.prefix, self.weight = prefix, weight
+
+    def forward(self, model_output, in_lens, out_lens, global_step, mask=None):
+        target, prediction = model_output["x"], model_output["x_hat"]
+        if mask is None:
+            mask = out_lens.mask.unsqueeze(1)
+        assert mask.dim() == target.dim()
+        mask = mask.bool()
+        loss = F.binary_cross_entropy_with_logits(prediction[mask], target[mask], reduction="sum") / mask.sum()
+        return {self.prefix + "loss": (loss, self.weight)}
+
+
+def _table(emb):
+    """an nn.Embedding (its weight) or a plain [n, d] tensor"""
+    return emb.weight if isinstance(emb, nn.Module) else emb
+
+
+class VarianceCovarianceEmbeddingRegLoss(nn.Module):
+    """loss.py:314-347 (VICReg-style regulariser of an embedding table [n, d]): hinge on the per-dimension
+    standard deviation, mean_d relu(gamma - sqrt(var_d + 1e-4)), and the squared off-diagonal entries of the
+    covariance matrix summed and divided by d."""
+
+    def __init__(self, name, loss_variance_weight, loss_covariance_weight, gamma=1):
+        super().__init__()
+        self.name = name
+        self.loss_variance_weight = float(loss_variance_weight)
+        self.loss_covariance_weight = float(loss_covariance_weight)
+        self.gamma = gamma
+
+    def forward(self, embeddings, lens=None):
+        embs = _table(embeddings)
+        n, d = embs.shape
+        std_loss = torch.relu(self.gamma - torch.sqrt(embs.var(dim=0) + 1e-4)).mean()
+        cen = embs - embs.mean(dim=0, keepdim=True)
+        cov = (cen.t() @ cen) / (n - 1)
+        off = cov - torch.diag(torch.diagonal(cov))
+        cov_loss = off.pow(2).sum() / d
+        return {f"loss_{self.name}_variance": (std_loss, self.loss_variance_weight),
+                f"loss_{self.name}_covariance": (cov_loss, self.loss_covariance_weight)}
+
+
+class AttributeMinCrossCovarianceRegLoss(nn.Module):
+    """loss.py:252-296: the batch's two attribute vectors [B, d1], [B, d2], each centred on the mean of ITS
+    embedding table (or of the batch when no table is given); mean squared entry of their [d1, d2]
+    cross-covariance (over B - 1)."""
+
+    def __init__(self, attr_name1, attr_name2, loss_cross_covariance_weight, gamma=1):
+        super().__init__()
+        self.attr_name1, self.attr_name2 = attr_name1, attr_name2
+        self.loss_cross_covariance_weight = float(loss_cross_covariance_weight)
+
+    def forward(self, batch_attr1, batch_attr2, attr1_embeddings, attr2_embeddings):
+        t1 = _table(attr1_embeddings) if attr1_embeddings is not None else batch_attr1
+        t2 = _table(attr2_embeddings) if attr2_embeddings is not None else batch_attr2
+        a = batch_attr1 - t1.mean(dim=0, keepdim=True)
+        b = batch_attr2 - t2.mean(dim=0, keepdim=True)
+        cross = (a.t() @ b) / (batch_attr1.shape[0] - 1)
+        loss = cross.pow(2).sum() / (t1.shape[1] * t2.shape[1])
+        return {f"loss_{self.attr_name1}-{self.attr_name2}_cross_covariance": (loss, self.loss_cross_covariance_weight)}
+
+
 def total_loss(loss_dict):
     """sum of value*weight (tts_lightning_modules.py:746-750)."""
     return sum(v * w for v, w in loss_dict.values())

@@ -25,7 +25,8 @@ class TTSTrainingStep(nn.Module):
                  use_speaker_emb_for_alignment=False, binarization_start_iter=20000, f0_predictor=None,
                  f0_predictor_loss=None, energy_predictor=None, energy_predictor_loss=None, voiced_predictor=None,
                  voiced_predictor_loss=None, duration_predictor=None, duration_predictor_loss=None,
-                 f0_loss_voiced_only=True):
+                 f0_loss_voiced_only=True, speaker_embed_regularization_loss=None, accent_embed_regularization_loss=None,
+                 speaker_accent_cross_regularization_loss=None):
         super().__init__()
         self.text_embeddings = nn.Embedding(n_text_tokens, n_text_dim)
         self.text_encoder = text_encoder
@@ -49,6 +50,11 @@ class TTSTrainingStep(nn.Module):
         self.energy_predictor, self.energy_predictor_loss = energy_predictor, energy_predictor_loss
         self.voiced_predictor, self.voiced_predictor_loss = voiced_predictor, voiced_predictor_loss
         self.duration_predictor, self.duration_predictor_loss = duration_predictor, duration_predictor_loss
+        # embedding regularisers (tts_lightning_modules.py:187-201; configs/RADMMM_model_config.yaml:49-61)
+        self.speaker_embed_regularization_loss = speaker_embed_regularization_loss
+        self.accent_embed_regularization_loss = accent_embed_regularization_loss
+        self.speaker_accent_cross_regularization_loss = speaker_accent_cross_regularization_loss
+        self.binarize = False                                    # validation uses the flag training last set (:644-646)
 
     # ---- tts_lightning_modules.py:543-545, 246-268 ---------------------------------------------
     @staticmethod
@@ -92,7 +98,7 @@ class TTSTrainingStep(nn.Module):
         """batch keys as data.py:756-788 (the ones this step reads): mel, speaker_ids, accent_ids, text,
         input_lengths, output_lengths, attn_prior, f0, energy_avg (+ voiced_mask, speaker_f0_mean/std when
         the attribute predictors are attached).  Returns (loss, {name: (value, weight)}, outputs)."""
-        binarize = global_step >= self.binarization_start_iter
+        binarize = self.binarize = global_step >= self.binarization_start_iter
         in_lens = SequenceLength(batch["input_lengths"])
         out_lens = SequenceLength(batch["output_lengths"])
         mel = self.mel_scale(batch["mel"])
@@ -126,6 +132,64 @@ class TTSTrainingStep(nn.Module):
         if self.duration_predictor is not None:
             o = self.duration_predictor(attn.sum(2).detach(), txt_enc.detach(), spk_vecs.detach(), in_lens, accent_emb=acc_d)
             losses.update(self.duration_predictor_loss(o, None, None, global_step, in_lens.mask.unsqueeze(1)))
+        losses.update(self._embedding_regularisers(spk_vecs, accent_vecs))
+        loss = None
+        for v, w in losses.values():
+            loss = v * w if loss is None else loss + v * w
+        return loss, losses, outputs
+
+    def _embedding_regularisers(self, spk_vecs, accent_vecs):
+        """tts_lightning_modules.py:729-745 (and :837-853 in validation)"""
+        out = {}
+        if self.speaker_embed_regularization_loss is not None:
+            out.update(self.speaker_embed_regularization_loss(self.speaker_embeddings))
+        if self.accent_embed_regularization_loss is not None:
+            out.update(self.accent_embed_regularization_loss(self.accent_embeddings))
+        if self.speaker_accent_cross_regularization_loss is not None:
+            out.update(self.speaker_accent_cross_regularization_loss(spk_vecs, accent_vecs, self.speaker_embeddings,
+                                                                     self.accent_embeddings))
+        return out
+
+    @torch.no_grad()
+    def validation_step(self, batch: Dict[str, torch.Tensor], global_step: int = 0
+                        ) -> Tuple[torch.Tensor, Dict[str, Tuple[torch.Tensor, float]], Dict[str, torch.Tensor]]:
+        """tts_lightning_modules.py:752-860: the same pass without gradients; the decoder criterion is evaluated
+        at step 100000 (all loss terms on), alignments are binarized when training last was (`self.binarize`),
+        and the predictors see the un-detached context.  `global_step` only reaches the predictor losses."""
+        in_lens = SequenceLength(batch["input_lengths"])
+        out_lens = SequenceLength(batch["output_lengths"])
+        mel = self.mel_scale(batch["mel"])
+        spk_vecs = self.encode_speaker(batch["speaker_ids"])
+        accent_vecs = self.encode_accent(batch["accent_ids"]) if self.use_accent else None
+        txt_enc, txt_emb = self.encode_text(batch["text"], in_lens.lengths,
+                                            accent_vecs if self.use_accent_emb_for_encoder else None)
+        attn, attn_soft, _, attn_logprob = self.compute_attention(
+            mel, txt_emb, spk_vecs, accent_vecs, out_lens.lengths, in_lens.lengths, batch["attn_prior"], self.binarize)
+        context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
+        f0, energy_avg = batch.get("f0"), batch.get("energy_avg")
+        outputs = self.decoder(mel, spk_vecs, context, out_lens, f0=f0, energy_avg=energy_avg, accent_vecs=accent_vecs)
+        outputs.update(attn=attn, attn_soft=attn_soft, attn_logprob=attn_logprob, context=context, spk_vecs=spk_vecs,
+                       accent_vecs=accent_vecs, txt_enc=txt_enc)
+        losses = dict(self.decoder_criterion(outputs, in_lens, out_lens, 100000))
+        if self.f0_predictor is not None:
+            o = self.f0_predictor(f0.unsqueeze(1), context, spk_vecs, out_lens, batch.get("speaker_f0_mean"),
+                                  batch.get("speaker_f0_std"), accent_vecs)
+            m = batch["voiced_mask"].unsqueeze(1) if self.f0_loss_voiced_only else None
+            losses.update(self.f0_predictor_loss(o, in_lens, out_lens, global_step, mask=m))
+            outputs["f0_outputs"] = o
+        if self.energy_predictor is not None:
+            o = self.energy_predictor(energy_avg.unsqueeze(1), context, spk_vecs, out_lens, accent_emb=accent_vecs)
+            losses.update(self.energy_predictor_loss(o, in_lens, out_lens, global_step))
+            outputs["energy_outputs"] = o
+        if self.voiced_predictor is not None:
+            o = self.voiced_predictor(batch["voiced_mask"].unsqueeze(1), context, spk_vecs, out_lens, accent_emb=accent_vecs)
+            losses.update(self.voiced_predictor_loss(o, in_lens, out_lens, global_step))
+            outputs["voiced_outputs"] = o
+        if self.duration_predictor is not None:
+            o = self.duration_predictor(attn.sum(2), txt_enc, spk_vecs, in_lens, accent_emb=accent_vecs)
+            losses.update(self.duration_predictor_loss(o, None, None, global_step, in_lens.mask.unsqueeze(1)))
+            outputs["duration_outputs"] = o
+        losses.update(self._embedding_regularisers(spk_vecs, accent_vecs))
         loss = None
         for v, w in losses.values():
             loss = v * w if loss is None else loss + v * w

@@ -593,6 +593,33 @@ def main():
             arrs[f"energy.out.{int(scaled)}"] = ref_data.AudioDataset.get_energy_average(ns, mel)
         save("prior.npz", **t2n(arrs))
 
+    # ------------------------------------------------------------------ embedding regularisers + BCE loss (caller, a17)
+    if want("regloss"):
+        import loss as ref_loss
+        import common as ref_common
+        gen = torch.Generator().manual_seed(91)
+        spk = torch.nn.Embedding(7, 16)
+        acc = torch.nn.Embedding(3, 8)
+        with torch.no_grad():
+            spk.weight.copy_(torch.randn(7, 16, generator=gen) * 0.7 + 0.1)
+            acc.weight.copy_(torch.randn(3, 8, generator=gen) * 1.3)
+        sid = torch.tensor([0, 3, 3, 6, 1])
+        aid = torch.tensor([2, 0, 1, 1, 2])
+        arrs = {"spk": spk.weight, "acc": acc.weight, "sid": sid, "aid": aid}
+        vc = ref_loss.VarianceCovarianceEmbeddingRegLoss("speaker", 0.3, 0.7, gamma=1.0)(spk)
+        arrs["vc.variance"], arrs["vc.covariance"] = vc["loss_speaker_variance"][0], vc["loss_speaker_covariance"][0]
+        vt = ref_loss.VarianceCovarianceEmbeddingRegLoss("accent", 1.0, 1.0, gamma=2.0)(acc)    # (modules only: a tensor raises)
+        arrs["vt.variance"], arrs["vt.covariance"] = vt["loss_accent_variance"][0], vt["loss_accent_covariance"][0]
+        cc = ref_loss.AttributeMinCrossCovarianceRegLoss("speaker", "accent", 1.0)
+        arrs["cc.tables"] = cc(spk(sid), acc(aid), spk, acc)["loss_speaker-accent_cross_covariance"][0]
+        arrs["cc.batch"] = cc(spk(sid), acc(aid), None, None)["loss_speaker-accent_cross_covariance"][0]
+        x = (torch.rand(3, 1, 11, generator=gen) > 0.5).float()
+        x_hat = torch.randn(3, 1, 11, generator=gen) * 2
+        lens = ref_common.SequenceLength(torch.tensor([11, 4, 7]))
+        arrs["bce.x"], arrs["bce.x_hat"], arrs["bce.lens"] = x, x_hat, lens.lengths
+        arrs["bce.loss"] = ref_loss.AttributeBCELoss("vpred_", 1.0)({"x": x, "x_hat": x_hat}, None, lens, 0)["vpred_loss"][0]
+        save("regloss.npz", **t2n(arrs))
+
 
 if __name__ == "__main__":
     main()

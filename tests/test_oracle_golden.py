@@ -266,3 +266,21 @@ def test_full_decoder_procedural(golden, tag, n_flows, n_splines):
         assert np.abs(p[n].grad.numpy() - gr).max() < 2e-4 * np.abs(gr).max() + 1e-8, n
     for n, gr in sub(g, "gradslice.").items():
         assert np.abs(p[n].grad[:4, :8].numpy() - gr).max() < 2e-4 * np.abs(gr).max() + 1e-8, n
+
+
+def test_regularisation_and_bce_losses_match_reference(golden):
+    """Embedding regularisers (configs/RADMMM_model_config.yaml:49-61) and the voiced predictor's BCE loss:
+    oracle restatement against values captured from the reference's loss.py (make_golden.py --only regloss)."""
+    g = golden("regloss.npz")
+    spk, acc = torch.from_numpy(g["spk"]), torch.from_numpy(g["acc"])
+    sid, aid = torch.from_numpy(g["sid"]), torch.from_numpy(g["aid"])
+    v, c = O.variance_covariance_reg(spk, 1.0)
+    assert abs(float(v) - float(g["vc.variance"])) < 1e-6 and abs(float(c) - float(g["vc.covariance"])) < 1e-6 * float(g["vc.covariance"])
+    v, c = O.variance_covariance_reg(acc, 2.0)
+    assert abs(float(v) - float(g["vt.variance"])) < 1e-6 and abs(float(c) - float(g["vt.covariance"])) < 1e-6 * float(g["vt.covariance"])
+    assert abs(float(O.min_cross_covariance(spk[sid], acc[aid], spk, acc)) - float(g["cc.tables"])) < 1e-6 * float(g["cc.tables"])
+    assert abs(float(O.min_cross_covariance(spk[sid], acc[aid], None, None)) - float(g["cc.batch"])) < 1e-6 * float(g["cc.batch"])
+    lens = torch.from_numpy(g["bce.lens"])
+    mask = (torch.arange(11)[None, :] < lens[:, None]).unsqueeze(1)
+    got = O.attribute_bce_loss(torch.from_numpy(g["bce.x_hat"]), torch.from_numpy(g["bce.x"]), mask)
+    assert abs(float(got) - float(g["bce.loss"])) < 1e-6 * float(g["bce.loss"])

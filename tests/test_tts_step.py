@@ -191,3 +191,67 @@ def test_joint_step_optimizer_update_matches_oracle(monkeypatch):
             upd = (p.detach() - ref_p[n]).abs().max()
             scale = lr                                        # an RAdam step moves every element by <= ~lr
             assert float(upd) <= 2e-3 * scale + 1e-6 * float(p.detach().abs().max()), (k, n, float(upd))
+
+
+def test_regularisation_and_bce_losses_match_reference_values():
+    """rad_mmm_amd.loss.{VarianceCovarianceEmbeddingRegLoss, AttributeMinCrossCovarianceRegLoss, AttributeBCELoss}
+    (configs/RADMMM_model_config.yaml:49-61, loss.py:213-347) against values captured from the reference."""
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd import loss as L
+    g = np.load(os.path.join(HERE, "golden", "regloss.npz"))
+    dev = "cuda:0"
+    spk, acc = torch.nn.Embedding(7, 16).to(dev), torch.nn.Embedding(3, 8).to(dev)
+    with torch.no_grad():
+        spk.weight.copy_(torch.from_numpy(g["spk"]))
+        acc.weight.copy_(torch.from_numpy(g["acc"]))
+    sid, aid = torch.from_numpy(g["sid"]).to(dev), torch.from_numpy(g["aid"]).to(dev)
+    close = lambda a, ref: abs(float(a) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-7
+    d = L.VarianceCovarianceEmbeddingRegLoss("speaker", 0.3, 0.7, gamma=1.0)(spk)
+    assert d["loss_speaker_variance"][1] == 0.3 and d["loss_speaker_covariance"][1] == 0.7
+    assert close(d["loss_speaker_variance"][0], g["vc.variance"]) and close(d["loss_speaker_covariance"][0], g["vc.covariance"])
+    d = L.VarianceCovarianceEmbeddingRegLoss("accent", 1.0, 1.0, gamma=2.0)(acc)
+    assert close(d["loss_accent_variance"][0], g["vt.variance"]) and close(d["loss_accent_covariance"][0], g["vt.covariance"])
+    cc = L.AttributeMinCrossCovarianceRegLoss("speaker", "accent", 1.0)
+    assert close(cc(spk(sid), acc(aid), spk, acc)["loss_speaker-accent_cross_covariance"][0], g["cc.tables"])
+    assert close(cc(spk(sid), acc(aid), None, None)["loss_speaker-accent_cross_covariance"][0], g["cc.batch"])
+    lens = SequenceLength(torch.from_numpy(g["bce.lens"]).to(dev))
+    out = {"x": torch.from_numpy(g["bce.x"]).to(dev), "x_hat": torch.from_numpy(g["bce.x_hat"]).to(dev)}
+    assert close(L.AttributeBCELoss("vpred_", 1.0)(out, None, lens, 0)["vpred_loss"][0], g["bce.loss"])
+
+
+def test_validation_step_equals_the_training_pass_without_gradients(monkeypatch):
+    """validation_step (tts_lightning_modules.py:752-860) = the training pass with the criterion at step 100000,
+    no gradients, plus the embedding regularisers of the model config."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd import loss as L
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    import torch.nn.functional as F
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), L.RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10,
+                            speaker_embed_regularization_loss=L.VarianceCovarianceEmbeddingRegLoss("speaker", 0.0, 0.0, 1.0),
+                            speaker_accent_cross_regularization_loss=L.AttributeMinCrossCovarianceRegLoss("speaker", "accent", 1.0))
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion")]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+    model = model.to(dev).train()
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    loss_t, losses_t, _ = model.training_step(batch, global_step=100000)
+    assert model.binarize and {"loss_speaker_variance", "loss_speaker_covariance", "loss_speaker-accent_cross_covariance"} <= set(losses_t)
+    # the golden "hard" case (step 10) has the same terms switched on: its decoder losses must reappear here
+    for k in losses_t:
+        if f"hard.{k}" in g.files:
+            assert abs(float(losses_t[k][0]) - float(g[f"hard.{k}"])) <= 1e-4 * max(abs(float(g[f"hard.{k}"])), 1e-3), k
+    model.eval()
+    loss_v, losses_v, out_v = model.validation_step(batch)
+    assert not loss_v.requires_grad and set(losses_v) == set(losses_t) and "txt_enc" in out_v
+    for k in losses_t:
+        assert abs(float(losses_v[k][0]) - float(losses_t[k][0])) <= 1e-5 * max(abs(float(losses_t[k][0])), 1e-3), k
+        assert losses_v[k][1] == losses_t[k][1]
+    assert abs(float(loss_v) - float(loss_t)) <= 1e-5 * abs(float(loss_t))
