@@ -87,3 +87,59 @@ def test_flat_radam_with_bucket_reducer_shares_gradient_flats():
                 O.radam_step(p.data, p.grad, m, v, k + 1, lr=1e-2)
     for p, q in zip(mod.parameters(), ref.parameters()):
         assert rel_err(p.detach().cpu(), q.detach().cpu()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_continues_bit_exactly():
+    """Checkpoint / resume (Lightning ModelCheckpoint saves module + optimizer state_dicts): two
+    steps, save both, one more step  ==  fresh module + optimizer, load both, the same third step."""
+    import io
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.optim import FlatRAdam
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd0 = {k: torch.from_numpy(np.asarray(v)) for k, v in S.procedural_decoder_state(S.decoder_state_shapes(cfg)).items()}
+    dev = "cuda:0"
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in S.synthetic_batch(3, 48, cfg, seed=20 + i, ragged=True).items()}
+               for i in range(3)]
+
+    def make(state=None, opt_state=None):
+        dec = RADMMMFlow(use_accent=True, **kw)
+        dec.load_state_dict(state if state is not None else sd0)
+        dec = dec.to(dev).train()
+        red = BucketedGradReducer(dec)
+        opt = FlatRAdam(dec.named_parameters(), lr=1e-3, weight_decay=1e-6, reducer=red)
+        if opt_state is not None:
+            opt.load_state_dict(opt_state)
+        return dec, red, opt
+
+    def step(dec, red, opt, b):
+        sl = SequenceLength(b["lengths"])
+        red.prepare()
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+        red.finish()
+        opt.clip_grad_norm(1.0)
+        opt.step()
+
+    dec, red, opt = make()
+    step(dec, red, opt, batches[0])
+    step(dec, red, opt, batches[1])
+    buf = io.BytesIO()
+    torch.save({"model": dec.state_dict(), "optimizer": opt.state_dict()}, buf)       # through serialisation, as a checkpoint
+    step(dec, red, opt, batches[2])
+    want = {n: p.detach().clone() for n, p in dec.named_parameters()}
+
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu")
+    assert ck["optimizer"]["state"][0]["step"] == 2
+    dec2, red2, opt2 = make(ck["model"], ck["optimizer"])
+    step(dec2, red2, opt2, batches[2])
+    for n, p in dec2.named_parameters():
+        assert torch.equal(p.detach(), want[n]), n
