@@ -536,19 +536,29 @@ _ts_pool = {}
 
 def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None, sum_out=None):
     """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
-    Buffers come from a small zero-initialised pool keyed by shape and role: the pads are never
-    written, the data and the gaps are rewritten on every call (single stream => reuse is ordered).
+    Buffers come from a small zero-initialised pool keyed by role: the pads are never written, the data
+    and the gaps are rewritten on every call (single stream => reuse is ordered).
     colsum = (row_weight, lens, taps, dil): also return the weighted column sums of x (the bias
     gradient) computed in the same pass -> (copy tuple, sums [C])."""
     Tp = T + _TS_FRONT
     Kt = round_up(B * Tp, 32)                 # contracted columns [FRONT, FRONT + Kt)
     ldk = Kt + 2 * _TS_FRONT
-    key = (x.device, C, Kt, role, need_odd)
-    bufs = _ts_pool.get(key)
-    if bufs is None:
+    # one set of flat buffers per (role, C): batches of a real run differ in B and T, so the [C, ldk] views are cut
+    # from storage sized for the largest shape seen, and whenever the shape changes the used region is cleared
+    # (the kernel rewrites data and gaps only; front, tail and the round-up columns must read as zeros)
+    key = (x.device, C, role, need_odd)
+    ent = _ts_pool.get(key)
+    need = C * ldk
+    if ent is None or ent["cap"] < need:
         n = 4 if need_odd else 2
-        bufs = [torch.zeros(C, ldk, device=x.device, dtype=torch.float16) for _ in range(n)]
-        _ts_pool[key] = bufs
+        ent = {"flat": [torch.zeros(need, device=x.device, dtype=torch.float16) for _ in range(n)], "cap": need,
+               "shape": (B, Tp)}
+        _ts_pool[key] = ent
+    elif ent["shape"] != (B, Tp):
+        for f in ent["flat"]:
+            f[:need].zero_()
+        ent["shape"] = (B, Tp)
+    bufs = [f[:need].view(C, ldk) for f in ent["flat"]]
     oh, ol = bufs[0], bufs[1]
     o1h, o1l = (bufs[2], bufs[3]) if need_odd else (None, None)
     if colsum is None:

@@ -251,3 +251,39 @@ def test_saturation_check_flags_an_overflowing_gradient_scale(monkeypatch):
     monkeypatch.setattr(ops, "grad_scale", lambda box, g: real(box, g) * 2.0 ** 30)
     with pytest.raises(FloatingPointError, match="saturated"):
         step()
+
+
+def test_batch_shape_changes_between_steps():
+    """Real batches differ in size and length from step to step.  The pooled transposed operand buffers of the
+    weight-gradient GEMMs are reused across steps: a step after a DIFFERENT shape (here one with the same padded
+    contraction length but a shorter real extent, the case where stale columns would be contracted) must give
+    exactly the gradients of the same step run from a clean pool."""
+    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    shapes = [(3, 96), (2, 138), (3, 96), (1, 40), (2, 138)]          # (3, 96) and (2, 138): both pad to 192 columns
+
+    def grads(B, Tn, seed):
+        # full-length batches for the 192-column shape: every column of the buffers then holds data
+        b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(B, Tn, cfg, seed=seed, ragged=(B != 3)).items()}
+        sl = SequenceLength(b["lengths"])
+        dec.zero_grad(set_to_none=True)
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+        return {n: p.grad.detach().clone() for n, p in dec.named_parameters()}
+
+    seq = [grads(B, Tn, 50 + i) for i, (B, Tn) in enumerate(shapes)]
+    for i, (B, Tn) in enumerate(shapes):
+        ops._ts_pool.clear()
+        ref = grads(B, Tn, 50 + i)
+        for n in ref:
+            assert torch.equal(seq[i][n], ref[n]), (i, (B, Tn), n)
