@@ -52,7 +52,9 @@ GRAD_SINKS = {}          # parameter data_ptr -> destination view (registered pe
 
 
 def grad_out(param: torch.Tensor) -> torch.Tensor:
-    t = GRAD_SINKS.get(param.data_ptr())
+    # one-shot: a second gradient for the same parameter before the reducer re-arms (a parameter used by two
+    # nodes, a second backward without prepare()) gets its own tensor and is ADDED by autograd, never overwrites
+    t = GRAD_SINKS.pop(param.data_ptr(), None)
     if t is not None and t.shape == param.shape and t.dtype == param.dtype:
         return t.view(t.shape)       # a fresh alias: AccumulateGrad only adopts a tensor nobody else references
     return torch.empty_like(param)

@@ -287,3 +287,42 @@ def test_batch_shape_changes_between_steps():
         ref = grads(B, Tn, 50 + i)
         for n in ref:
             assert torch.equal(seq[i][n], ref[n]), (i, (B, Tn), n)
+
+
+def test_second_backward_without_rearming_accumulates():
+    """The reducer's direct-write sinks are one-shot: backward twice between prepare() and finish() (gradient
+    accumulation) must ADD the second gradient, not overwrite the first."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    bs = [{k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=70 + i, ragged=True).items()}
+          for i in range(2)]
+
+    def backward(b):
+        sl = SequenceLength(b["lengths"])
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+
+    single = []
+    for b in bs:
+        dec.zero_grad(set_to_none=True)
+        backward(b)
+        single.append({n: p.grad.detach().clone() for n, p in dec.named_parameters()})
+    red = BucketedGradReducer(dec)
+    red.prepare()
+    backward(bs[0])
+    backward(bs[1])
+    red.finish()
+    for n, p in dec.named_parameters():
+        want = (single[0][n] + single[1][n]).cpu()
+        assert rel_err(p.grad.cpu(), want) < 1e-6, n
