@@ -85,6 +85,10 @@ class BucketedGradReducer:
                 view.copy_(param.grad)               # the node did not use the sink (or autograd cloned): one copy
                 param.grad = view
             bucket["pending"] -= 1
+            if bucket["pending"] < 0 and self.active:
+                raise RuntimeError("BucketedGradReducer: a second backward between prepare() and finish() would add to "
+                                   "gradients that are already being all-reduced; accumulate locally without a process "
+                                   "group or call prepare()/finish() around every backward")
             if bucket["pending"] == 0 and self.active:
                 # RCCL stream waits for the kernels already queued on the compute stream, then
                 # runs concurrently with the rest of backward
