@@ -166,6 +166,8 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
         return None
     if not t.is_cuda:
         raise RadmmmError("rad_mmm_amd ops need GPU tensors (there is no CPU path)")
+    if t.dtype is torch.bfloat16:
+        raise RadmmmError("a bfloat16 tensor reached the fp32 C ABI (an autocast region upstream?): cast it to float")
     return t.data_ptr()
 
 
@@ -219,3 +221,23 @@ def wgrad(**kw) -> None:
             v = ptr(v)
         setattr(d, k, v)
     check(lib.radmmm_wgrad_f32(C.byref(d), stream()), "radmmm_wgrad_f32")
+
+
+# Every custom autograd Function of this package computes in fp32 through raw pointers: under torch.autocast
+# (Lightning `precision: bf16-mixed`) a stock op inside a forward would hand a bf16 tensor to an fp32 kernel.
+# amp_fwd switches autocast off inside forward (casting floating tensor arguments to fp32), amp_bwd runs
+# backward in the same state.
+amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def fp32_region(fn):
+    """Module-level forwards of this package also hold a few stock matmuls (W @ mean of the whitening conv, the LSTM's
+    input projection, hipBLASLt GEMMs of the predictors): run them with autocast off, like the kernels they feed."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        with torch.autocast(device_type="cuda", enabled=False):
+            return fn(*args, **kwargs)
+    return wrapped

@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from . import ops
+from ._lib import fp32_region
 from .common import _WNConv
 
 
@@ -52,6 +53,7 @@ class ConvAttention(nn.Module):
                               act="relu" if i < n - 1 else "none")
         return x
 
+    @fp32_region
     def forward(self, queries, keys, query_lens=None, mask=None, key_lens=None, attn_prior=None):
         """queries [B, n_mel, T1], keys [B, n_text, T2]; mask: bool [B, T2, 1] True at PADDED text
         positions (only its lengths matter: it is rebuilt from key_lens, or from the mask itself);

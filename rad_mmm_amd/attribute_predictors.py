@@ -14,6 +14,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
+from ._lib import fp32_region
 from .common import SequenceLength, _WNConv
 from .lstm import bilstm
 
@@ -134,6 +135,7 @@ class ConvLSTMLinearDAP(AttributePredictor):
         self.feat_pred_fn = ConvLSTMLinear(in_dim=d, out_dim=out_dim, n_layers=n_backbone_layers, n_channels=n_hidden,
                                            kernel_size=kernel_size, p_dropout=p_dropout, lstm_type=lstm_type)
 
+    @fp32_region
     def forward(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
         if not text_enc.is_cuda:
             raise RuntimeError("rad_mmm_amd.attribute_predictors runs on an MI355X only (no CPU path)")
@@ -153,6 +155,7 @@ class ConvLSTMLinearDAP(AttributePredictor):
         x_hat = self.feat_pred_fn.forward_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T)
         return {"x_hat": x_hat, "x": x_target}
 
+    @fp32_region
     def infer(self, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
         res = self.forward(None, text_enc, spk_emb, lens, accent_emb=accent_emb)
         return self.inv_tx_data(res["x_hat"], x_mean, x_std)

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
+from ._lib import fp32_region
 
 
 def _hann_periodic(n: int) -> np.ndarray:
@@ -81,6 +82,7 @@ class TacotronSTFT(nn.Module):
         self.register_buffer("mel_basis", torch.from_numpy(
             mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax)))
 
+    @fp32_region
     def mel_spectrogram(self, y: torch.Tensor) -> torch.Tensor:
         """y [B, S] in [-1, 1] -> [B, n_mel, 1 + S//hop] log-mel (clamp 1e-5)."""
         if not y.is_cuda:

@@ -17,6 +17,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
+from ._lib import fp32_region
 from .common import (AffineTransformationLayer, DataInitializedInvertible1x1Conv,
                      Invertible1x1ConvLUS, SequenceLength)
 
@@ -194,6 +195,7 @@ class RADMMMFlow(nn.Module):
         return out * (t < total[:, None])[:, :, None].to(x.dtype)
 
     @torch.no_grad()
+    @fp32_region
     def infer(self, spk_vec, txt_enc, sigma, dur=None, f0=None, energy_avg=None, out_lens=None, accent_vecs=None,
               residual=None):
         """z -> mel (reference decoders.py:207-248): length-regulate the text encoding, build the
@@ -337,6 +339,7 @@ class RADMMMFlow(nn.Module):
         return self.preprocess_context_cl(context, spk_vecs, sl, f0, energy_avg, accent_vecs).transpose(1, 2)
 
     # ------------------------------------------------------------------ forward
+    @fp32_region
     def forward(self, mel, spk_vecs, context, out_lens: SequenceLength, f0=None, energy_avg=None,
                 accent_vecs=None):
         """mel [B, n_mel, T], spk_vecs [B, n_spk], context [B, n_text, T], out_lens SequenceLength,

@@ -14,7 +14,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import lib, check, ptr, stream
+from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd, fp32_region
 from .common import _WNConv
 from .lstm import bilstm
 
@@ -23,6 +23,7 @@ class InstanceNormReluFn(torch.autograd.Function):
     """y = relu(instance_norm(x) * w + b) over the valid frames of each item; x [B*T, ld] channels-last."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, x, weight, bias, lens, B, T, C, relu):
         y = torch.empty(B * T, x.shape[1], device=x.device, dtype=torch.float32)
         if x.shape[1] != C:
@@ -36,6 +37,7 @@ class InstanceNormReluFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gy):
         B, T, C, relu = ctx.dims
         x, y, weight, mean, rstd, lens = ctx.saved_tensors
@@ -78,6 +80,7 @@ class Encoder(nn.Module):
         for hook in self.lstm._forward_pre_hooks.values():
             hook(self.lstm, ())
 
+    @fp32_region
     def forward(self, x, in_lens):
         """x [B, C, L] padded text embeddings, in_lens [B] -> [B, max(in_lens), C]."""
         if not x.is_cuda:
@@ -95,6 +98,7 @@ class Encoder(nn.Module):
         y = bilstm(self.lstm, h.view(B, L, C), lens32)
         return y[:, : int(in_lens.max())]
 
+    @fp32_region
     def infer(self, x):
         """single utterance / full-length batch (common.py:495-505)."""
         B, _, L = x.shape

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import lib, check, ptr, stream
+from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd
 
 
 def _scratch(B, H, which, like):
@@ -23,6 +23,7 @@ class BiLSTMFn(torch.autograd.Function):
     backward consumes the saved gate activations in place (not re-entrant: no retain_graph)."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, x, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         B, T, I = x.shape
         H = w_hh_f.shape[1]
@@ -43,6 +44,7 @@ class BiLSTMFn(torch.autograd.Function):
         return y.view(B, T, 2 * H)
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, dy):
         B, T, I, H = ctx.dims
         x2, G, c, y, W_ih, W_hh, lens = ctx.saved_tensors

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad, f32c
+from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad, f32c, amp_fwd, amp_bwd
 
 ZLD = 160            # row pitch of every flow-variable matrix (n_mel*group padded, see decoders.py)
 
@@ -65,6 +65,7 @@ class LUWeightFn(torch.autograd.Function):
     placed at columns [col_offset, col_offset + c) of a zero matrix; one launch each way (csrc/lu_weight.hip)."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, p, lower, lower_diag, upper, upper_diag, ldw, col_offset):
         c = upper_diag.shape[0]
         p, lower_c, ld, upper_c, ud = f32c(p), f32c(lower), f32c(lower_diag), f32c(upper), f32c(upper_diag)
@@ -78,6 +79,7 @@ class LUWeightFn(torch.autograd.Function):
         return W, logdet
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gW, glogdet):
         p, lower_c, ld, upper_c, ud = ctx.saved_tensors
         lower, upper, upper_diag = ctx.params
@@ -154,6 +156,7 @@ class AffineFlowStepFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, meta, z_in, cond, lens, W_eff, b_eff, start_v, start_g, start_b, end_w, end_b,
                 *layer_params):
         B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
@@ -217,6 +220,7 @@ class AffineFlowStepFn(torch.autograd.Function):
         return z_out, log_s
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, g_zout, g_logs):
         meta, nl = ctx.meta, ctx.nl
         B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
@@ -302,6 +306,7 @@ class MaskedReduceFn(torch.autograd.Function):
     dense (permuted) view."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, x, lens, mode):
         assert x.dim() == 3 and x.dtype == torch.float32
         B, C, T = x.shape
@@ -315,6 +320,7 @@ class MaskedReduceFn(torch.autograd.Function):
         return out.view(())
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, g):
         x, lens = ctx.saved_tensors
         B, C, T = x.shape
@@ -357,6 +363,7 @@ class ConvNormFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, meta, x, v, g, bias, lens):
         B, T, dil = meta["B"], meta["T"], meta["dil"]
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
@@ -385,6 +392,7 @@ class ConvNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gy):
         meta = ctx.meta
         B, T, dil = meta["B"], meta["T"], meta["dil"]
@@ -441,6 +449,7 @@ class AttentionCoreFn(torch.autograd.Function):
     or None -> attn, attn_logprob [B,T1,T2]."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, Q, K, prior, in_lens, temp):
         B, T1, Ca = Q.shape
         T2 = K.shape[1]
@@ -453,6 +462,7 @@ class AttentionCoreFn(torch.autograd.Function):
         return attn, logprob
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gattn, glogprob):
         Q, K, prior, in_lens, attn, logprob = ctx.saved_tensors
         has_prior, has_lens, temp = ctx.flags
@@ -625,6 +635,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
     every elementwise / reduction kernel stay fp32."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, meta, z_in, cond, lens, W_eff, b_eff, start_v, start_g, start_b, end_w, end_b,
                 *layer_params):
         B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
@@ -693,6 +704,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         return z_out, log_s
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, g_zout, g_logs):
         meta, nl = ctx.meta, ctx.nl
         NPR = meta.get("nprod", 3)
@@ -807,6 +819,7 @@ class ConvNormH3Fn(torch.autograd.Function):
     comes out of the transposing pass; Cout is padded to a multiple of 32 for the data gradient's K."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, meta, x, v, g, bias, lens):
         B, T, dil = meta["B"], meta["T"], meta["dil"]
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
@@ -829,6 +842,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gy):
         meta = ctx.meta
         B, T, dil = meta["B"], meta["T"], meta["dil"]

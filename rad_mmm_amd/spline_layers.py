@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import lib, check, ptr, stream
+from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd
 from .common import _PlainConv, _WNConv
 
 
@@ -42,6 +42,7 @@ class FiLMPostFn(torch.autograd.Function):
     """out = 0.5 * (leaky(bn(h2) * (c1a + 1) + c1b) + x1r)  (common.py:728-735)."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, h2, c1, x1r, bn_w, bn_b, mean, invstd, lens, T, n_valid, use_bn):
         rows, C = h2.shape[0], x1r.shape[1]
         out = torch.empty(rows, C, device=h2.device, dtype=torch.float32)
@@ -54,6 +55,7 @@ class FiLMPostFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gout):
         h2, c1, bn_w, bn_b, mean, invstd, lens = ctx.saved_tensors
         T, n_valid, use_bn, has_lens, C = ctx.meta
@@ -143,6 +145,7 @@ class PQSplineFn(torch.autograd.Function):
     [0,1) units) with q [rows, h*(2K+1)]; returns y [rows, h] and the per-row sum of log-jacobians."""
 
     @staticmethod
+    @amp_fwd
     def forward(ctx, x, q, h, K):
         rows = x.shape[0]
         y = torch.empty(rows, h, device=x.device, dtype=torch.float32)
@@ -154,6 +157,7 @@ class PQSplineFn(torch.autograd.Function):
         return y, lj[:rows]
 
     @staticmethod
+    @amp_bwd
     def backward(ctx, gy, glj):
         x, q = ctx.saved_tensors
         h, K = ctx.hk

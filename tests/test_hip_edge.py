@@ -326,3 +326,36 @@ def test_second_backward_without_rearming_accumulates():
     for n, p in dec.named_parameters():
         want = (single[0][n] + single[1][n]).cpu()
         assert rel_err(p.grad.cpu(), want) < 1e-6, n
+
+
+def test_autocast_context_does_not_reach_the_kernels():
+    """Lightning `precision: bf16-mixed` wraps the step in torch.autocast.  The package computes in fp32 through raw
+    pointers, so its Functions switch autocast off inside: decoder forward + backward under autocast(bf16) must
+    equal the plain run bit for bit (without the guard the LSTM's input GEMM would hand bf16 to an fp32 kernel)."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=9, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    res = []
+    for amp in (False, True):
+        dec.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+            loss = crit(out, None, sl, 0)["loss_mel"][0]
+        loss.backward()
+        assert out["z_mel"].dtype == torch.float32
+        res.append((out["z_mel"].detach().clone(), loss.detach().clone(),
+                    {n: p.grad.detach().clone() for n, p in dec.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n

@@ -255,3 +255,43 @@ def test_validation_step_equals_the_training_pass_without_gradients(monkeypatch)
         assert abs(float(losses_v[k][0]) - float(losses_t[k][0])) <= 1e-5 * max(abs(float(losses_t[k][0])), 1e-3), k
         assert losses_v[k][1] == losses_t[k][1]
     assert abs(float(loss_v) - float(loss_t)) <= 1e-5 * abs(float(loss_t))
+
+
+def test_training_step_under_autocast_runs_in_fp32_where_it_matters(monkeypatch):
+    """Lightning `precision: bf16-mixed`: the caller's stock matmuls (context = txt_enc x attn) autocast to bf16 as
+    they do in the reference; everything behind this package's modules stays fp32 (no bf16 tensor may reach the C
+    ABI).  The joint loss must stay within bf16 rounding of the fp32 run and backward must work."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    import torch.nn.functional as F
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    torch.manual_seed(3)
+    mk = lambda: ConvLSTMLinearDAP(n_speaker_dim=16, in_dim=32, out_dim=1, reduction_factor=4, n_backbone_layers=2, n_hidden=32,
+                                   kernel_size=3, p_dropout=0.0)
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10, f0_predictor=mk(),
+                            f0_predictor_loss=AttributeRegressionLoss("f0_", 1.0), duration_predictor=mk(),
+                            duration_predictor_loss=AttributeRegressionLoss("duration_", 1.0))
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion") and "_predictor" not in n]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+    model = model.to(dev).train()
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    batch["voiced_mask"] = (batch["f0"] > 0).float()
+    loss32, losses32, _ = model.training_step(batch, global_step=0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss16, losses16, out = model.training_step(batch, global_step=0)
+    loss16.backward()
+    assert out["z_mel"].dtype == torch.float32 and torch.isfinite(loss16)
+    for k in losses32:
+        a, b = float(losses32[k][0]), float(losses16[k][0])
+        assert abs(a - b) <= 3e-2 * max(abs(a), 1e-2), (k, a, b)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
