@@ -177,7 +177,19 @@ class RADMMMFlow(nn.Module):
             f.enable_inverse_cache()
 
     def remove_norms(self):
-        raise NotImplementedError("inference-only helper; out of scope (SURVEY.md §8f4)")
+        """models/radmmm.py:150-166 ("call before inference"): strips the spectral / weight norm from the context
+        LSTM's recurrent weights (torch's own parametrisation hooks, as in the reference).  The convolutions keep
+        their (weight_g, weight_v) pair: the HIP kernels fold the normalisation into the pass that splits the
+        weights for the GEMM, so there is no separate norm to remove and outputs are unchanged either way."""
+        if not self.use_context_lstm:
+            return
+        for name in ("weight_hh_l0", "weight_hh_l0_reverse"):
+            for remove in (nn.utils.remove_spectral_norm, nn.utils.remove_weight_norm):
+                try:
+                    remove(self.context_lstm, name=name)
+                    break
+                except (ValueError, AttributeError):
+                    pass
 
     @staticmethod
     def length_regulator(x, dur):

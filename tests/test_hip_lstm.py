@@ -82,3 +82,31 @@ def test_decoder_context_lstm_with_normed_recurrent_weights(norm, monkeypatch):
     assert rel_err(outs["hip"][0], outs["miopen"][0]) < 2e-5
     for n in outs["hip"][1]:
         assert rel_err(outs["hip"][1][n], outs["miopen"][1][n]) < 1e-4, n
+
+
+@pytest.mark.parametrize("norm", ["spectral", "weight", None])
+def test_remove_norms_keeps_the_context(norm):
+    """RADMMMFlow.remove_norms (models/radmmm.py:150-166, "call before inference"): the parametrisation of the
+    context LSTM's recurrent weights is stripped, the eval-mode context is unchanged, the state_dict now carries
+    plain `weight_hh_l0*`."""
+    import numpy as np
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=1,
+              context_lstm_norm=norm)
+    torch.manual_seed(4)
+    dec = RADMMMFlow(use_accent=True, **kw).to(DEV).eval()
+    cfg = S.DecoderConfig(**{k: v for k, v in kw.items() if k != "context_lstm_norm"})
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 40, cfg, seed=2, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    with torch.no_grad():
+        before = dec.preprocess_context_cl(b["context"], b["spk"], sl, b["f0"], b["energy"], b["accent"]).clone()
+        dec.remove_norms()
+        after = dec.preprocess_context_cl(b["context"], b["spk"], sl, b["f0"], b["energy"], b["accent"])
+    names = set(dec.context_lstm.state_dict())
+    assert "weight_hh_l0" in names and "weight_hh_l0_reverse" in names
+    assert not any(n.endswith(("_orig", "_g", "_v", "_u")) for n in names), names
+    assert rel_err(after.cpu(), before.cpu()) < 1e-6
+    dec.remove_norms()                                          # idempotent
