@@ -118,8 +118,9 @@ class RADTTSLoss(nn.Module):
 
 
 class RADMMMLoss(RADTTSLoss):
-    """loss.py:500-537: same arithmetic as RADTTSLoss; the extra constructor keywords only
-    configure embedding regularisers that live in the LightningModule (out of scope)."""
+    """loss.py:500-537: same arithmetic as RADTTSLoss; the extra constructor keywords are stored and, as in the
+    reference, never read by forward (the embedding regularisers are separate modules called by the training step:
+    VarianceCovarianceEmbeddingRegLoss / AttributeMinCrossCovarianceRegLoss below, tts_step.py)."""
 
     def __init__(self, sigma=1.0, n_group_size=1, CTC_blank_logprob=-1, kl_loss_start_iter=5000,
                  binarization_loss_weight=1.0, ctc_loss_weight=0.1, use_spk_embed_reg=False,
