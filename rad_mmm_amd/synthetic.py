@@ -44,7 +44,8 @@ class DecoderConfig:
 
     @property
     def cond_dims(self):
-        return 2 * self.lstm_hidden
+        """decoder_cond_dims (decoders.py:126-134): the bi-LSTM's output width, or its input's without the LSTM"""
+        return 2 * self.lstm_hidden if self.use_context_lstm else self.lstm_in
 
     def flow_channels(self) -> List[int]:
         c = self.n_mel_channels * self.n_group_size
@@ -139,7 +140,7 @@ def decoder_state_shapes(cfg: DecoderConfig, wn_channels: int = 1024, film_hidde
     against the reference by tests/golden/make_golden.py)."""
     sh: Dict[str, Tuple[int, ...]] = {}
     H, I = cfg.lstm_hidden, cfg.lstm_in
-    for suf in ("", "_reverse"):
+    for suf in ("", "_reverse") if cfg.use_context_lstm else ():
         sh[f"context_lstm.weight_ih_l0{suf}"] = (4 * H, I)
         sh[f"context_lstm.weight_hh_l0{suf}"] = (4 * H, H)
         sh[f"context_lstm.bias_ih_l0{suf}"] = (4 * H,)

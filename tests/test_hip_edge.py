@@ -359,3 +359,30 @@ def test_autocast_context_does_not_reach_the_kernels():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for n in res[0][2]:
         assert torch.equal(res[0][2][n], res[1][2][n]), n
+
+
+@pytest.mark.parametrize("opt", [dict(use_context_lstm=False),
+                                 # (the widths count f0 / energy regardless of the flag, models/radmmm.py:73-78: the
+                                 #  flag only works together with zero-width f0 / energy, as in the reference)
+                                 dict(context_w_f0_and_energy=False, n_f0_dims=0, n_energy_avg_dims=0),
+                                 dict(use_accent_emb_for_decoder=False),
+                                 dict(use_context_lstm=False, context_w_f0_and_energy=False, n_f0_dims=0, n_energy_avg_dims=0)])
+def test_context_options_of_the_constructor(opt):
+    """decoders.py:83-143 / models/radmmm.py:103-148: context without the LSTM, without f0 / energy columns,
+    without the accent embedding -- HIP path vs the oracle, outputs, NLL and gradients."""
+    kw = dict(BASE, n_flows=2, n_text_dim=64, **opt)
+    lens = [64, 38]
+    dec, out, lm, p, ro, lo, cfg = _run_both(kw, 2, 64, lens)
+    ul = torch.tensor(lens) // cfg.n_group_size
+    Tg = ro["z_mel"].shape[2]
+    m = (torch.arange(Tg)[None] < ul[:, None])[:, None].expand_as(ro["z_mel"])
+    assert rel_err(out["z_mel"].detach().cpu()[:, :, :Tg][m], ro["z_mel"].detach()[m]) < 1e-4
+    assert abs(float(lm.detach()) - float(lo.detach())) < 1e-4 * abs(float(lo.detach()))
+    assert out["context_w_spkvec"].shape[1] == dec.decoder_cond_dims
+    params = dict(dec.named_parameters())
+    names = ["flows.1.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
+             "flows.0.coupling_tfn.affine_param_predictor.start.weight_v", "flows.1.invtbl_conv.lower"]
+    if cfg.use_context_lstm:
+        names.append("context_lstm.weight_ih_l0")
+    for n in names:
+        assert rel_err(params[n].grad.cpu(), p[n].grad) < 1e-3, n
