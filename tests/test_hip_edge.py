@@ -386,3 +386,53 @@ def test_context_options_of_the_constructor(opt):
         names.append("context_lstm.weight_ih_l0")
     for n in names:
         assert rel_err(params[n].grad.cpu(), p[n].grad) < 1e-3, n
+
+
+def test_relu_activation_in_the_wn():
+    """affine_activation='relu' (common.py:776-835 takes either): fused epilogue / activation-gradient kernels vs the oracle"""
+    kw = dict(BASE, n_flows=2, n_text_dim=64, affine_activation="relu")
+    lens = [64, 50]
+    r = _run_both(kw, 2, 64, lens)
+    dec, out, lm, p, ro, lo, cfg = r
+    ul = torch.tensor(lens) // cfg.n_group_size
+    Tg = ro["z_mel"].shape[2]
+    m = (torch.arange(Tg)[None] < ul[:, None])[:, None].expand_as(ro["z_mel"])
+    assert rel_err(out["z_mel"].detach().cpu()[:, :, :Tg][m], ro["z_mel"].detach()[m]) < 1e-4
+    assert abs(float(lm.detach()) - float(lo.detach())) < 1e-4 * abs(float(lo.detach()))
+    params = dict(dec.named_parameters())
+    for n in ("flows.1.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
+              "flows.0.coupling_tfn.affine_param_predictor.res_skip_layers.0.weight_v", "flows.1.invtbl_conv.lower"):
+        # relu' is discontinuous: an activation within rounding of 0 flips a whole gradient term
+        assert rel_err(params[n].grad.cpu(), p[n].grad) < 2e-3, n
+
+
+def test_frozen_whitening_layer_trains_the_rest():
+    """freeze_whitening_layer=True (decoders.py:143-145): flow 0's 1x1 conv gets no gradient, the others do, and the
+    bucket reducer copes with parameters outside its buckets."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    grads = {}
+    for frozen in (False, True):
+        dec = RADMMMFlow(use_accent=True, freeze_whitening_layer=frozen, **kw)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).train()
+        red = BucketedGradReducer(dec)
+        b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=4, ragged=True).items()}
+        sl = SequenceLength(b["lengths"])
+        red.prepare()
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        RADMMMLoss(sigma=1.0, n_group_size=2)(out, None, sl, 0)["loss_mel"][0].backward()
+        red.finish()
+        grads[frozen] = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in dec.named_parameters()}
+        if frozen:
+            assert all(not p.requires_grad and p.grad is None for n, p in dec.named_parameters() if n.startswith("flows.0.invtbl_conv."))
+    for n, gfree in grads[False].items():
+        if not n.startswith("flows.0.invtbl_conv."):
+            assert torch.equal(gfree, grads[True][n]), n
