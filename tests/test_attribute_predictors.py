@@ -50,3 +50,48 @@ def test_hip_dap_matches_reference():
     for n, p in dap.named_parameters():
         ref = g["gradp." + n]
         assert rel_err(p.grad.cpu(), ref) < 3e-4 or float((p.grad.cpu() - ref).abs().max()) < 1e-4 * scale, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,k", [(3, 70, 15), (32, 400, 15), (32, 400, 5)])
+def test_hip_dap_at_the_shipped_config_sizes(B, T, k):
+    """The f0 / voiced predictor shapes of configs/RAD{TTS,MMM}_f0model_config.yaml (in_dim 512, reduction 16, 3 backbone
+    layers of 256 channels, kernel 15 resp. 5, accent embedding on), small batch (fp32 conv path) and the full
+    32 x 400 batch (split-f16 conv path with 15 taps): forward and parameter gradients against the oracle."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.attribute_predictors import ConvLSTMLinearDAP
+    from rad_mmm_amd.common import SequenceLength
+    dev = "cuda:0"
+    torch.manual_seed(B + k)
+    dap = ConvLSTMLinearDAP(n_speaker_dim=16, n_accent_dim=8, in_dim=512, out_dim=1, reduction_factor=16, n_backbone_layers=3,
+                            n_hidden=256, kernel_size=k, p_dropout=0.0, target_offset=-5, use_accent_embedding=True)
+    dap = dap.to(dev).train()
+    for _ in range(20):          # converge spectral norm's power iteration: fresh u / v leave |W_hh| ~ 10, a chaotic recurrence
+        for hook in dap.feat_pred_fn.bilstm._forward_pre_hooks.values():
+            hook(dap.feat_pred_fn.bilstm, ())
+    dap = dap.eval()
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    txt = torch.randn(B, 512, T, generator=g) * 0.5
+    spk, acc = torch.randn(B, 16, generator=g), torch.randn(B, 8, generator=g)
+    gy = torch.randn(B, 1, T, generator=g)
+    sl = SequenceLength(lens.to(dev))
+    out = dap(None, txt.to(dev), spk.to(dev), sl, accent_emb=acc.to(dev))["x_hat"]
+    mask = (torch.arange(T)[None, :] < lens[:, None])[:, None]
+    ((out * (gy * mask).to(dev)).sum()).backward()
+    p = {n: v.detach().cpu().clone() for n, v in dap.state_dict().items()}
+    for n in p:
+        if p[n].dtype == torch.float32 and not n.endswith(("_u", "_v")) and p[n].dim() > 0:
+            p[n].requires_grad_(True)
+    ref = O.dap_forward(p, "", txt, torch.cat((spk, acc), 1), lens, 3)          # the module appends accent after speaker
+    ((ref * gy[:, :, : ref.shape[2]] * mask[:, :, : ref.shape[2]]).sum()).backward()
+    o = out.detach().cpu()[:, :, : ref.shape[2]]
+    assert rel_err(o[mask[:, :, : ref.shape[2]]], ref.detach()[mask[:, :, : ref.shape[2]]]) < 1e-4
+    errs = {n: rel_err(q.grad.cpu(), p[n].grad) for n, q in dap.named_parameters() if n in p and p[n].grad is not None}
+    # relu' is discontinuous: of the 3.3 M pre-activations per layer of the full batch a handful lie within rounding of
+    # zero and flip between the two implementations, which moves the gradients upstream of the ReLUs by ~1e-3
+    # (same on the fp32-MFMA path, RADMMM_PRECISION=fp32); everything downstream of them stays at 1e-6
+    loose = 1e-2 if B * T > 5000 else 5e-4
+    bad = {n: e for n, e in errs.items() if not e < (loose if n.startswith(("bottleneck", "feat_pred_fn.convolutions")) else 5e-4)}
+    assert not bad, (bad, errs)
