@@ -207,3 +207,48 @@ def test_conv_norm_op_grad(k, dil, partial, act):
     assert rel_err(vc.grad.cpu(), vo.grad) < 5e-5
     assert rel_err(gc.grad.cpu(), go.grad) < 5e-5
     assert rel_err(bc.grad.cpu(), bo.grad) < 5e-5
+
+
+def test_attention_full_size_with_device_prior():
+    """BASELINE batch shape (32 x 800 mel frames x up to 150 tokens, 80 attention channels) with the prior built on
+    the device (rad_mmm_amd.data): against the oracle on the first 3 utterances, and for the whole batch the
+    size-independent properties -- rows are distributions over the valid tokens, padded tokens get exactly zero,
+    log-probabilities are finite on valid entries, binarized alignments are one-hot monotone paths."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.alignment import binarize_attention
+    from rad_mmm_amd.attention import ConvAttention
+    from rad_mmm_amd.data import BetaBinomialInterpolator
+    torch.manual_seed(2)
+    B, T1, T2 = 32, 800, 150
+    att = ConvAttention(80, 512, 80).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    out_lens = torch.randint(300, T1 + 1, (B,), generator=g); out_lens[0] = T1
+    in_lens = torch.randint(40, T2 + 1, (B,), generator=g); in_lens[0] = T2
+    q = torch.randn(B, 80, T1, generator=g)
+    k = torch.randn(B, 512, T2, generator=g) * 0.3
+    prior = BetaBinomialInterpolator().batch(in_lens.tolist(), out_lens.tolist())
+    assert prior.shape == (B, T1, T2)
+    kmask = ~(torch.arange(T2)[None] < in_lens[:, None])[..., None]
+    with torch.no_grad():
+        attn, lp = att(q.to(DEV), k.to(DEV), out_lens.to(DEV), kmask.to(DEV), key_lens=in_lens.to(DEV), attn_prior=prior)
+    a = attn[:, 0].cpu()
+    p = {"att." + n: v.detach().cpu() for n, v in att.state_dict().items()}
+    n_ref = 3
+    ra, rl = O.conv_attention_forward(p, "att.", q[:n_ref], k[:n_ref], kmask[:n_ref], prior[:n_ref].cpu())
+    for b in range(n_ref):
+        t, n = int(out_lens[b]), int(in_lens[b])
+        assert rel_err(a[b, :t, :n], ra[b, 0, :t, :n]) < 1e-4
+        assert rel_err(lp[b, 0, :t, :n].cpu(), rl[b, 0, :t, :n]) < 1e-4
+    for b in range(B):
+        t, n = int(out_lens[b]), int(in_lens[b])
+        np.testing.assert_allclose(a[b, :t, :n].sum(1).numpy(), 1.0, rtol=1e-5)
+        assert torch.all(a[b, :, n:] == 0)
+        assert torch.isfinite(lp[b, 0, :t, :n]).all()
+    hard = binarize_attention(attn, in_lens.to(DEV), out_lens.to(DEV))[:, 0].cpu()
+    for b in (0, 7, 31):
+        t, n = int(out_lens[b]), int(in_lens[b])
+        h = hard[b, :t, :n]
+        assert torch.all(h.sum(1) == 1)
+        idx = h.argmax(1)
+        assert int(idx[0]) == 0 and int(idx[-1]) == n - 1 and torch.all((idx[1:] - idx[:-1] >= 0) & (idx[1:] - idx[:-1] <= 1))
+        assert torch.all(hard[b, t:] == 0) and torch.all(hard[b, :, n:] == 0)
