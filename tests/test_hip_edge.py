@@ -436,3 +436,62 @@ def test_frozen_whitening_layer_trains_the_rest():
     for n, gfree in grads[False].items():
         if not n.startswith("flows.0.invtbl_conv."):
             assert torch.equal(gfree, grads[True][n]), n
+
+
+def test_three_training_steps_follow_the_oracle_trajectory():
+    """End to end, several steps: decoder forward + NLL + backward -> global-norm clip 1.0 -> RAdam, three times, HIP
+    (bucket reducer + FlatRAdam) against the CPU oracle (autograd of the restatement + its RAdam / clip): the loss of
+    every step and the parameters after the last one must agree."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.optim import FlatRAdam
+    kw = dict(BASE, n_flows=2, n_text_dim=64)
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    red = BucketedGradReducer(dec)
+    lr, wd = 2e-4, 1e-6
+    opt = FlatRAdam(dec.named_parameters(), lr=lr, weight_decay=wd, reducer=red)
+    crit = RADMMMLoss(n_group_size=cfg.n_group_size)
+    trainable = [n for n, _ in dec.named_parameters()]
+    p = {k: v.clone() for k, v in sd.items()}
+    for n in trainable:
+        p[n].requires_grad_(True)
+    m = {n: torch.zeros_like(p[n]) for n in trainable}
+    v = {n: torch.zeros_like(p[n]) for n in trainable}
+    lens = [[64, 40], [64, 64], [52, 64]]
+    for k in range(3):
+        b = T(O.synthetic_batch(2, 64, cfg, 30 + k, ragged=False))
+        b["lengths"] = torch.tensor(lens[k])
+        for i in range(2):
+            L = lens[k][i]
+            b["mel"][i, :, L:] = 0; b["context"][i, :, L:] = 0; b["f0"][i, L:] = 0; b["energy"][i, L:] = 0
+        gb = {kk: vv.to(DEV) for kk, vv in b.items()}
+        sl = SequenceLength(gb["lengths"])
+        red.prepare()
+        out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+        loss = crit(out, None, sl, 0)["loss_mel"][0]
+        loss.backward()
+        red.finish()
+        total = opt.clip_grad_norm(1.0)
+        opt.step()
+        # oracle
+        for n in trainable:
+            p[n].grad = None
+        ro = O.decoder_forward(p, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
+        lo, _ = O.decoder_loss(ro, b["lengths"], cfg.n_group_size)
+        lo.backward()
+        rt, clipped = O.clip_grad_norm([p[n].grad for n in trainable], 1.0)
+        with torch.no_grad():
+            for n, gc in zip(trainable, clipped):
+                O.radam_step(p[n], gc, m[n], v[n], k + 1, lr=lr, weight_decay=wd)
+        assert abs(float(loss) - float(lo)) < 2e-5 * abs(float(lo)), (k, float(loss), float(lo))
+        assert abs(float(total) - float(rt)) < 1e-4 * float(rt), (k, float(total), float(rt))
+    for n, q in dec.named_parameters():
+        d = float((q.detach().cpu() - p[n].detach()).abs().max())
+        assert d <= 2e-2 * lr + 1e-6 * float(p[n].detach().abs().max()), (n, d)      # 3 steps of <= lr each; 1 % of a step
