@@ -47,6 +47,10 @@ class BiLSTMFn(torch.autograd.Function):
     @amp_bwd
     def backward(ctx, dy):
         B, T, I, H = ctx.dims
+        if getattr(ctx, "_consumed", False):
+            raise RuntimeError("BiLSTMFn.backward ran twice on the same graph: it turns the saved gate activations into "
+                               "gradients in place (no retain_graph / double backward)")
+        ctx._consumed = True
         x2, G, c, y, W_ih, W_hh, lens = ctx.saved_tensors
         lens = lens if ctx.has_lens else None
         dy2 = dy.contiguous().view(B * T, 2 * H)

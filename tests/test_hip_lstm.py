@@ -110,3 +110,15 @@ def test_remove_norms_keeps_the_context(norm):
     assert not any(n.endswith(("_orig", "_g", "_v", "_u")) for n in names), names
     assert rel_err(after.cpu(), before.cpu()) < 1e-6
     dec.remove_norms()                                          # idempotent
+
+
+def test_second_backward_through_the_lstm_is_refused():
+    """BiLSTMFn overwrites its saved gate activations with their gradients: retain_graph + a second backward would
+    silently compute garbage, so it raises."""
+    from rad_mmm_amd.lstm import bilstm
+    lstm = nn.LSTM(6, 5, num_layers=1, batch_first=True, bidirectional=True).to(DEV)
+    x = torch.randn(2, 4, 6, device=DEV, requires_grad=True)
+    y = bilstm(lstm, x, None).sum()
+    y.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ran twice"):
+        y.backward()
