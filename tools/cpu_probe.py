@@ -11,7 +11,7 @@ cfg, sd = bench.procedural_state(CFG)
 dev = "cuda:0"
 dec = RADMMMFlow(use_accent=True, **CFG); dec.load_state_dict(sd); dec = dec.to(dev).train()
 crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)
-gb = {k: torch.from_numpy(v).to(dev) for k, v in S.synthetic_batch(32, 800, cfg, seed=1234, ragged=False).items()}
+gb = {k: torch.from_numpy(v).to(dev) for k, v in S.synthetic_batch(32, 800, cfg, seed=1234, ragged=("--ragged" in sys.argv)).items()}
 sl = SequenceLength(gb["lengths"]); red = BucketedGradReducer(dec)
 def step():
     red.prepare()
