@@ -191,15 +191,18 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   const long long a_bytes = (long long)p.M * d->lda_h * 2;
   const long long b_bytes = ((long long)(p.taps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "rowgemm_h3: operand >= 2 GiB");
-  // default: the wide-tile kernel (rowgemm_h3w.hip); RADMMM_H3_TILE=128 keeps this file's 128x128 one (A/B runs)
-  static const bool narrow = [] {
-    const char* e = getenv("RADMMM_H3_TILE");
-    return e && atoi(e) == 128;
-  }();
+  // default: the wide-tile kernel (rowgemm_h3w.hip), one workgroup per CU.  A small batch does not give it enough
+  // tiles (M = 3200: 100 workgroups of its smallest 128 x 256 tile on 256 CUs): below half a round this file's
+  // 128 x 128 kernel, two workgroups per CU, is faster (B = 8, T = 800: 40.0 vs 43.9 ms per step).
+  // RADMMM_H3_TILE=128 / 256 forces one or the other (A/B runs).
+  const char* forced_env = getenv("RADMMM_H3_TILE");          // read per launch: tests switch it
+  const int forced = forced_env ? atoi(forced_env) : 0;
   static const bool narrow_1x1 = [] {                 // experiment: short-K launches on the 2-workgroup-per-CU kernel
     const char* e = getenv("RADMMM_H3_1X1");
     return e && atoi(e) == 128;
   }();
+  const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
+  const bool narrow = forced == 128 || (forced != 256 && wide_wgs < 128);
   if (!narrow && !(narrow_1x1 && p.taps == 1))
     return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {

@@ -210,12 +210,14 @@ def test_decoder_f16_throughput_mode_is_close(R, golden, monkeypatch):
             assert abs(float(p.grad.norm()) - float(g[k])) < 2e-2 * float(g[k]), n
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])
 @pytest.mark.parametrize("Cin,Cout,taps,dil,partial,wn", [(32, 40, 5, 2, True, True), (64, 21, 1, 1, False, False),
                                                          (96, 64, 5, 1, True, True), (32, 32, 3, 1, False, True)])
-def test_conv_norm_h3_matches_fp32_path(R, Cin, Cout, taps, dil, partial, wn, monkeypatch):
+def test_conv_norm_h3_matches_fp32_path(R, Cin, Cout, taps, dil, partial, wn, tile, monkeypatch):
     """ConvNormH3Fn (split-f16 conv, odd/even shifts, K padding of the data gradient, plain and
     weight-normed weights) against ConvNormFn (fp32 MFMA path, itself pinned to the oracle above)."""
     from rad_mmm_amd import ops
+    monkeypatch.setenv("RADMMM_H3_TILE", tile)           # both split-f16 forward / data-gradient kernels
     g = torch.Generator().manual_seed(Cin + Cout)
     B, Tn = 3, 40
     lens = _lens_dev([40, 26, 7])
@@ -371,9 +373,15 @@ def _build_decoder(g, precision="fp32"):
 
 
 @pytest.mark.parametrize("tag,precision", [("cfg1", "fp32"), ("cfg2_small", "fp32"), ("cfg5_small", "fp32"),
-                                           ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3")])
+                                           ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3"),
+                                           ("cfg1", "h3-wide"), ("cfg2_small", "h3-wide"), ("cfg5_small", "h3-wide")])
 def test_decoder_golden(R, golden, tag, precision, monkeypatch):
-    # "h3": also route the (small) FiLM convs through ConvNormH3Fn, which by default only takes frame-rate sizes
+    # "h3": also route the (small) FiLM convs through ConvNormH3Fn, which by default only takes frame-rate sizes.
+    # Problems this small go to the 128 x 128 split-f16 kernel by default; "h3-wide" forces the one-workgroup-per-CU
+    # kernel of the benchmark shape onto them (ragged tiles, partial columns).
+    if precision == "h3-wide":
+        precision = "h3"
+        monkeypatch.setenv("RADMMM_H3_TILE", "256")
     monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", "0" if precision == "h3" else "1000000000")
     monkeypatch.setenv("RADMMM_PRECISION", precision)
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
