@@ -284,6 +284,11 @@ int radmmm_attn_bwd(const float* Q, const float* Kx, const float* prior, const i
  * outside).  scratch: radmmm_mas_scratch_bytes(B, T1, T2). */
 int radmmm_mas_width1(const float* logp, const int32_t* in_lens, const int32_t* out_lens,
                       float* hard, void* scratch, int B, int T1, int T2, radmmm_stream_t stream);
+/* Same search on PROBABILITIES attn [B, T1, T2] (TTSModel.binarize_attention, tts_lightning_modules.py:270-284,
+ * hands alignment.py:31 the soft attention and the log is taken inside, alignment.py:36): the kernel takes the log
+ * itself, correctly rounded to fp32, so no log tensor is materialised. */
+int radmmm_mas_width1_prob(const float* attn, const int32_t* in_lens, const int32_t* out_lens,
+                           float* hard, void* scratch, int B, int T1, int T2, radmmm_stream_t stream);
 int64_t radmmm_mas_scratch_bytes(int B, int T1, int T2);
 
 /* STFT magnitude -> mel -> log-clamp (audio_processing.py:137-154, 227-255).

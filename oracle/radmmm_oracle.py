@@ -521,16 +521,17 @@ def mas_width1(attn_map: np.ndarray) -> np.ndarray:
     return opt
 
 
-def mas_width1_c(attn_map: np.ndarray) -> np.ndarray:
+def mas_width1_c(attn_map: np.ndarray, logp: np.ndarray = None) -> np.ndarray:
     """Same search through the plain-C restatement (oracle/mas_ref.c, built by oracle/Makefile);
-    the log is taken here with numpy exactly as alignment.py:36 does."""
+    the log is taken here with numpy exactly as alignment.py:36 does (or `logp` is used as given:
+    the search on a caller-supplied float32 log, for comparisons on identical log inputs)."""
     import ctypes
     import os
     so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmas_ref.so")
     lib = ctypes.CDLL(so)
     T1, T2 = attn_map.shape
     with np.errstate(divide="ignore"):
-        lp = np.ascontiguousarray(np.log(attn_map.astype(np.float32)))
+        lp = np.ascontiguousarray(np.log(attn_map.astype(np.float32)) if logp is None else logp.astype(np.float32))
     opt = np.zeros((T1, T2), dtype=np.float32)
     rc = lib.mas_width1_ref(lp.ctypes.data_as(ctypes.c_void_p), T1, T2, opt.ctypes.data_as(ctypes.c_void_p))
     if rc:

@@ -127,6 +127,7 @@ def _load() -> C.CDLL:
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
         "radmmm_attn_bwd": [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, f, p],
         "radmmm_mas_width1": [p, p, p, p, p, i, i, i, p],
+        "radmmm_mas_width1_prob": [p, p, p, p, p, i, i, i, p],
         "radmmm_stft_mel": [p, p, p, p, p, i, i, i, i, i, f, p],
     }
     missing = [n for n in sig if not hasattr(lib, n)]

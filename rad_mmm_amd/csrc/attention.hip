@@ -143,6 +143,16 @@ __global__ __launch_bounds__(128) void attn_bwd_keys_kernel(
 }
 
 // ------------------------------------------------------------------ MAS
+// PROB: the input holds probabilities and the log is taken here, correctly rounded to fp32 (double log, then one
+// rounding): a device-independent definition of the reference's `np.log(attn)` (alignment.py:36), whose own float32
+// result depends on the host's SIMD log (numpy's vector float32 log is documented to ~4 ulp).
+template <bool PROB>
+__device__ __forceinline__ float mas_load(const float* p) {
+  if constexpr (PROB) return (float)log((double)*p);
+  return *p;
+}
+
+template <bool PROB>
 __global__ __launch_bounds__(256) void mas_width1_kernel(
     const float* __restrict__ logp, const int* __restrict__ in_lens, const int* __restrict__ out_lens,
     float* __restrict__ hard, unsigned char* __restrict__ back, int T1, int T2) {
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void mas_width1_kernel(
   float* prev = sm;
   float* cur = sm + T2;
   for (int j = threadIdx.x; j < n2; j += blockDim.x) {
-    prev[j] = j == 0 ? lp[0] : -INFINITY;  // first row forced to column 0 (alignment.py:37)
+    prev[j] = j == 0 ? mas_load<PROB>(lp) : -INFINITY;  // first row forced to column 0 (alignment.py:37)
     bk[j] = 0;
   }
   __syncthreads();
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void mas_width1_kernel(
         pl = prev[j - 1];
         mv = 1;
       }
-      cur[j] = lp[(long long)i * T2 + j] + pl;
+      cur[j] = mas_load<PROB>(lp + (long long)i * T2 + j) + pl;
       bk[(long long)i * T2 + j] = mv;
     }
     __syncthreads();
@@ -234,7 +244,19 @@ extern "C" int radmmm_mas_width1(const float* logp, const int32_t* in_lens, cons
   RADMMM_REQUIRE(B > 0 && T1 > 0 && T2 > 0, "mas_width1: bad dims");
   const size_t smem = (size_t)2 * T2 * sizeof(float);
   RADMMM_REQUIRE(smem <= 64 * 1024, "mas_width1: T2=%d too long", T2);
-  hipLaunchKernelGGL(mas_width1_kernel, dim3(B), dim3(256), smem, static_cast<hipStream_t>(stream), logp,
+  hipLaunchKernelGGL(mas_width1_kernel<false>, dim3(B), dim3(256), smem, static_cast<hipStream_t>(stream), logp,
                      in_lens, out_lens, hard, static_cast<unsigned char*>(scratch), T1, T2);
   return radmmm::check_launch("mas_width1");
+}
+
+extern "C" int radmmm_mas_width1_prob(const float* attn, const int32_t* in_lens, const int32_t* out_lens,
+                                      float* hard, void* scratch, int B, int T1, int T2,
+                                      radmmm_stream_t stream) {
+  RADMMM_REQUIRE(attn && in_lens && out_lens && hard && scratch, "mas_width1_prob: null pointer");
+  RADMMM_REQUIRE(B > 0 && T1 > 0 && T2 > 0, "mas_width1_prob: bad dims");
+  const size_t smem = (size_t)2 * T2 * sizeof(float);
+  RADMMM_REQUIRE(smem <= 64 * 1024, "mas_width1_prob: T2=%d too long", T2);
+  hipLaunchKernelGGL(mas_width1_kernel<true>, dim3(B), dim3(256), smem, static_cast<hipStream_t>(stream), attn,
+                     in_lens, out_lens, hard, static_cast<unsigned char*>(scratch), T1, T2);
+  return radmmm::check_launch("mas_width1_prob");
 }

@@ -1,10 +1,28 @@
 #!/bin/bash
 # Build libradmmm_hip.so in-tree for gfx950 (cross-compiles without a GPU).
+# Every source is compiled to its own object (in parallel, rebuilt only when it or a header is
+# newer) under build/ and the objects are linked into one shared library.  Extra arguments are
+# passed to every compile (e.g. -DRADMMM_ABLATION); they are part of the cache key.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../libradmmm_hip.so"
+OUT="${RADMMM_OUT:-$HERE/../libradmmm_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=("$HERE"/*.hip "$HERE"/error.cpp)
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function)
-"$HIPCC" "${FLAGS[@]}" "${SRCS[@]}" -o "$OUT" "$@"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@")
+KEY="$(printf '%s ' "${FLAGS[@]}" | md5sum | cut -c1-8)"
+OBJ="$HERE/build/$KEY"
+mkdir -p "$OBJ"
+NEWEST_HDR="$(ls -t "$HERE"/*.h "$HERE/../../include"/*.h | head -1)"
+pids=()
+for src in "$HERE"/*.hip "$HERE"/error.cpp; do
+  o="$OBJ/$(basename "$src").o"
+  if [[ ! -f "$o" || "$src" -nt "$o" || "$NEWEST_HDR" -nt "$o" ]]; then
+    ( "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do
+  [[ -n "$p" ]] && wait "$p"
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT.tmp"
+mv "$OUT.tmp" "$OUT"
 echo "built $OUT"

@@ -478,13 +478,14 @@ class AttentionCoreFn(torch.autograd.Function):
         return gQ, gK, None, None, None
 
 
-def mas_width1_batch(logp: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.Tensor) -> torch.Tensor:
-    """logp [B,T1,T2] = log(attn) on the GPU -> 0/1 hard alignment [B,T1,T2] (alignment.py:31-59)."""
+def mas_width1_batch(logp: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.Tensor, prob: bool = False) -> torch.Tensor:
+    """logp [B,T1,T2] = log(attn) on the GPU (prob=True: the attention itself, the kernel takes the correctly rounded
+    fp32 log) -> 0/1 hard alignment [B,T1,T2] (alignment.py:31-59)."""
     B, T1, T2 = logp.shape
     hard = _empty(B, T1, T2, like=logp)
     scratch = torch.empty(int(lib.radmmm_mas_scratch_bytes(B, T1, T2)), device=logp.device, dtype=torch.uint8)
-    check(lib.radmmm_mas_width1(ptr(logp.contiguous()), ptr(in_lens), ptr(out_lens), ptr(hard), ptr(scratch), B, T1,
-                                T2, stream()), "mas_width1")
+    fn = lib.radmmm_mas_width1_prob if prob else lib.radmmm_mas_width1
+    check(fn(ptr(f32c(logp)), ptr(in_lens), ptr(out_lens), ptr(hard), ptr(scratch), B, T1, T2, stream()), "mas_width1")
     return hard
 
 

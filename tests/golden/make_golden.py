@@ -353,6 +353,11 @@ def main():
         mm = dict(radtts, n_text_dim=520, use_accent_emb_for_decoder=False, n_flows=4, n_splines=2,
                   use_bn=True)
         run_decoder("cfg5_small", mm, 2, 64, True, set())
+    if want("decoder_cfg3s"):
+        # BASELINE configs[2]: the shipped RADMMM decoder (configs/RADMMM_model_config.yaml:16-39): 8 affine flows,
+        # n_text_dim 520, accent embedding NOT fed to the decoder -> D = 1056, at a CPU-sized batch
+        run_decoder("cfg3_small", dict(radtts, n_text_dim=520, use_accent_emb_for_decoder=False, n_flows=8),
+                    2, 112, True, set())
 
     # ------------------------------------------------------------------ text Encoder (f1)
     if want("encoder"):

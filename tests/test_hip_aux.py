@@ -60,10 +60,14 @@ def test_mas_bit_exact(golden):
 
 
 def test_mas_full_size_properties():
-    """B=32, T_mel=800, T_txt=200 (benchmark scale): one 1 per mel frame, monotone, starts at
-    column 0 and ends at the last text index; identical to the oracle on two items."""
+    """B=32, T_mel=800, T_txt=200 (benchmark scale).  (1) Properties of the product path (binarize_attention): one 1
+    per mel frame, monotone, starts at column 0 and ends at the last text index.  (2) INDEX WORK, unconditional and
+    bit-exact for all 32 items: the device search on numpy's float32 log (the array the reference hands its numba loop,
+    alignment.py:36) equals the C oracle on the same array.  (3) The product path takes the correctly rounded fp32 log
+    inside the kernel: it equals the oracle's search on that log for all 32 items, and the number of alignments that
+    differ from the numpy-log ones (a last-bit log difference flipping an exact near-tie) is counted and printed."""
     from oracle import radmmm_oracle as O
-    from rad_mmm_amd.alignment import binarize_attention
+    from rad_mmm_amd.alignment import binarize_attention, mas_width1
     r = np.random.Generator(np.random.PCG64(5))
     B, T1, T2 = 32, 800, 200
     out_lens = np.sort(r.integers(500, T1 + 1, B))[::-1].copy()
@@ -79,13 +83,20 @@ def test_mas_full_size_properties():
         assert cols[0] == 0 and cols[-1] == in_lens[b] - 1
         assert ((np.diff(cols) == 0) | (np.diff(cols) == 1)).all()
         assert hard[b, out_lens[b]:].sum() == 0 and hard[b, :, in_lens[b]:].sum() == 0
-    for b in (0, 31):
-        # same float32 log as the device path would need identical libm; compare through the oracle
-        # on the device's own log to keep the check bit-exact
-        lp = torch.log(attn[b, 0, : out_lens[b], : in_lens[b]].to(DEV)).cpu().numpy()
-        ref = O.mas_width1(np.exp(lp.astype(np.float64)).astype(np.float32))  # round trip may differ by 1 ulp
-        if np.array_equal(np.log(np.exp(lp.astype(np.float64)).astype(np.float32)), lp):
-            assert np.array_equal(hard[b, : out_lens[b], : in_lens[b]], ref)
+    changed_items, changed_logs, total_logs = 0, 0, 0
+    for b in range(B):
+        a = attn[b, 0, : out_lens[b], : in_lens[b]].numpy().copy()
+        ref_np = O.mas_width1_c(a)                                   # numpy float32 log of this host + C search
+        assert np.array_equal(mas_width1(a, DEV), ref_np), b         # same host log -> device search: bit-exact
+        lp_rn = np.log(a.astype(np.float64)).astype(np.float32)      # correctly rounded fp32 log
+        ref_rn = O.mas_width1_c(a, logp=lp_rn)
+        assert np.array_equal(hard[b, : out_lens[b], : in_lens[b]], ref_rn), b
+        changed_items += int(not np.array_equal(ref_rn, ref_np))
+        changed_logs += int((lp_rn != np.log(a)).sum())
+        total_logs += a.size
+    print(f"MAS full size: numpy float32 log differs from the correctly rounded one in {changed_logs} of {total_logs} "
+          f"elements; alignments changed by that: {changed_items} of {B}")
+    assert changed_items <= 1
 
 
 def test_pq_spline_kernel_golden(golden):

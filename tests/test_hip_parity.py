@@ -374,7 +374,8 @@ def _build_decoder(g, precision="fp32"):
 
 @pytest.mark.parametrize("tag,precision", [("cfg1", "fp32"), ("cfg2_small", "fp32"), ("cfg5_small", "fp32"),
                                            ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3"),
-                                           ("cfg1", "h3-wide"), ("cfg2_small", "h3-wide"), ("cfg5_small", "h3-wide")])
+                                           ("cfg1", "h3-wide"), ("cfg2_small", "h3-wide"), ("cfg5_small", "h3-wide"),
+                                           ("cfg3_small", "fp32"), ("cfg3_small", "h3"), ("cfg3_small", "h3-wide")])
 def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     # "h3": also route the (small) FiLM convs through ConvNormH3Fn, which by default only takes frame-rate sizes.
     # Problems this small go to the 128 x 128 split-f16 kernel by default; "h3-wide" forces the one-workgroup-per-CU
@@ -386,6 +387,8 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     monkeypatch.setenv("RADMMM_PRECISION", precision)
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
     cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture;
+    cfg3_small = BASELINE configs[2], the shipped RADMMM decoder (configs/RADMMM_model_config.yaml:16-39: 8 affine
+    flows, n_text_dim 520, accent embedding not fed to the decoder, D = 1056);
     cfg5_small = config-5 architecture (RADMMM dims, 2 spline + 2 affine flows, masked batch-norm)."""
     from oracle import radmmm_oracle as O
     from rad_mmm_amd.common import SequenceLength
@@ -512,3 +515,62 @@ def test_decoder_full_size_item_independence(R):
     ldw = float(torch.stack(out["log_det_W_list"]).sum()) * Tv
     nll_i = (zsq - lss - ldw) / (Tv * 160)
     assert abs(nll_i - float(lo)) < 1e-4 * abs(float(lo))
+
+
+def test_decoder_full_size_backward_matches_oracle(R):
+    """BASELINE config 2 at its full size (8 flows, B=32, T=800 ragged): forward, NLL and the WHOLE backward against the
+    CPU oracle run on the same batch.  This is the only place the benchmark-shape launches are checked for gradient
+    parity: the MB=7 wide tile at M=12 800, wgrad_h3 with Kt ~ 13 k and its split-K slab sums, and the gradient scale
+    carried across 8 flows.  Bars: z / NLL 1e-4 (BASELINE north_star), gradients 5e-4 (same as the golden tests)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+              scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+              n_conv_layers_per_step=4, n_flows=8)
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    b = T(O.synthetic_batch(32, 800, cfg, 4321, ragged=True))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    mel = gb["mel"].clone().requires_grad_(True)
+    ctx = gb["context"].clone().requires_grad_(True)
+    out = dec(mel, gb["spk"], ctx, sl, gb["f0"], gb["energy"], gb["accent"])
+    lm = RADMMMLoss(n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    torch.cuda.synchronize()
+    # the oracle on the whole batch (torch-CPU autograd; ~10-20 s on the GPU box's host cores)
+    p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
+             and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
+    omel = b["mel"].clone().requires_grad_(True)
+    octx = b["context"].clone().requires_grad_(True)
+    ro = O.decoder_forward(p, cfg, omel, b["spk"], octx, b["lengths"], b["f0"], b["energy"], b["accent"])
+    lo, _ = O.decoder_loss(ro, b["lengths"], 2)
+    lo.backward()
+    ul = b["lengths"] // 2
+    m = (torch.arange(400)[None] < ul[:, None])[:, None]
+    zh, zo = out["z_mel"].detach().cpu(), ro["z_mel"].detach()
+    assert rel_err(zh * m, zo * m) < 1e-4
+    assert abs(float(lm) - float(lo)) < 1e-4 * abs(float(lo))
+    for a, c in zip(out["log_det_W_list"], ro["log_det_W_list"]):
+        assert abs(float(a) - float(c)) < 1e-4 * max(1.0, abs(float(c)))
+    assert rel_err(mel.grad.cpu(), omel.grad) < 5e-4
+    assert rel_err(ctx.grad.cpu(), octx.grad) < 5e-4
+    worst, worst_n, worst_el = 0.0, "", 0.0
+    for n, q in dec.named_parameters():
+        go = p[n].grad
+        gn = float(go.norm())
+        mine = float(q.grad.norm())
+        assert abs(mine - gn) < 5e-4 * gn + 2e-7, (n, mine, gn)
+        el = float((q.grad.cpu() - go).abs().max()) / (float(go.abs().max()) + 1e-12)
+        assert el < 5e-4 or float(go.abs().max()) < 1e-7, (n, el)
+        if abs(mine - gn) / (gn + 1e-6) > worst:
+            worst, worst_n = abs(mine - gn) / (gn + 1e-6), n
+        worst_el = max(worst_el, el)
+    print(f"full size: z rel {rel_err(zh * m, zo * m):.2e}, loss rel {abs(float(lm) - float(lo)) / abs(float(lo)):.2e}, "
+          f"worst grad-norm rel {worst:.2e} ({worst_n}), worst elementwise grad rel {worst_el:.2e}")

@@ -221,7 +221,7 @@ def test_mel_filterbank_selfcheck():
 
 
 @pytest.mark.parametrize("tag,n_flows,n_splines", [("cfg1", 2, 0), ("cfg2_small", 8, 0),
-                                                   ("cfg5_small", 4, 2)])
+                                                   ("cfg3_small", 8, 0), ("cfg5_small", 4, 2)])
 def test_full_decoder_procedural(golden, tag, n_flows, n_splines):
     """Full-width (WN 1024) decoder with procedural weights: oracle forward, NLL and
     gradients vs the reference run."""
