@@ -164,28 +164,6 @@ def time_wgrad_h3(N, T, reps=10):
     return out, 2.0 * N * 1024 * 5 * 1024
 
 
-def time_h3_probe(N, reps=20):
-    """EXPERIMENTAL: the same GEMM volume as the dominant kernel on the split-f16 path (no taps)."""
-    from rad_mmm_amd._lib import lib, check, ptr, stream
-    dev = torch.device("cuda", torch.cuda.current_device())
-    K = 5120
-    mk = lambda r: (torch.empty(r, K, dtype=torch.float16, device=dev).normal_(), torch.empty(r, K, dtype=torch.float16, device=dev).normal_(0, 1e-3))
-    (Ah, Al), (Bh, Bl) = mk(N), mk(1024)
-    C = torch.empty(N, 1024, device=dev)
-    run = lambda: check(lib.radmmm_h3gemm_nt(ptr(Ah), ptr(Al), K, ptr(Bh), ptr(Bl), K, ptr(C), 1024, N, 1024, K, 1.0,
-                                            stream()), "h3gemm")
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * K
-
-
 def time_wgrad_kernel(N, T, reps=10):
     """Average duration of the in_layer weight-gradient launch (5 taps, split-K as the step uses)."""
     from rad_mmm_amd import ops
@@ -260,8 +238,8 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="radtts",
@@ -273,7 +251,17 @@ def main():
                     help="also run the fused global-norm clip + RAdam update inside the timed step (NOT the BASELINE metric, "
                          "which is fwd+bwd only; reported with config.includes_optimizer = true)")
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
+    ap.add_argument("--dominant-only", action="store_true",
+                    help="launch only the roofline leg's kernel (the PMC passes of tools/pmc_dominant.sh wrap this)")
     args = ap.parse_args()
+    if args.dominant_only:
+        import rad_mmm_amd  # noqa: F401
+        torch.cuda.set_device(0)
+        N, Tg = args.batch * (args.frames // 2), args.frames // 2
+        hdur, hflop = time_dominant_kernel_h3(N, Tg)
+        print(json.dumps({"kernel": "rowgemm_h3 in_layer fwd", "M": N, "avg_launch_ms": hdur * 1e3,
+                          "fp32_equiv_tflops": hflop / hdur / 1e12}))
+        return
     if args.kernel_only:
         import rad_mmm_amd  # noqa: F401
         torch.cuda.set_device(0)
@@ -281,13 +269,6 @@ def main():
         kdur, kflop = time_dominant_kernel(N, Tg)
         print(json.dumps({"kernel": "rowgemm_f32 in_layer fwd", "M": N, "avg_launch_ms": kdur * 1e3,
                           "tflops": kflop / kdur / 1e12, "tile_env": os.environ.get("RADMMM_ROWGEMM_TILE", "16")}))
-        try:
-            hdur, hflop = time_h3_probe(N)
-            print(json.dumps({"kernel": "EXPERIMENTAL h3gemm_nt (split-f16 x3) M=%d N=1024 K=5120" % N,
-                              "avg_launch_ms": hdur * 1e3, "effective_tflops": hflop / hdur / 1e12,
-                              "mfma_tflops": 3 * hflop / hdur / 1e12}))
-        except Exception as e:  # the probe is optional
-            print(json.dumps({"kernel": "h3 probe", "error": str(e)}))
         wdur, wflop = time_wgrad_kernel(N, Tg)
         print(json.dumps({"kernel": "wgrad_f32 in_layer", "R": N, "avg_launch_ms": wdur * 1e3,
                           "tflops": wflop / wdur / 1e12}))
@@ -299,12 +280,26 @@ def main():
                           "fp32_equiv_tflops": wf / w1 / 1e12}))
         return
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("RADMMM_BENCH_SPAWN") == "1"):
+        # bare `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, through torch's
+        # launcher on the loopback address (the reference's Lightning `strategy: ddp`, `devices: auto` does the same:
+        # configs/RADMMM_train_config.yaml:10,28).  RADMMM_BENCH_SPAWN=1 takes this path at N = 1 too (RCCL at world
+        # size 1: the only multi-process check a 1-GPU box can run).
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"), RADMMM_FORCE_DIST="1")
+        sys.stdout.flush()
+        os.execvpe(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                    f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                    os.path.abspath(__file__), *sys.argv[1:]], env)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("RADMMM_FORCE_DIST") == "1"   # the latter: RCCL smoke test on 1 GPU
@@ -356,14 +351,20 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step HIP events on the compute stream (no synchronisation inside the timed region): the median step
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -376,24 +377,37 @@ def main():
         N = B * (T // cfg.n_group_size)
         h3 = dec.gemm_precision == "h3"
         if h3:
-            # split-f16 path: every fp32 product is three f16 MFMA products (Ah*Bh + Ah*Bl + Al*Bh), so the
-            # kernel executes 3x the fp32-equivalent flops on the f16 matrix cores; the roofline is the dense
-            # f16 MFMA peak and `achieved` counts the executed MFMA flops
+            # split-f16 path: every fp32 product is three f16 MFMA products (Ah*Bh + Ah*Bl + Al*Bh) on the f16 matrix
+            # cores.  `achieved` counts the ALGORITHMIC flops of the launch (2*M*N*K*taps) against the dense
+            # f16 MFMA peak the kernel runs on; `executed_*` counts the 3x MFMA flops really issued (pipe utilisation).
             kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size)
-            achieved, peak = 3.0 * kflop / kdur / 1e12, PEAK_F16_MFMA_TFLOPS
+            nprod, peak = 3.0, PEAK_F16_MFMA_TFLOPS
             kname = ("rowgemm_h3d_kernel<MB> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA products "
-                     "per fp32 product; PMC of this launch: profiles/r01_pmc_h3d.txt)") % N
+                     "per fp32 product)") % N
             prec = "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)"
         else:
             kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)
-            achieved, peak = kflop / kdur / 1e12, PEAK_FP32_MFMA_TFLOPS
+            nprod, peak = 1.0, PEAK_FP32_MFMA_TFLOPS
             kname = "rowgemm_f32_kernel<0> (WN in_layer conv fwd, M=%d N=1024 K=5x1024)" % N
             prec = "fp32 MFMA"
+        achieved = kflop / kdur / 1e12
+        # HBM-side bytes per launch: PMC counters need rocprofv3 around the process, so they cannot be read in-run;
+        # tools/pmc_dominant.sh measures this same launch (FETCH_SIZE / WRITE_SIZE in their own passes, the guide's
+        # gfx950 corrections) and writes profiles/pmc_dominant.json, which is quoted here and labelled static
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_dominant.json")) as f:
+                pm = json.load(f)
+            if h3 and pm.get("M") == N:
+                traffic, traffic_src = pm["traffic_bytes_per_launch"], pm["source"]
+        except Exception:
+            pass
         fl = algorithmic_flops_per_frame(cfg)
         by = algorithmic_bytes_per_frame(cfg) + 3 * 4 * sum(p.numel() for p in dec.parameters()) / (B * T)
         res = {
             "metric": "mel-frames/sec training step (fwd+bwd)", "value": frames_per_s, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (procedural random-init weights, N(2.5,0.5) mel, fixed length)",
             "config": {"workload": ("RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
@@ -404,20 +418,20 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec,
                        "includes_optimizer": bool(args.optimizer)},
             "loss_mel": loss_val,
+            "distributed": {"backend": dist.get_backend() if use_dist else None, "process_group": bool(use_dist),
+                            "gradient_buckets": len(reducer.buckets), "gradient_bytes_per_step": reducer.total_bytes,
+                            "gemm_cu_budget": os.environ.get("RADMMM_GEMM_CUS")},
             "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "avg_launch_ms": kdur * 1e3,
-                         "flop_per_launch": (3.0 if h3 else 1.0) * kflop, "fp32_equiv_tflops": kflop / kdur / 1e12,
-                         # memory-side bytes per launch from the separate --pmc passes over this same launch
-                         # (profiles/r01_pmc_h3d.txt): FETCH_SIZE 2.235e5 KiB x2 (gfx950 correction for 16 B/lane
-                         # loads) + WRITE_SIZE 1.024e5 KiB; algorithmic operand + output bytes: 1.78e8
-                         "traffic": (2.235e5 * 2 + 1.024e5) * 1024 if (h3 and N == 12800) else None,
-                         "traffic_source": "profiles/r01_pmc_h3d.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes)"
-                         if (h3 and N == 12800) else None,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "frac_algorithmic": achieved / peak, "frac_executed": nprod * achieved / peak,
+                         "avg_launch_ms": kdur * 1e3, "flop_per_launch": kflop, "executed_mfma_flop_per_launch": nprod * kflop,
+                         "executed_mfma_tflops": nprod * achieved,
+                         "algorithmic_bytes_per_launch": (N * 1024 * 4 + 5 * 1024 * 1024 * 4 + N * 1024 * 4) if h3 else None,
+                         "traffic": traffic, "traffic_static": traffic is not None, "traffic_source": traffic_src,
                          # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
                          # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
                          "peak_measured_random_operands": 1620.0 if h3 else None,
-                         "frac_of_measured_peak": (achieved / 1620.0) if h3 else None},
+                         "frac_executed_of_measured_peak": (nprod * achieved / 1620.0) if h3 else None},
             "step_flops": {"algorithmic_tflop_per_step": fl * B * T / 1e12,
                            "achieved_tflops_per_gpu": fl * B * T / (ms_per_step * 1e-3) / 1e12,
                            "frac_of_fp32_mfma_peak": fl * B * T / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},

@@ -300,11 +300,10 @@ int radmmm_stft_mel(const float* audio, const float* basis, const float* mel_bas
 int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_mel);
 
 /* ------------------------------------------------------------------------------------
- * Split-f16 support (radmmm_rowgemm_h3's operands) and the plain NT probe GEMM: fp32-class GEMM on the f16 matrix
+ * Split-f16 support (radmmm_rowgemm_h3's operands): fp32-class GEMM on the f16 matrix
  * cores by operand splitting (x*scale = hi + lo in fp16; A.B ~= Ah.Bh + Ah.Bl + Al.Bh with fp32
- * accumulate).  radmmm_split_f16 writes hi/lo [rows][ldh] halves (ldh % 8 == 0, zero padded);
- * radmmm_h3gemm_nt computes C[M,N] = out_scale * (A B^T) from K-contiguous split operands
- * (K % 32 == 0).  See DESIGN.md §8 for the measured rate and error.
+ * accumulate).  radmmm_split_f16 writes hi/lo [rows][ldh] halves (ldh % 8 == 0, zero padded).
+ * See DESIGN.md §4.2 for the measured rate and error.
  * ------------------------------------------------------------------------------------ */
 int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int ldh, int rows, int cols,
                      float scale, radmmm_stream_t stream);
@@ -317,9 +316,10 @@ int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl,
 int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, int64_t src_batch,
                               void* dst_h, void* dst_l, int ld_dst, int64_t dst_batch, int batches,
                               int rows, int cols, radmmm_stream_t stream);
-int radmmm_h3gemm_nt(const void* Ah, const void* Al, int lda, const void* Bh, const void* Bl, int ldb,
-                     float* C, int ldc, int M, int N, int K, float out_scale,
-                     radmmm_stream_t stream);
+/* Workgroup slots the GEMM grids are sized for: the device's CU count, or RADMMM_GEMM_CUS (32 .. CUs; read once
+ * per process) when data-parallel runs leave CUs to RCCL's channel kernels (Lightning `strategy: ddp`,
+ * configs/RADMMM_train_config.yaml:28; rad_mmm_amd/ddp.py reserve_collective_cus). */
+int radmmm_gemm_cu_slots(void);
 
 /* Weight gradient on the split-f16 path.  Operands are transposed, time-contiguous, zero-gapped
  * split copies made by radmmm_transpose_split_act from channels-last fp32 [B*T][ld]:

@@ -80,6 +80,8 @@ def _load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.radmmm_last_error.restype = C.c_char_p
     lib.radmmm_abi_version.restype = C.c_int
+    lib.radmmm_gemm_cu_slots.restype = C.c_int
+    lib.radmmm_gemm_cu_slots.argtypes = []
     if lib.radmmm_abi_version() != 1:
         raise ImportError("libradmmm_hip.so ABI version mismatch")
     i, i64, p = C.c_int, C.c_int64, C.c_void_p
@@ -121,7 +123,6 @@ def _load() -> C.CDLL:
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],
-        "radmmm_h3gemm_nt": [p, p, i, p, p, i, p, i, i, i, i, f, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],

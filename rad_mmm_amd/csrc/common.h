@@ -17,6 +17,7 @@ int launch_wgrad16(const radmmm_wgrad_desc& d, hipStream_t stream);
 
 // rowgemm_h3w.hip: wide-tile (32*MB x 256, one workgroup per CU) split-f16 conv GEMM
 int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
+int gemm_cu_slots();
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -138,240 +138,14 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
   }
 }
 
-// The K step as one software pipeline of 2*MB "items" (k block kb = t / MB, row block i = t % MB):
-//   item t:  ds_read A fragments of item t + D | 6 MFMAs of item t | 2 staging ds_writes (t < NW)
-// plus the B fragments of the second k block D items before they are needed and, once the staging
-// registers are free (t == NW), the 16 buffer loads of the tile two steps ahead.  The instruction
-// order is pinned with sched_group_barrier; without it the scheduler keeps a single ds_read in
-// flight and every MFMA group waits for LDS (measured: 39 % MFMA busy inside a workgroup).
-constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100, SGB_DSW = 0x200;
-#ifndef H3_LOOKAHEAD
-#define H3_LOOKAHEAD 2
-#endif
-#ifndef H3_DPI
-#define H3_DPI 2        // DMA pieces issued per pipeline item
-#endif
-constexpr int LOOKAHEAD = H3_LOOKAHEAD, DPI = H3_DPI;
-
-template <int MB, int T>
-__device__ __forceinline__ void pin_items() {
-  constexpr int NT = 2 * MB, NW = (MB + 1) / 2 + 4;
-  if constexpr (T < NT) {
-    if constexpr (T + LOOKAHEAD < NT) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
-    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 6, 0);
-    if constexpr (T < NW) __builtin_amdgcn_sched_group_barrier(SGB_DSW, 2, 0);
-    if constexpr (T == NW) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 2 * ((MB + 1) / 2) + 8, 0);
-    pin_items<MB, T + 1>();
-  }
-}
-
-// ABL: ablation bits for bottleneck hunting (results are wrong when != 0): 1 no global loads,
-// 2 no staging stores, 4 no fragment reads, 8 no MFMAs inside the K loop.
-template <int MB, int ABL = 0, bool FASTEPI = false>
-__global__ __launch_bounds__(256, 1) void rowgemm_h3w_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
-                                                              const int b_bytes) {
-  using G = Geo<MB>;
-  constexpr int NT = 2 * MB, NW = G::AI + 4, D = LOOKAHEAD;
-  constexpr bool DO_LOAD = !(ABL & 1), DO_STORE = !(ABL & 2), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
-  static_assert(NW < NT && D <= MB, "pipeline shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  const radmmm_rowgemm_desc& p = q.base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BMR - 1) / G::BMR;
-  const int nt = ntn * ntm, wg = blockIdx.x;
-  const int xcd = wg & 7, loc = wg >> 3, qq = nt >> 3, r8 = nt & 7;
-  const int tile = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int m0 = tm * G::BMR, n0 = tn * BN;
-  const int kpt = p.K / BK;
-  const int nsteps = kpt * p.taps;
-
-  // staging: thread -> row (tid >> 2) + 64 i, 16-byte chunk (tid & 3); the chunk lands in LDS slot
-  // chunk ^ ((row >> 2) & 3), and 64 i does not touch row bits 2..3.  Odd MB: the last A pass has
-  // only 32 rows; the other 32 threads-rows write to a dump area behind the two stages instead
-  // of branching (a branch would split the pinned schedule).
-  const int s_row = tid >> 2, s_chunk = tid & 3;
-  const int s_lds = s_row * ROWB + ((s_chunk ^ ((s_row >> 2) & 3)) << 4);
-  int a_t[G::AI], a_lim[G::AI], a_base[G::AI], b_voff[4];
-#pragma unroll
-  for (int i = 0; i < G::AI; ++i) {
-    const int rl = s_row + 64 * i;
-    const int r = m0 + rl;
-    a_t[i] = 0;
-    a_lim[i] = -1;                                       // no frame passes "ts < a_lim"
-    a_base[i] = 0;
-    if (rl < G::BMR && r < p.M) {
-      const int b = r / p.T;
-      a_t[i] = r - b * p.T;
-      a_lim[i] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
-      a_base[i] = (b * p.T * q.lda_h + s_chunk * 8) * 2;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + s_row + 64 * i;
-    b_voff[i] = n < p.N ? (n * q.ldb_h + s_chunk * 8) * 2 : OOB;
-  }
-  const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Ah), 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Al), 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bh), 0, b_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bl), 0, b_bytes, 0x00020000);
-
-  struct Regs {
-    u32x4 a[2][G::AI];
-    u32x4 b[2][4];
-  };
-  // branch-free: the frame shift of tap `tap` is applied to every load (a few VALU ops per step)
-  auto load_tiles = [&](int tap, int kb, Regs& R) __attribute__((always_inline)) {
-    const int s = p.sign * (tap - p.taps / 2) * p.dil;
-    const int so_a = kb * (BK * 2);
-    const int so_b = (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
-#pragma unroll
-    for (int i = 0; i < G::AI; ++i) {
-      const int ts = a_t[i] + s;
-      const int vo = (ts >= 0 && ts < a_lim[i]) ? a_base[i] + ts * q.lda_h * 2 : OOB;
-      R.a[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rAh, vo, so_a, 0);
-      R.a[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rAl, vo, so_a, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      R.b[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rBh, b_voff[i], so_b, 0);
-      R.b[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rBl, b_voff[i], so_b, 0);
-    }
-  };
-  // staging store piece w of 0 .. AI+3 (two ds_write_b128 each): A pass w, then B pass w - AI
-  const int dump = 2 * G::STAGE + (s_row & 31) * ROWB + (s_chunk << 4);
-  auto store_piece = [&](int buf, int w, const Regs& R) __attribute__((always_inline)) {
-    unsigned char* st = sm + buf * G::STAGE + s_lds;
-    if (w < G::AI) {
-      unsigned char* d0 = st + w * 64 * ROWB;
-      unsigned char* d1 = d0 + G::A_BYTES;
-      if ((MB & 1) && w == G::AI - 1) {                    // 32 real rows in this pass
-        const bool real = s_row < 32;
-        d0 = real ? d0 : sm + dump;
-        d1 = real ? d1 : sm + dump + 2048;
-      }
-      *reinterpret_cast<u32x4*>(d0) = R.a[0][w];
-      *reinterpret_cast<u32x4*>(d1) = R.a[1][w];
-    } else {
-      const int i = w - G::AI;
-      *reinterpret_cast<u32x4*>(st + 2 * G::A_BYTES + i * 64 * ROWB) = R.b[0][i];
-      *reinterpret_cast<u32x4*>(st + 2 * G::A_BYTES + G::B_BYTES + i * 64 * ROWB) = R.b[1][i];
-    }
-  };
-
-  f32x16 acc[MB][2];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment of a 16-deep k block kb: lane l holds row (l & 31), chunk 2 kb + (l >> 5)
-  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3;
-  const int f_off0 = f_row + (((0 + (lane >> 5)) ^ f_swz) << 4);
-  const int f_off1 = f_row + (((2 + (lane >> 5)) ^ f_swz) << 4);
-
-  // (tap, kb) of the tile two steps ahead, advanced without divisions; clamped to the last tile
-  int l_tap = 0, l_kb = 0;
-  auto advance = [&]() __attribute__((always_inline)) {
-    const bool last = (l_tap == p.taps - 1) && (l_kb == kpt - 1);
-    const bool wrap = l_kb == kpt - 1;
-    l_kb = last ? l_kb : (wrap ? 0 : l_kb + 1);
-    l_tap = (wrap && !last) ? l_tap + 1 : l_tap;
-  };
-  Regs R;
-  load_tiles(0, 0, R);
-#pragma unroll
-  for (int w = 0; w < NW; ++w) store_piece(0, w, R);
-  advance();
-  load_tiles(l_tap, l_kb, R);                        // tile 1 (or tile 0 again if there is only one)
-  __syncthreads();
-  f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
-  if constexpr (!DO_READ) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      fah[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16);
-      fal[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16 + 512);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bh[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 20000 + t * 1024 + lane * 16);
-      bl[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 30000 + t * 1024 + lane * 16);
-    }
-  }
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    advance();                                       // -> tile step + 2
-    const unsigned char* st = sm + buf * G::STAGE;
-    const unsigned char* sB = st + 2 * G::A_BYTES + wave * 64 * ROWB;
-    auto read_a = [&](int t) __attribute__((always_inline)) {
-      if constexpr (!DO_READ) return;
-      const int fo = (t >= MB) ? f_off1 : f_off0;
-      const int i = t >= MB ? t - MB : t;
-      fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
-      fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
-    };
-    auto read_b = [&](int kb) __attribute__((always_inline)) {
-      if constexpr (!DO_READ) return;
-      const int fo = kb ? f_off1 : f_off0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
-        bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
-      }
-    };
-    read_b(0);
-#pragma unroll
-    for (int t = 0; t < D; ++t) read_a(t);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t + D < NT) read_a(t + D);
-      if (t + D == MB) read_b(1);
-      const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
-      if constexpr (DO_MFMA) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
-      } else {
-        asm volatile("" ::"v"(fah[t]), "v"(fal[t]), "v"(bh[kb][0]), "v"(bh[kb][1]), "v"(bl[kb][0]), "v"(bl[kb][1]));
-      }
-      if (DO_STORE && t < NW) store_piece(buf ^ 1, t, R);   // tile step + 1, loaded during the previous step
-      if (DO_LOAD && t == NW) load_tiles(l_tap, l_kb, R);   // tile step + 2
-    }
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, 4 + 2 * D, 0);
-    pin_items<MB, 0>();
-    __syncthreads();
-  }
-
-  // ---- epilogue: one 32-row block at a time through LDS ([32][256] fp32 = 32 KiB).  The per-row
-  // factors (length mask, partial-conv ratio: an integer division and a dependent lens[] load each)
-  // are computed once per row into LDS and the bias of this thread's 4 columns is kept in
-  // registers: with one workgroup per CU nothing else hides the latency of loads in this tail.
-  const radmmm::EpilogueCtx ec(p);
-  float* smf = reinterpret_cast<float*>(sm);
-  float2* rowf = reinterpret_cast<float2*>(sm + 32768);
-  if (tid < G::BMR) {
-    float mk, rt;
-    radmmm::epilogue_row_factors(p, ec, m0 + tid, mk, rt);
-    rowf[tid] = make_float2(mk, rt);
-  }
-  float biasv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
-    const int c = n0 + (tid & 63) * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
-  }
-  epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
-}
+// instruction-order pinning of the K step (sched_group_barrier masks); without it the scheduler keeps a single
+// ds_read in flight and every MFMA group waits for LDS (measured: 39 % MFMA busy inside a workgroup)
+constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100;
+constexpr int LOOKAHEAD = 2;    // fragment look-ahead in pipeline items
+constexpr int DPI = 2;          // DMA pieces issued per pipeline item
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-DMA variant: the operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), no
+// LDS-DMA staging: the operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), no
 // staging registers and no ds_write instructions.  A wave instruction writes 1 KiB = 16 LDS rows
 // lane-linearly (lane l -> row l >> 2, 16-byte slot l & 3), so the XOR swizzle is applied on the
 // SOURCE side: lane l fetches chunk (l & 3) ^ ((l >> 4) & 3) of its row.  Out-of-range lanes (rows
@@ -411,13 +185,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
-template <int MB, int ABL = 0, int PR = 3, bool FASTEPI = false>
+template <int MB, int PR = 3, bool FASTEPI = false>
 __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
                                                               const int b_bytes) {
   using G = Geo<MB>;
   constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB;                // NG: 16-row groups of an A array
   constexpr int NPA = Pieces<MB, PR>::A, NP = Pieces<MB, PR>::N;        // DMA pieces per wave
-  constexpr bool DO_LOAD = !(ABL & 1), DO_READ = !(ABL & 4), DO_MFMA = !(ABL & 8);
   static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP && (PR == 1 || PR == 3), "pipeline shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
@@ -517,21 +290,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   for (int w = 0; w < NP; ++w) dma_piece(0, w, 0, 0);
   __syncthreads();
   f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
-  if constexpr (!DO_READ) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      fah[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16);
-      fal[t] = *reinterpret_cast<const f16x8*>(sm + t * 1024 + lane * 16 + 512);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bh[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 20000 + t * 1024 + lane * 16);
-      bl[t >> 1][t & 1] = *reinterpret_cast<const f16x8*>(sm + 30000 + t * 1024 + lane * 16);
-    }
-  }
   // fragment readers of LDS stage `bsel`
   auto read_a = [&](int bsel, int t) __attribute__((always_inline)) {
-    if constexpr (!DO_READ) return;
     const unsigned char* st = sm + bsel * G::STAGE;
     const int fo = (t >= MB) ? f_off1 : f_off0;
     const int i = t >= MB ? t - MB : t;
@@ -539,7 +299,6 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     if constexpr (PR == 3) fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
   };
   auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
-    if constexpr (!DO_READ) return;
     const unsigned char* sB = sm + bsel * G::STAGE + 2 * G::A_BYTES + wave * 64 * ROWB;
     const int fo = kb ? f_off1 : f_off0;
 #pragma unroll
@@ -550,18 +309,16 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   };
   auto mfma_item = [&](int t) __attribute__((always_inline)) {
     const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
-    if constexpr (DO_MFMA && PR == 1) {
+    if constexpr (PR == 1) {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
-    } else if constexpr (DO_MFMA) {
+    } else {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bl[kb][1], acc[i][1], 0, 0, 0);
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
-    } else {
-      asm volatile("" ::"v"(fah[t]), "v"(fal[t]), "v"(bh[kb][0]), "v"(bh[kb][1]), "v"(bl[kb][0]), "v"(bl[kb][1]));
     }
   };
   // first fragments of step 0; every later step gets them from the tail of the previous one
@@ -578,11 +335,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
       read_a(buf, t + D);
       if (t + D == MB) read_b(buf, 1);
       mfma_item(t);
-      if constexpr (DO_LOAD) {
 #pragma unroll
-        for (int q = 0; q < DPI; ++q)
-          if (DPI * t + q < NP) dma_piece(buf ^ 1, DPI * t + q, l_tap, l_kb);
-      }
+      for (int q = 0; q < DPI; ++q)
+        if (DPI * t + q < NP) dma_piece(buf ^ 1, DPI * t + q, l_tap, l_kb);
     }
     pin_items_dma<MB, 0, PR>();
     // every read of stage `buf` has been issued: retire them and this wave's DMA, meet the other
@@ -617,11 +372,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
 }
 
-template <int MB, int ABL = 0, int PR = 3, bool FASTEPI = false>
+template <int MB, int PR = 3, bool FASTEPI = false>
 int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = Geo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, ABL, PR, FASTEPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3d_kernel<MB, PR, FASTEPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_h3d<%d>): %s", MB, hipGetErrorString(e));
@@ -632,27 +387,8 @@ int launch_dma(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, ABL, PR, FASTEPI>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_h3d_kernel<MB, PR, FASTEPI>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_h3d");
-}
-
-template <int MB, int ABL = 0>
-int launch(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
-  using G = Geo<MB>;
-  static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3w_kernel<MB, ABL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
-    if (e != hipSuccess) {
-      radmmm::set_error("hipFuncSetAttribute(rowgemm_h3w<%d>): %s", MB, hipGetErrorString(e));
-      return -2;
-    }
-    return 0;
-  }();
-  if (once) return once;
-  const radmmm_rowgemm_desc& p = d.base;
-  const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_h3w_kernel<MB, ABL>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
-  return radmmm::check_launch("rowgemm_h3w");
 }
 
 }  // namespace
@@ -680,91 +416,58 @@ int pick_h3w_mb(int M, int N, int slots) {
   return best;
 }
 
-int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+// Workgroup slots a GEMM grid is sized for: the device's CUs, or RADMMM_GEMM_CUS when set (data-parallel runs
+// leave a few CUs to RCCL's channel kernels so that an all-reduce landing during a GEMM launch does not push the
+// grid into a second round: rad_mmm_amd/ddp.py reserve_collective_cus).  Read once per process.
+int gemm_cu_slots() {
   static const int slots = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
-    return n > 0 ? n : 256;
+    if (const char* e = getenv("RADMMM_GEMM_CUS")) {
+      const int v = atoi(e);
+      if (v >= 32 && v <= n) n = v;
+    }
+    return n;
   }();
-  int mb = pick_h3w_mb(d.base.M, d.base.N, slots);
+  return slots;
+}
+
+int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  int mb = pick_h3w_mb(d.base.M, d.base.N, gemm_cu_slots());
   if (const char* e = getenv("RADMMM_H3W_MB")) {
     const int v = atoi(e);
     if (v >= 4 && v <= 8) mb = v;
   }
-  // default: LDS-DMA staging (rowgemm_h3d_kernel); RADMMM_H3W_DMA=0 selects the register-staged variant
-  static const bool dma = [] {
-    const char* e = getenv("RADMMM_H3W_DMA");
-    return !(e && atoi(e) == 0);
-  }();
-  if (dma) {
-#ifdef RADMMM_ABLATION
-    if (const char* e = getenv("RADMMM_H3W_ABL")) {
-      switch (atoi(e)) {
-        case 1: return launch_dma<7, 1>(d, stream, a_bytes, b_bytes);
-        case 4: return launch_dma<7, 4>(d, stream, a_bytes, b_bytes);
-        case 5: return launch_dma<7, 5>(d, stream, a_bytes, b_bytes);
-        case 8: return launch_dma<7, 8>(d, stream, a_bytes, b_bytes);
-        case 12: return launch_dma<7, 12>(d, stream, a_bytes, b_bytes);
-        case 13: return launch_dma<7, 13>(d, stream, a_bytes, b_bytes);
-        case 15: return launch_dma<7, 15>(d, stream, a_bytes, b_bytes);
-        default: break;
-      }
-    }
-#endif
-    // lean epilogue (16-byte accesses, 32-bit element offsets) when every output / side input allows it
-    const radmmm_rowgemm_desc& p = d.base;
-    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    auto fits = [&](long long ld) { return (long long)p.M * ld < 0x7fffffffLL; };
-    const bool fast = p.N % 4 == 0 && p.ldc % 4 == 0 && a16(p.C) && fits(p.ldc) &&
-                      (!p.add || (p.ldadd % 4 == 0 && a16(p.add) && fits(p.ldadd))) &&
-                      (!p.dact || (p.lddact % 4 == 0 && a16(p.dact_src) && fits(p.lddact))) &&
-                      (!p.C2 || (p.ldc2 % 4 == 0 && a16(p.C2) && fits(p.ldc2))) &&
-                      (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && (reinterpret_cast<uintptr_t>(p.Ch) & 7) == 0 &&
-                                 (reinterpret_cast<uintptr_t>(p.Cl) & 7) == 0)) &&
-                      (!p.C2h || (p.ldc2h % 4 == 0 && fits(p.ldc2h) && (reinterpret_cast<uintptr_t>(p.C2h) & 7) == 0 &&
-                                  (reinterpret_cast<uintptr_t>(p.C2l) & 7) == 0));
-#define RADMMM_H3D_CASE(MBV, PRV)                                                       \
-  case MBV:                                                                             \
-    return fast ? launch_dma<MBV, 0, PRV, true>(d, stream, a_bytes, b_bytes)            \
-                : launch_dma<MBV, 0, PRV, false>(d, stream, a_bytes, b_bytes);
-    if (d.nprod == 1) {                                // 16-bit throughput mode: hi halves only
-      switch (mb) {
-        RADMMM_H3D_CASE(4, 1) RADMMM_H3D_CASE(5, 1) RADMMM_H3D_CASE(6, 1) RADMMM_H3D_CASE(7, 1)
-        default: return fast ? launch_dma<8, 0, 1, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 0, 1, false>(d, stream, a_bytes, b_bytes);
-      }
-    }
+  // lean epilogue (16-byte accesses, 32-bit element offsets) when every output / side input allows it
+  const radmmm_rowgemm_desc& p = d.base;
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  auto a8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+  auto fits = [&](long long ld) { return (long long)p.M * ld < 0x7fffffffLL; };
+  const bool fast = p.N % 4 == 0 && p.ldc % 4 == 0 && a16(p.C) && fits(p.ldc) &&
+                    (!p.add || (p.ldadd % 4 == 0 && a16(p.add) && fits(p.ldadd))) &&
+                    (!p.dact || (p.lddact % 4 == 0 && a16(p.dact_src) && fits(p.lddact))) &&
+                    (!p.C2 || (p.ldc2 % 4 == 0 && a16(p.C2) && fits(p.ldc2))) &&
+                    (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && a8(p.Ch) && a8(p.Cl))) &&
+                    (!p.C2h || (p.ldc2h % 4 == 0 && fits(p.ldc2h) && a8(p.C2h) && a8(p.C2l)));
+#define RADMMM_H3D_CASE(MBV, PRV)                                                 \
+  case MBV:                                                                       \
+    return fast ? launch_dma<MBV, PRV, true>(d, stream, a_bytes, b_bytes)         \
+                : launch_dma<MBV, PRV, false>(d, stream, a_bytes, b_bytes);
+  if (d.nprod == 1) {                                // 16-bit throughput mode: hi halves only
     switch (mb) {
-      RADMMM_H3D_CASE(4, 3) RADMMM_H3D_CASE(5, 3) RADMMM_H3D_CASE(6, 3) RADMMM_H3D_CASE(7, 3)
-      default: return fast ? launch_dma<8, 0, 3, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 0, 3, false>(d, stream, a_bytes, b_bytes);
-    }
-#undef RADMMM_H3D_CASE
-  }
-#ifdef RADMMM_ABLATION
-  if (const char* e = getenv("RADMMM_H3W_ABL")) {
-    switch (atoi(e)) {
-      case 1: return launch<7, 1>(d, stream, a_bytes, b_bytes);
-      case 2: return launch<7, 2>(d, stream, a_bytes, b_bytes);
-      case 3: return launch<7, 3>(d, stream, a_bytes, b_bytes);
-      case 4: return launch<7, 4>(d, stream, a_bytes, b_bytes);
-      case 7: return launch<7, 7>(d, stream, a_bytes, b_bytes);
-      case 8: return launch<7, 8>(d, stream, a_bytes, b_bytes);
-      case 11: return launch<7, 11>(d, stream, a_bytes, b_bytes);
-      case 12: return launch<7, 12>(d, stream, a_bytes, b_bytes);
-      case 14: return launch<7, 14>(d, stream, a_bytes, b_bytes);
-      case 15: return launch<7, 15>(d, stream, a_bytes, b_bytes);
-      default: break;
+      RADMMM_H3D_CASE(4, 1) RADMMM_H3D_CASE(5, 1) RADMMM_H3D_CASE(6, 1) RADMMM_H3D_CASE(7, 1)
+      default: return fast ? launch_dma<8, 1, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 1, false>(d, stream, a_bytes, b_bytes);
     }
   }
-#endif
   switch (mb) {
-    case 4: return launch<4>(d, stream, a_bytes, b_bytes);
-    case 5: return launch<5>(d, stream, a_bytes, b_bytes);
-    case 6: return launch<6>(d, stream, a_bytes, b_bytes);
-    case 7: return launch<7>(d, stream, a_bytes, b_bytes);
-    default: return launch<8>(d, stream, a_bytes, b_bytes);
+    RADMMM_H3D_CASE(4, 3) RADMMM_H3D_CASE(5, 3) RADMMM_H3D_CASE(6, 3) RADMMM_H3D_CASE(7, 3)
+    default: return fast ? launch_dma<8, 3, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 3, false>(d, stream, a_bytes, b_bytes);
   }
+#undef RADMMM_H3D_CASE
 }
 
 }  // namespace radmmm
+
+extern "C" int radmmm_gemm_cu_slots(void) { return radmmm::gemm_cu_slots(); }

@@ -596,7 +596,7 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     xh, xl, x1h, x1l, Kt2 = x_t
     assert Kt == Kt2
     tiles = int(lib.radmmm_wgrad_h3_tiles(Mc, Nc, taps))
-    S = pick_splits(tiles, Kt, slots=256)            # one workgroup per CU
+    S = pick_splits(tiles, Kt, slots=int(lib.radmmm_gemm_cu_slots()))            # one workgroup per CU
     if os.environ.get("RADMMM_WGRAD_SPLITS"):         # experiments
         S = int(os.environ["RADMMM_WGRAD_SPLITS"])
     P = torch.empty(S, taps, Mc, ldp, device=gh.device, dtype=torch.float32)

@@ -1,5 +1,5 @@
-"""EXPERIMENTAL probe: split-fp16 (hi/lo) GEMM on the f16 matrix cores -- accuracy vs fp64 and vs
-the fp32-MFMA kernel, so the numbers in DESIGN.md §8 are reproducible."""
+"""Accuracy of the split-fp16 (hi/lo) GEMM on the f16 matrix cores (radmmm_rowgemm_h3) vs fp64 and vs the
+fp32-MFMA kernel, so the numbers in DESIGN.md §4.2 are reproducible."""
 import numpy as np
 import pytest
 import torch
@@ -22,7 +22,7 @@ def _split(x, scale):
 
 @pytest.mark.parametrize("M,N,K,wscale", [(256, 128, 64, 256.0), (300, 200, 1024, 256.0), (1280, 1024, 5120, 256.0)])
 def test_h3gemm_accuracy(M, N, K, wscale):
-    from rad_mmm_amd._lib import lib, check, ptr, stream, rowgemm
+    from rad_mmm_amd._lib import rowgemm, rowgemm_h3
     g = torch.Generator().manual_seed(K)
     A = torch.nn.functional.softplus(torch.randn(M, K, generator=g) * 2).to(DEV)       # activations-like
     Bw = (torch.randn(N, K, generator=g) * 0.03).to(DEV)                                # weights-like
@@ -30,8 +30,8 @@ def test_h3gemm_accuracy(M, N, K, wscale):
     Bh, Bl = _split(Bw, wscale)
     assert rel_err((Ah.float() + Al.float())[:, :K].cpu(), A.cpu()) < 1e-6
     C = torch.full((M, N), float("nan"), device=DEV)
-    check(lib.radmmm_h3gemm_nt(ptr(Ah), ptr(Al), Ah.shape[1], ptr(Bh), ptr(Bl), Bh.shape[1], ptr(C), N, M, N, K,
-                               1.0 / wscale, stream()), "h3gemm")
+    rowgemm_h3(Ah=Ah, Al=Al, lda_h=Ah.shape[1], Bh=Bh, Bl=Bl, ldb_h=Bh.shape[1], acc_scale=1.0 / wscale, C=C, ldc=N, M=M, N=N,
+               K=K, T=M)
     ref = A.double().cpu() @ Bw.double().cpu().t()
     e_h3 = rel_err(C.cpu().double(), ref)
     C32 = torch.empty(M, N, device=DEV)
