@@ -45,6 +45,22 @@ enum { RADMMM_ACT_NONE = 0, RADMMM_ACT_SOFTPLUS = 1, RADMMM_ACT_RELU = 2, RADMMM
 enum { RADMMM_SCALE_TANH = 0, RADMMM_SCALE_EXP = 1, RADMMM_SCALE_SIGMOID = 2, RADMMM_SCALE_TRANSLATE = 3 };
 
 /* ------------------------------------------------------------------------------------
+ * Split formats of the row-major operand copies (one K-contiguous row per frame / output channel):
+ *   RADMMM_SPLIT_F16  two half arrays [rows][ld]: hi = fp16(t), lo = fp16(t - hi), t = scale * x clamped to +-60000
+ *   RADMMM_SPLIT_X8A  hi as above + the 8-bit CROSS array in place of lo, same row pitch (2*ld bytes), ld % 32 == 0:
+ *                     per 32 columns 64 bytes [ e4m3(t * 2^e) x 32 | e4m3((t - hi) * 2^(11+e)) x 32 ]  (A role)
+ *   RADMMM_SPLIT_X8B  the same with the two 32-byte halves swapped [ lo8 | hi8 ]                     (B role, weights)
+ * e4m3 = OCP FP8 E4M3, round to nearest even, saturated at +-448.  A block-scaled FP8 MFMA of an X8A fragment with an
+ * X8B fragment yields Ah.Bl + Al.Bh (radmmm_rowgemm_h3 with nprod = 2).
+ * ------------------------------------------------------------------------------------ */
+#define RADMMM_SPLIT_F16 0
+#define RADMMM_SPLIT_X8A 1
+#define RADMMM_SPLIT_X8B 2
+/* options of a split producer: format, exponent e of the 8-bit parts, optional saturation flag (device int, OR-ed
+ * with 1 when |scale * x| > 60000 was clamped) */
+typedef struct { int fmt; int x8_exp; int32_t* sat_flag; } radmmm_split_opts;
+
+/* ------------------------------------------------------------------------------------
  * Row GEMM with taps: the Conv1d family in channels-last form, fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, exact fp32).
  *
@@ -95,6 +111,9 @@ typedef struct {
    * Ch/Cl [M][ldch] halves receive hi/lo of ch_scale * C, C2h/C2l of c2h_scale * C2 (ld % 4 == 0) */
   void* Ch; void* Cl; int ldch; float ch_scale;
   void* C2h; void* C2l; int ldc2h; float c2h_scale;
+  /* split format of Ch/Cl and C2h/C2l (RADMMM_SPLIT_*, see "split formats" below) and the exponents of their 8-bit parts */
+  int split_fmt; int ch_x8_exp; int c2h_x8_exp;
+  int32_t* sat_flag;     /* optional device int: OR-ed with 1 when a split output exceeded the fp16 range (was clamped) */
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
@@ -114,7 +133,10 @@ typedef struct {
   const void* Bh; const void* Bl; int ldb_h; int64_t b_tap_stride_h;
   float acc_scale;
   int nprod;                  /* 0 or 3: split products Ah.Bh + Ah.Bl + Al.Bh (fp32-class accuracy);
-                                 1: Ah.Bh only = plain fp16 operands, fp32 accumulate (16-bit throughput mode) */
+                                 1: Ah.Bh only = plain fp16 operands, fp32 accumulate (16-bit throughput mode);
+                                 2: Ah.Bh on the f16 pipe + both cross terms in ONE block-scaled FP8 MFMA per 32-deep k
+                                    step: Al / Bl are then the 8-bit cross arrays RADMMM_SPLIT_X8A / RADMMM_SPLIT_X8B */
+  int a8_exp, b8_exp;         /* nprod 2: exponents e the 8-bit parts of A / B were written with (values * 2^e) */
 } radmmm_rowgemm_h3_desc;
 
 int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);
@@ -166,8 +188,8 @@ int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
  * ------------------------------------------------------------------------------------ */
 int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz,
                         float* X0, int ldx0, int rows, int D, int h,
-                        void* X0h, void* X0l /* optional split-fp16 copy, pitch ldx0, may be NULL */,
-                        radmmm_stream_t stream);
+                        void* X0h, void* X0l /* optional split copy, pitch ldx0, may be NULL */,
+                        const radmmm_split_opts* so, radmmm_stream_t stream);
 int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int ctx_accum,
                         float* gz, int ldz, int rows, int D, int h, radmmm_stream_t stream);
 
@@ -196,7 +218,7 @@ int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float*
                     int rows, int cols, int dact, int rowscale, int T, const int32_t* lens,
                     int taps, int dil,
                     void* yh, void* yl, int ldyh, float yscale /* optional split-fp16 copy of yscale*y */,
-                    radmmm_stream_t stream);
+                    const radmmm_split_opts* so /* NULL: f16 pair, no flag */, radmmm_stream_t stream);
 
 /* out[c] = sum_r w(r) * f(X[r, c]), f = identity or square;  row_weight 0: 1 ; 1: [t < lens[b]] ;
  * 2: (cnt+1e-6)/taps over valid rows (undoes the partial-conv ratio: bias gradient of
@@ -306,16 +328,19 @@ int64_t radmmm_stft_mel_scratch_floats(int B, int S, int n_fft, int hop, int n_m
  * See DESIGN.md §4.2 for the measured rate and error.
  * ------------------------------------------------------------------------------------ */
 int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int ldh, int rows, int cols,
-                     float scale, radmmm_stream_t stream);
+                     float scale, const radmmm_split_opts* so, radmmm_stream_t stream);
 /* weight-norm fold (see radmmm_weightnorm_fwd) straight into split packed weights
- * W{h,l}[tap][Cout][ldk] = split(scale * g v/||v||); g == NULL: plain weights (inv_norm unused) */
+ * W{h,l}[tap][Cout][ldk] = split(scale * g v/||v||); g == NULL: plain weights (inv_norm unused).
+ * so->fmt RADMMM_SPLIT_X8B: Wl is the B-role cross array (ldk % 32 == 0) */
 int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl, float* inv_norm,
                              int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo,
-                             int off_hi, float scale, radmmm_stream_t stream);
-/* dst[b][c][r] = src[b][r][c] for both members of a split pair (batches of [rows][cols]) */
+                             int off_hi, float scale, const radmmm_split_opts* so, radmmm_stream_t stream);
+/* dst[b][c][r] = src[b][r][c] for both members of a split pair (batches of [rows][cols]); fmt RADMMM_SPLIT_X8B:
+ * src_l / dst_l are B-role cross arrays (their 8-bit hi parts are re-derived from the fp16 hi, the 8-bit lo parts
+ * move with the transposition; ld_src, ld_dst % 32 == 0, x8_exp as the source was written) */
 int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, int64_t src_batch,
                               void* dst_h, void* dst_l, int ld_dst, int64_t dst_batch, int batches,
-                              int rows, int cols, radmmm_stream_t stream);
+                              int rows, int cols, int fmt, int x8_exp, radmmm_stream_t stream);
 /* Workgroup slots the GEMM grids are sized for: the device's CU count, or RADMMM_GEMM_CUS (32 .. CUs; read once
  * per process) when data-parallel runs leave CUs to RCCL's channel kernels (Lightning `strategy: ddp`,
  * configs/RADMMM_train_config.yaml:28; rad_mmm_amd/ddp.py reserve_collective_cus). */

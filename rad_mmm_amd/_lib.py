@@ -46,7 +46,23 @@ class RowGemmDesc(C.Structure):
         ("C2", C.c_void_p), ("ldc2", C.c_int), ("c2_accum", C.c_int),
         ("Ch", C.c_void_p), ("Cl", C.c_void_p), ("ldch", C.c_int), ("ch_scale", C.c_float),
         ("C2h", C.c_void_p), ("C2l", C.c_void_p), ("ldc2h", C.c_int), ("c2h_scale", C.c_float),
+        ("split_fmt", C.c_int), ("ch_x8_exp", C.c_int), ("c2h_x8_exp", C.c_int),
+        ("sat_flag", C.c_void_p),
     ]
+
+
+class SplitOpts(C.Structure):
+    """radmmm_split_opts: format of a split producer's second array (SPLIT_F16 / SPLIT_X8A / SPLIT_X8B), exponent of its
+    8-bit parts, optional device saturation flag."""
+    _fields_ = [("fmt", C.c_int), ("x8_exp", C.c_int), ("sat_flag", C.c_void_p)]
+
+
+SPLIT_F16, SPLIT_X8A, SPLIT_X8B = 0, 1, 2
+
+
+def split_opts(fmt: int = 0, x8_exp: int = 0, sat_flag: Optional[torch.Tensor] = None):
+    """byref(SplitOpts) for a C-ABI call (the struct is read during the call only)."""
+    return C.byref(SplitOpts(fmt, x8_exp, sat_flag.data_ptr() if sat_flag is not None else None))
 
 
 class RowGemmH3Desc(C.Structure):
@@ -56,6 +72,7 @@ class RowGemmH3Desc(C.Structure):
         ("Bh", C.c_void_p), ("Bl", C.c_void_p), ("ldb_h", C.c_int), ("b_tap_stride_h", C.c_int64),
         ("acc_scale", C.c_float),
         ("nprod", C.c_int),
+        ("a8_exp", C.c_int), ("b8_exp", C.c_int),
     ]
 
 
@@ -86,24 +103,25 @@ def _load() -> C.CDLL:
         raise ImportError("libradmmm_hip.so ABI version mismatch")
     i, i64, p = C.c_int, C.c_int64, C.c_void_p
     f = C.c_float
+    so = C.POINTER(SplitOpts)
     sig = {
         "radmmm_rowgemm_f32": [C.POINTER(RowGemmDesc), p],
         "radmmm_wgrad_f32": [C.POINTER(WgradDesc), p],
         "radmmm_rowgemm_h3": [C.POINTER(RowGemmH3Desc), p],
         "radmmm_weightnorm_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
         "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p],
-        "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p, p, p],
+        "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p, p, so, p],
         "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
         "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
         "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
-        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p, p, i, f, p],
+        "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p, p, i, f, so, p],
         "radmmm_colsum": [p, i, p, p, i, i, i, i, p, i, i, i, p],
         "radmmm_masked_reduce": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_masked_reduce_bwd": [p, i, i, i, i64, i64, i64, p, i, p, p, p],
         "radmmm_fused_add_tanh_sigmoid_multiply": [p, p, i, p, i, i, i, p],
         "radmmm_film_fwd": [p, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p],
         "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
-        "radmmm_split_f16": [p, i, p, p, i, i, i, f, p],
+        "radmmm_split_f16": [p, i, p, p, i, i, i, f, so, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
         "radmmm_betabinom_prior": [i, i, C.c_double, p, p],
@@ -121,8 +139,8 @@ def _load() -> C.CDLL:
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
-        "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, p],
-        "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, p],
+        "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, so, p],
+        "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, i, i, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
@@ -194,7 +212,7 @@ def rowgemm(**kw) -> None:
     check(lib.radmmm_rowgemm_f32(C.byref(d), stream()), "radmmm_rowgemm_f32")
 
 
-_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale", "nprod"}
+_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale", "nprod", "a8_exp", "b8_exp"}
 
 
 def rowgemm_h3(**kw) -> None:

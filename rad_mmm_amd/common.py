@@ -224,13 +224,14 @@ class AffineTransformationLayer(nn.Module):
     def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision="fp32", scale_box=None):
         """Fused [1x1 mix -> WN -> coupling] on channels-last operands.  Returns z_out, log_s.
         precision "fp32": fp32 MFMA GEMMs; "h3": split-f16 GEMMs (fp32-class accuracy, f16 matrix
-        cores) when the WN width allows it (multiple of 32); "f16": the same kernels with the hi halves
-        only = plain fp16 operands, fp32 accumulate (16-bit throughput mode, NOT within the 1e-4 bar)."""
+        cores) when the WN width allows it (multiple of 32); "f8x": the hi.hi product on the f16 cores and both cross
+        terms in one block-scaled FP8 MFMA (2/3 of the MFMA time, z within 4e-5); "f16": the same kernels with the hi
+        halves only = plain fp16 operands, fp32 accumulate (16-bit throughput mode, NOT within the 1e-4 bar)."""
         wn = self.affine_param_predictor
         head, layers = wn.flat_params()
         meta = dict(B=B, T=T, C=self.n_mel_channels, D=self.n_context_dim, n_layers=wn.n_layers,
                     act=ACT[wn.affine_activation], scaling=SCALE[self.scaling_fn],
                     partial=bool(wn.use_partial_padding), scale_box=scale_box if scale_box is not None else {},
-                    nprod=1 if precision == "f16" else 3)
-        fn = ops.AffineFlowStepH3Fn if (precision in ("h3", "f16") and wn.n_channels % 32 == 0) else ops.AffineFlowStepFn
+                    nprod=ops.NPROD.get(precision, 3))
+        fn = ops.AffineFlowStepH3Fn if (precision in ops.NPROD and wn.n_channels % 32 == 0) else ops.AffineFlowStepFn
         return fn.apply(meta, z_cl, cond_cl, lens32, W_eff, b_eff, *head, *layers)

@@ -13,8 +13,10 @@ OBJ="$HERE/build/$KEY"
 mkdir -p "$OBJ"
 NEWEST_HDR="$(ls -t "$HERE"/*.h "$HERE/../../include"/*.h | head -1)"
 pids=()
+objs=()
 for src in "$HERE"/*.hip "$HERE"/error.cpp; do
   o="$OBJ/$(basename "$src").o"
+  objs+=("$o")
   if [[ ! -f "$o" || "$src" -nt "$o" || "$NEWEST_HDR" -nt "$o" ]]; then
     ( "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
     pids+=($!)
@@ -23,6 +25,6 @@ done
 for p in "${pids[@]:-}"; do
   [[ -n "$p" ]] && wait "$p"
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT.tmp"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT.tmp"      # only objects of sources that still exist
 mv "$OUT.tmp" "$OUT"
 echo "built $OUT"

@@ -3,7 +3,11 @@
 // NLL reductions.  All fp32, channels-last rows; every kernel keeps consecutive lanes on
 // consecutive addresses (coalesced 256 B per wave-instruction or float4 where the layout
 // allows) and reduces through wavefront shuffles (64 lanes) before touching LDS.
+#include <math.h>
+#include <stdlib.h>
+
 #include "common.h"
+#include "split_pack.h"
 
 namespace {
 
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
 __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz,
     float* __restrict__ X0, int ldx0, int rows, int D, int h, _Float16* __restrict__ Xh,
-    _Float16* __restrict__ Xl) {
+    _Float16* __restrict__ Xl, int fmt, float x8_mul) {
   const long long total = (long long)rows * ldx0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -107,12 +111,7 @@ __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     if (c < D) v = ctx[(long long)r * ldctx + c];
     else if (c < D + h) v = z[(long long)r * ldz + (c - D)];
     X0[i] = v;
-    if (Xh) {                                // split-fp16 copy (same pitch), scale 1
-      const float t = fminf(fmaxf(v, -60000.f), 60000.f);
-      const _Float16 hh = (_Float16)t;
-      Xh[i] = hh;
-      Xl[i] = (_Float16)(t - (float)hh);
-    }
+    if (Xh) radmmm::store_split1_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v);   // split copy (same pitch), scale 1
   }
 }
 
@@ -204,7 +203,8 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds,
     float* __restrict__ y, int ldy, int rows, int cols, int dact, int rowscale, int T,
     const int* __restrict__ lens, int taps, int dil, _Float16* __restrict__ yh, _Float16* __restrict__ yl,
-    int ldyh, float yscale) {
+    int ldyh, float yscale, int fmt, float x8_mul, int* __restrict__ sat_flag) {
+  float sat = 0.f;
   const int c4n = (cols + 3) / 4;
   const long long total = (long long)rows * c4n;
   const bool vec = (cols % 4 == 0) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldy % 4 == 0);
@@ -231,32 +231,17 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
         o.x = gv.x * rs; o.y = gv.y * rs; o.z = gv.z * rs; o.w = gv.w * rs;
       }
       *reinterpret_cast<float4*>(y + (long long)r * ldy + c) = o;
-      if (yh) {
-        const float ov[4] = {o.x, o.y, o.z, o.w};
-        _Float16 hh[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float tt = fminf(fmaxf(ov[e] * yscale, -60000.f), 60000.f);
-          hh[e] = (_Float16)tt;
-          ll[e] = (_Float16)(tt - (float)hh[e]);
-        }
-        *reinterpret_cast<uint2*>(yh + (long long)r * ldyh + c) = *reinterpret_cast<const uint2*>(hh);
-        *reinterpret_cast<uint2*>(yl + (long long)r * ldyh + c) = *reinterpret_cast<const uint2*>(ll);
-      }
+      if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, (long long)r * ldyh, c, fmt, x8_mul, yscale, o.x, o.y, o.z, o.w));
     } else {
       for (int e = 0; e < 4 && c + e < cols; ++e) {
         const float d = dact ? radmmm::dact_from_out(saved[(long long)r * lds + c + e], dact) : 1.f;
         const float ov = g[(long long)r * ldg + c + e] * d * rs;
         y[(long long)r * ldy + c + e] = ov;
-        if (yh) {
-          const float tt = fminf(fmaxf(ov * yscale, -60000.f), 60000.f);
-          const _Float16 hh = (_Float16)tt;
-          yh[(long long)r * ldyh + c + e] = hh;
-          yl[(long long)r * ldyh + c + e] = (_Float16)(tt - (float)hh);
-        }
+        if (yh) sat = fmaxf(sat, radmmm::store_split1_fmt(yh, yl, (long long)r * ldyh, c + e, fmt, x8_mul, yscale, ov));
       }
     }
   }
+  radmmm::raise_sat_flag(sat_flag, sat);
 }
 
 // ------------------------------------------------------------------ column sums
@@ -466,12 +451,14 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
 
 extern "C" int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz, float* X0,
                                    int ldx0, int rows, int D, int h, void* Xh, void* Xl,
-                                   radmmm_stream_t stream) {
+                                   const radmmm_split_opts* so, radmmm_stream_t stream) {
   RADMMM_REQUIRE(ctx && z && X0, "wn_input_fwd: null pointer");
   RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_fwd: bad dims");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || !Xh || (ldx0 % 32 == 0 && abs(so->x8_exp) <= 16), "wn_input_fwd: 8-bit format needs ldx0 %% 32 == 0");
   hipLaunchKernelGGL(wn_input_fwd_kernel, dim3(grid_for((long long)rows * ldx0)), dim3(256), 0,
                      ST(stream), ctx, ldctx, z, ldz, X0, ldx0, rows, D, h, static_cast<_Float16*>(Xh),
-                     static_cast<_Float16*>(Xl));
+                     static_cast<_Float16*>(Xl), fmt, ldexpf(1.f, so ? so->x8_exp : 0));
   return radmmm::check_launch("wn_input_fwd");
 }
 
@@ -509,15 +496,19 @@ extern "C" int radmmm_affine_coupling_bwd(const float* O, int ldo, const float* 
 extern "C" int radmmm_dact_mul(const float* g, int ldg, const float* saved, int lds, float* y,
                                int ldy, int rows, int cols, int dact, int rowscale, int T,
                                const int32_t* lens, int taps, int dil, void* yh, void* yl, int ldyh,
-                               float yscale, radmmm_stream_t stream) {
+                               float yscale, const radmmm_split_opts* so, radmmm_stream_t stream) {
   RADMMM_REQUIRE(!yh || (yl && ldyh >= cols && ldyh % 4 == 0), "dact_mul: split output needs ldyh %% 4 == 0");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || !yh || (ldyh % 32 == 0 && cols % 4 == 0 && abs(so->x8_exp) <= 16),
+                 "dact_mul: 8-bit format needs ldyh %% 32 == 0");
   RADMMM_REQUIRE(g && y && (saved || !dact), "dact_mul: null pointer");
   RADMMM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && ldy >= cols && (!dact || lds >= cols), "dact_mul: bad dims");
   RADMMM_REQUIRE(!rowscale || (T > 0 && rows % T == 0), "dact_mul: rows must be a multiple of T");
   RADMMM_REQUIRE(rowscale != 2 || (taps >= 1 && dil >= 1), "dact_mul: taps/dil");
   hipLaunchKernelGGL(dact_mul_kernel, dim3(grid_for((long long)rows * ((cols + 3) / 4))), dim3(256), 0,
                      ST(stream), g, ldg, saved, lds, y, ldy, rows, cols, dact, rowscale, T > 0 ? T : 1, lens, taps,
-                     dil, static_cast<_Float16*>(yh), static_cast<_Float16*>(yl), ldyh, yscale);
+                     dil, static_cast<_Float16*>(yh), static_cast<_Float16*>(yl), ldyh, yscale, fmt,
+                     ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr);
   return radmmm::check_launch("dact_mul");
 }
 

@@ -1,24 +1,22 @@
 // Support kernels of the split-f16 GEMM path: weight-norm fold straight into split (hi/lo fp16)
 // packed weights, and a tiled transpose of a split pair (the data-gradient GEMM wants the weights
 // K-contiguous in the OUTPUT-channel index).
+#include <math.h>
+#include <stdlib.h>
+
 #include "common.h"
+#include "split_pack.h"
 
 namespace {
 
 using radmmm::block_sum;
-
-__device__ __forceinline__ void split1(float t, _Float16& h, _Float16& l) {
-  t = fminf(fmaxf(t, -60000.f), 60000.f);
-  h = (_Float16)t;
-  l = (_Float16)(t - (float)h);
-}
 
 // W{h,l}[tap][co][col(ci)] = split(scale * g[co] * v[co][ci][tap] / ||v[co]||); columns not hit by
 // col() must have been zeroed by the caller.  g == NULL: plain conv weights (no normalisation).
 __global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
     const float* __restrict__ v, const float* __restrict__ g, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
     float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi,
-    float scale) {
+    float scale, int fmt, float x8_mul) {
   __shared__ float sh[17];
   const int co = blockIdx.x;
   const int n = Cin * taps;
@@ -35,13 +33,27 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int ci = i / taps, k = i - ci * taps;
     const int col = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi;
-    _Float16 h, l;
     // same rounding as the fp32 path (w = v * (g / ||v||)), then the exact power-of-two scale
-    split1((vr[i] * wn) * scale, h, l);
-    const long long o = ((long long)k * Cout + co) * ldk + col;
-    Wh[o] = h;
-    Wl[o] = l;
+    radmmm::store_split1_fmt(Wh, Wl, ((long long)k * Cout + co) * ldk, col, fmt, x8_mul, scale, vr[i] * wn);
   }
+}
+
+// hi/lo [rows][ldh] split of scale * x (zero padded to ldh), any split format
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int ld, void* __restrict__ hi,
+                                                        void* __restrict__ lo, int ldh, int rows, int cols, float scale,
+                                                        int fmt, float x8_mul, int* __restrict__ sat_flag) {
+  const int c4n = ldh / 4;
+  const long long total = (long long)rows * c4n;
+  float sat = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? x[(long long)r * ld + c + e] : 0.f;
+    sat = fmaxf(sat, radmmm::store_split4_fmt(hi, lo, (long long)r * ldh, c, fmt, x8_mul, scale, v[0], v[1], v[2], v[3]));
+  }
+  radmmm::raise_sat_flag(sat_flag, sat);
 }
 
 // dst[b][c][r] = src[b][r][c] for both members of a split pair; 32x32 tiles through LDS
@@ -69,24 +81,78 @@ __global__ __launch_bounds__(256) void transpose_pair_kernel(const _Float16* __r
   }
 }
 
+// the same for a B-role 8-bit pair (hi f16 + cross array [lo8 | hi8] per 32 columns): the 8-bit lo parts move with the
+// transposition, the 8-bit hi parts are re-derived from the fp16 hi (what the producer did: e4m3(hi * 2^e) of the value
+// already rounded to fp16 differs from e4m3(t * 2^e) only in double-rounding ties; both are valid 8-bit images of hi)
+__global__ __launch_bounds__(256) void transpose_pair_x8_kernel(const _Float16* __restrict__ sh_, const unsigned char* __restrict__ sx,
+                                                                int ld_src, long long src_batch, _Float16* __restrict__ dh,
+                                                                unsigned char* __restrict__ dx, int ld_dst, long long dst_batch,
+                                                                int rows, int cols, int fmt, float x8_mul) {
+  __shared__ _Float16 th[32][34];
+  __shared__ unsigned char tl[32][36];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const bool ok = r < rows && c < cols;
+    th[i][tx] = ok ? sh_[b * src_batch + (long long)r * ld_src + c] : (_Float16)0.f;
+    tl[i][tx] = ok ? sx[2 * (b * src_batch + (long long)r * ld_src) + radmmm::x8_lo_off(c, fmt)] : (unsigned char)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) {
+      const _Float16 h = th[tx][i];
+      dh[b * dst_batch + (long long)c * ld_dst + r] = h;
+      unsigned char* row = dx + 2 * (b * dst_batch + (long long)c * ld_dst);
+      row[radmmm::x8_hi_off(r, fmt)] = (unsigned char)(radmmm::pack_e4m3x4((float)h * x8_mul, 0.f, 0.f, 0.f) & 0xffu);
+      row[radmmm::x8_lo_off(r, fmt)] = tl[tx][i];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl, float* inv_norm, int Cout,
                                         int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi, float scale,
-                                        radmmm_stream_t stream) {
+                                        const radmmm_split_opts* so, radmmm_stream_t stream) {
   RADMMM_REQUIRE(v && Wh && Wl && (inv_norm || !g), "weightnorm_fwd_h3: null pointer");
   RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldk >= Cin && ldk % 8 == 0, "weightnorm_fwd_h3: bad dims");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || (ldk % 32 == 0 && abs(so->x8_exp) <= 16), "weightnorm_fwd_h3: 8-bit format needs ldk %% 32 == 0");
   hipLaunchKernelGGL(weightnorm_fwd_h3_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), v, g,
                      static_cast<_Float16*>(Wh), static_cast<_Float16*>(Wl), inv_norm, Cout, Cin, taps, ldk, perm_split,
-                     off_lo, off_hi, scale);
+                     off_lo, off_hi, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0));
   return radmmm::check_launch("weightnorm_fwd_h3");
+}
+
+extern "C" int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int ldh, int rows, int cols, float scale,
+                                const radmmm_split_opts* so, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(x && hi && lo, "split_f16: null pointer");
+  RADMMM_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ldh >= cols && ldh % 8 == 0, "split_f16: bad dims (ldh %% 8 == 0)");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || (ldh % 32 == 0 && abs(so->x8_exp) <= 16), "split_f16: 8-bit format needs ldh %% 32 == 0");
+  const long long total = (long long)rows * (ldh / 4);
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(split_f16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, hi, lo, ldh, rows,
+                     cols, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr);
+  return radmmm::check_launch("split_f16");
 }
 
 extern "C" int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, int64_t src_batch, void* dst_h,
                                          void* dst_l, int ld_dst, int64_t dst_batch, int batches, int rows, int cols,
-                                         radmmm_stream_t stream) {
+                                         int fmt, int x8_exp, radmmm_stream_t stream) {
   RADMMM_REQUIRE(src_h && src_l && dst_h && dst_l, "transpose_f16_pair: null pointer");
   RADMMM_REQUIRE(batches > 0 && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "transpose_f16_pair: bad dims");
+  if (fmt != RADMMM_SPLIT_F16) {
+    RADMMM_REQUIRE(ld_src % 32 == 0 && ld_dst % 32 == 0 && abs(x8_exp) <= 16, "transpose_f16_pair: 8-bit format needs ld %% 32 == 0");
+    hipLaunchKernelGGL(transpose_pair_x8_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batches), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const _Float16*>(src_h),
+                       static_cast<const unsigned char*>(src_l), ld_src, (long long)src_batch, static_cast<_Float16*>(dst_h),
+                       static_cast<unsigned char*>(dst_l), ld_dst, (long long)dst_batch, rows, cols, fmt, ldexpf(1.f, x8_exp));
+    return radmmm::check_launch("transpose_f16_pair(x8)");
+  }
   hipLaunchKernelGGL(transpose_pair_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batches), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(src_h),
                      static_cast<const _Float16*>(src_l), ld_src, (long long)src_batch, static_cast<_Float16*>(dst_h),

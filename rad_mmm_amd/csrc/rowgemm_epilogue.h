@@ -2,12 +2,13 @@
 // applied to 4 consecutive output columns of one row.  Shared by both tilings of the kernel.
 #pragma once
 #include "common.h"
+#include "split_pack.h"
 
 namespace radmmm {
 
 struct EpilogueCtx {
   bool need_row, vec_ok;
-  __device__ explicit EpilogueCtx(const radmmm_rowgemm_desc& p) {
+  __device__ __forceinline__ explicit EpilogueCtx(const radmmm_rowgemm_desc& p) {
     need_row = p.pconv || p.premask || p.postmask || p.rowscale;
     vec_ok = (p.ldc % 4 == 0) && aligned16(p.C) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) &&
              (!p.dact || (p.lddact % 4 == 0 && aligned16(p.dact_src))) &&
@@ -15,21 +16,19 @@ struct EpilogueCtx {
   }
 };
 
-// hi = fp16(s*x) (saturated), lo = fp16(s*x - hi): 4 columns, 8-byte stores (ld % 4 == 0, col % 4 == 0)
-__device__ __forceinline__ void store_split4(void* hi_, void* lo_, int ld, float s, int row, int col, int N,
-                                             const float (&x)[4]) {
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float t = (col + e < N) ? x[e] * s : 0.f;
-    t = fminf(fmaxf(t, -60000.f), 60000.f);
-    h[e] = (_Float16)t;
-    l[e] = (_Float16)(t - (float)h[e]);
+// split copy of 4 output columns (ld % 4 == 0, col % 4 == 0) in the descriptor's split format; columns >= N are
+// written as zeros in the f16 format and skipped in the 8-bit formats.  Returns max |scale * x| (saturation tracking).
+__device__ __forceinline__ float store_split4(void* hi_, void* lo_, int ld, float s, int fmt, int x8_exp, int row, int col,
+                                              int N, const float (&x)[4]) {
+  const float mul = __builtin_ldexpf(1.f, x8_exp);
+  if (col + 3 < N || fmt == 0) {
+    return store_split4_fmt(hi_, lo_, (long long)row * ld, col, fmt, mul, s, x[0], col + 1 < N ? x[1] : 0.f,
+                            col + 2 < N ? x[2] : 0.f, col + 3 < N ? x[3] : 0.f);
   }
-  _Float16* hi = static_cast<_Float16*>(hi_) + (long long)row * ld + col;
-  _Float16* lo = static_cast<_Float16*>(lo_) + (long long)row * ld + col;
-  *reinterpret_cast<uint2*>(hi) = *reinterpret_cast<const uint2*>(h);
-  *reinterpret_cast<uint2*>(lo) = *reinterpret_cast<const uint2*>(l);
+  float amax = 0.f;
+  for (int e = 0; e < 4 && col + e < N; ++e)
+    amax = fmaxf(amax, store_split1_fmt(hi_, lo_, (long long)row * ld, col + e, fmt, mul, s, x[e]));
+  return amax;
 }
 
 // per-row factors of the epilogue: length mask and partial-conv renormalisation ratio
@@ -46,12 +45,12 @@ __device__ __forceinline__ void epilogue_row_factors(const radmmm_rowgemm_desc& 
   }
 }
 
-__device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
-                                                    float4 a4, float maskv, float ratio, const float (&biasv)[4]);
+__device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
+                                                     float4 a4, float maskv, float ratio, const float (&biasv)[4]);
 
-__device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
-                                                int col, float4 a4) {
-  if (row >= p.M || col >= p.N) return;
+__device__ __forceinline__ float epilogue_store4(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row,
+                                                 int col, float4 a4) {
+  if (row >= p.M || col >= p.N) return 0.f;
   float maskv, ratio;
   epilogue_row_factors(p, ec, row, maskv, ratio);
   float biasv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -59,14 +58,15 @@ __device__ __forceinline__ void epilogue_store4(const radmmm_rowgemm_desc& p, co
 #pragma unroll
     for (int e = 0; e < 4; ++e) biasv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
   }
-  epilogue_store4_pre(p, ec, row, col, a4, maskv, ratio, biasv);
+  return epilogue_store4_pre(p, ec, row, col, a4, maskv, ratio, biasv);
 }
 
 // same with the row factors and the bias of the 4 columns supplied by the caller (kernels that hoist
-// them out of the per-row loop: no dependent global loads remain in the store path)
-__device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
-                                                    float4 a4, float maskv, float ratio, const float (&biasv)[4]) {
-  if (row >= p.M || col >= p.N) return;
+// them out of the per-row loop: no dependent global loads remain in the store path).  Returns max |scale * x| over the
+// split outputs written (0 without split outputs).
+__device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& p, const EpilogueCtx& ec, int row, int col,
+                                                     float4 a4, float maskv, float ratio, const float (&biasv)[4]) {
+  if (row >= p.M || col >= p.N) return 0.f;
   float v[4] = {a4.x, a4.y, a4.z, a4.w};
   const bool full = ec.vec_ok && col + 3 < p.N;
   float addv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f}, c2v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -109,8 +109,9 @@ __device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p
     c2v[e] += x;
   }
   // optional split-fp16 copies (hi/lo of scale*x) feeding the next split-f16 GEMM
-  if (p.Ch) store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, row, col, p.N, v);
-  if (p.C2h) store_split4(p.C2h, p.C2l, p.ldc2h, p.c2h_scale, row, col, p.N, c2v);
+  float amax = 0.f;
+  if (p.Ch) amax = store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, p.split_fmt, p.ch_x8_exp, row, col, p.N, v);
+  if (p.C2h) amax = fmaxf(amax, store_split4(p.C2h, p.C2l, p.ldc2h, p.c2h_scale, p.split_fmt, p.c2h_x8_exp, row, col, p.N, c2v));
   if (full) {
     *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
     if (p.C2)
@@ -124,6 +125,7 @@ __device__ __forceinline__ void epilogue_store4_pre(const radmmm_rowgemm_desc& p
       }
     }
   }
+  return amax;
 }
 
 }  // namespace radmmm

@@ -162,11 +162,13 @@ __global__ __launch_bounds__(256, 2) void rowgemm_h3_kernel(const radmmm_rowgemm
   __syncthreads();
   const radmmm::EpilogueCtx ec(p);
   const int c4 = (tid & 31) * 4;
+  float sat = 0.f;
   for (int i = 0; i < 16; ++i) {
     const int rl = i * 8 + (tid >> 5);
     const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
-    radmmm::epilogue_store4(p, ec, m0 + rl, n0 + c4, a4);
+    sat = fmaxf(sat, radmmm::epilogue_store4(p, ec, m0 + rl, n0 + c4, a4));
   }
+  radmmm::raise_sat_flag(p.sat_flag, sat);
 }
 
 }  // namespace
@@ -188,6 +190,14 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   RADMMM_REQUIRE(!p.dact || p.dact_src, "rowgemm_h3: dact needs dact_src");
   RADMMM_REQUIRE(!p.Ch || (p.Cl && p.ldch % 4 == 0 && p.ldch >= ((p.N + 3) & ~3)), "rowgemm_h3: Ch/Cl");
   RADMMM_REQUIRE(!p.C2h || (p.C2l && p.C2 && p.ldc2h % 4 == 0 && p.ldc2h >= ((p.N + 3) & ~3)), "rowgemm_h3: C2h/C2l");
+  RADMMM_REQUIRE(p.split_fmt >= RADMMM_SPLIT_F16 && p.split_fmt <= RADMMM_SPLIT_X8B, "rowgemm_h3: split_fmt");
+  RADMMM_REQUIRE(p.split_fmt == RADMMM_SPLIT_F16 || ((!p.Ch || p.ldch % 32 == 0) && (!p.C2h || p.ldc2h % 32 == 0) &&
+                                                      abs(p.ch_x8_exp) <= 16 && abs(p.c2h_x8_exp) <= 16),
+                 "rowgemm_h3: 8-bit split outputs need ld %% 32 == 0 and |x8_exp| <= 16");
+  RADMMM_REQUIRE(d->nprod >= 0 && d->nprod <= 3, "rowgemm_h3: nprod");
+  RADMMM_REQUIRE(d->nprod != 2 || (abs(d->a8_exp) <= 16 && abs(d->b8_exp) <= 16 && d->lda_h % 32 == 0 && d->ldb_h % 32 == 0 &&
+                                   d->b_tap_stride_h % 32 == 0),
+                 "rowgemm_h3: nprod 2 needs ld %% 32 == 0 and |x8_exp| <= 16");
   const long long a_bytes = (long long)p.M * d->lda_h * 2;
   const long long b_bytes = ((long long)(p.taps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "rowgemm_h3: operand >= 2 GiB");
@@ -202,7 +212,8 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
     return e && atoi(e) == 128;
   }();
   const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
-  const bool narrow = forced == 128 || (forced != 256 && wide_wgs < 128);
+  // (the FP8 cross-term scheme exists on the wide kernel only)
+  const bool narrow = d->nprod != 2 && (forced == 128 || (forced != 256 && wide_wgs < 128));
   if (!narrow && !(narrow_1x1 && p.taps == 1))
     return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {

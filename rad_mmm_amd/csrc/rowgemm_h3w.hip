@@ -19,12 +19,15 @@
 
 #include "common.h"
 #include "rowgemm_epilogue.h"
+#include "split_pack.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BN = 256, BK = 32, ROWB = 64;
 constexpr int OOB = 0x7fffffff;
@@ -43,28 +46,18 @@ struct Geo {
 // depend on the row (column validity, bias, base pointers) is hoisted by the caller, all accesses are
 // 16-byte (8-byte for the fp16 copies) and the option flags are wave-uniform branches.  Preconditions
 // (checked once per workgroup): EpilogueCtx::vec_ok, N % 4 == 0.  Same arithmetic and order as
-// radmmm::epilogue_store4_pre.
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-// hi = fp16(s x) (saturated), lo = fp16(s x - hi) for 4 values, kept in vector registers (arrays whose
-// address is taken for a wide store end up in scratch)
-__device__ __forceinline__ void pack_split(float x0, float x1, float x2, float x3, float s, f16x4& hi, f16x4& lo) {
-  const float t0 = fminf(fmaxf(x0 * s, -60000.f), 60000.f), t1 = fminf(fmaxf(x1 * s, -60000.f), 60000.f);
-  const float t2 = fminf(fmaxf(x2 * s, -60000.f), 60000.f), t3 = fminf(fmaxf(x3 * s, -60000.f), 60000.f);
-  hi[0] = (_Float16)t0; hi[1] = (_Float16)t1; hi[2] = (_Float16)t2; hi[3] = (_Float16)t3;
-  lo[0] = (_Float16)(t0 - (float)hi[0]); lo[1] = (_Float16)(t1 - (float)hi[1]);
-  lo[2] = (_Float16)(t2 - (float)hi[2]); lo[3] = (_Float16)(t3 - (float)hi[3]);
-}
-
-// all indices are 32-bit element offsets from the (wave-uniform) base pointers: M * ld < 2^31 is checked
+// radmmm::epilogue_store4_pre.  The side inputs (add, dact_src, C2) arrive in registers: the caller
+// fetched them before the block was parked in LDS, so their latency is not exposed here.
+// All indices are 32-bit element offsets from the (wave-uniform) base pointers: M * ld < 2^31 is checked
 // by the host, and a scalar base + 32-bit vector offset keeps the epilogue's VGPR demand small enough
-// not to push accumulators into scratch
-__device__ __forceinline__ void epilogue_row_fast(const radmmm_rowgemm_desc& p, int row, int col, float4 a4, float maskv,
-                                                  float ratio, float b0, float b1, float b2, float b3) {
-  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), dsv = addv, c2v = addv;
-  if (p.add) addv = *reinterpret_cast<const float4*>(p.add + (unsigned)(row * p.ldadd + col));
-  if (p.dact) dsv = *reinterpret_cast<const float4*>(p.dact_src + (unsigned)(row * p.lddact + col));
-  if (p.C2 && p.c2_accum) c2v = *reinterpret_cast<const float4*>(p.C2 + (unsigned)(row * p.ldc2 + col));
+// not to push accumulators into scratch.
+struct EpiConst {
+  float b0, b1, b2, b3;          // bias of this thread's 4 columns
+  float ch_mul, c2h_mul;         // 2^x8_exp of the two split outputs
+};
+
+__device__ __forceinline__ float epilogue_row_fast(const radmmm_rowgemm_desc& p, int row, int col, float4 a4, float maskv,
+                                                   float ratio, const EpiConst& ec, float4 addv, float4 dsv, float4 c2v) {
   const float pre = (p.pconv ? ratio : 1.f) * (p.premask ? maskv : 1.f);
   const float post = (p.postmask ? maskv : 1.f);
   const float rsc = p.rowscale == 1 ? maskv : (p.rowscale == 2 ? maskv * ratio : 1.f);
@@ -73,35 +66,64 @@ __device__ __forceinline__ void epilogue_row_fast(const radmmm_rowgemm_desc& p, 
     if (p.dact) x *= radmmm::dact_from_out(ds, p.dact);
     return radmmm::act_apply(x * rsc, p.act);
   };
-  const float v0 = one(a4.x, b0, addv.x, dsv.x), v1 = one(a4.y, b1, addv.y, dsv.y);
-  const float v2 = one(a4.z, b2, addv.z, dsv.z), v3 = one(a4.w, b3, addv.w, dsv.w);
+  const float v0 = one(a4.x, ec.b0, addv.x, dsv.x), v1 = one(a4.y, ec.b1, addv.y, dsv.y);
+  const float v2 = one(a4.z, ec.b2, addv.z, dsv.z), v3 = one(a4.w, ec.b3, addv.w, dsv.w);
   c2v.x += v0; c2v.y += v1; c2v.z += v2; c2v.w += v3;
-  if (p.Ch) {
-    f16x4 hi, lo;
-    pack_split(v0, v1, v2, v3, p.ch_scale, hi, lo);
-    const unsigned o = (unsigned)(row * p.ldch + col);
-    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.Ch) + o) = hi;
-    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.Cl) + o) = lo;
-  }
-  if (p.C2h) {
-    f16x4 hi, lo;
-    pack_split(c2v.x, c2v.y, c2v.z, c2v.w, p.c2h_scale, hi, lo);
-    const unsigned o = (unsigned)(row * p.ldc2h + col);
-    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.C2h) + o) = hi;
-    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.C2l) + o) = lo;
-  }
+  float amax = 0.f;
+  if (p.Ch)
+    amax = radmmm::store_split4_fmt(p.Ch, p.Cl, (unsigned)(row * p.ldch), col, p.split_fmt, ec.ch_mul, p.ch_scale, v0, v1, v2, v3);
+  if (p.C2h)
+    amax = fmaxf(amax, radmmm::store_split4_fmt(p.C2h, p.C2l, (unsigned)(row * p.ldc2h), col, p.split_fmt, ec.c2h_mul,
+                                                p.c2h_scale, c2v.x, c2v.y, c2v.z, c2v.w));
   *reinterpret_cast<float4*>(p.C + (unsigned)(row * p.ldc + col)) = make_float4(v0, v1, v2, v3);
   if (p.C2) *reinterpret_cast<float4*>(p.C2 + (unsigned)(row * p.ldc2 + col)) = c2v;
+  return amax;
+}
+
+// side inputs of one output row (4 columns) of the fused epilogue, requested ahead of their use
+__device__ __forceinline__ void fetch_side(const radmmm_rowgemm_desc& p, bool live, int row, int col, float4& a, float4& d,
+                                           float4& c) {
+  a = d = c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && row < p.M) {
+    if (p.add) a = *reinterpret_cast<const float4*>(p.add + (unsigned)(row * p.ldadd + col));
+    if (p.dact) d = *reinterpret_cast<const float4*>(p.dact_src + (unsigned)(row * p.lddact + col));
+    if (p.C2 && p.c2_accum) c = *reinterpret_cast<const float4*>(p.C2 + (unsigned)(row * p.ldc2 + col));
+  }
 }
 
 // Epilogue of row block I (compile-time index: a runtime-indexed accumulator array would live in
 // scratch): the four waves park their 32x64 pieces in LDS, then all threads run the fused epilogue
-// on coalesced float4 rows.
+// on coalesced float4 rows.  A thread owns rows rl = 4 k + (tid >> 6), k = 0..7, of the block and handles them in four
+// pairs; the side inputs (add, dact_src, C2) of the first pair are requested before the park and those of pair n + 1
+// before pair n is processed, so that no global-load latency sits between the LDS read-out and the stores (one
+// workgroup per CU: nothing else would hide it).  Plain arrays with compile-time indices only: anything whose address
+// escapes into a closure ends up in scratch.
 template <int MB, int I, bool FAST>
 __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], float* smf, const float2* rowf,
                                                 const radmmm_rowgemm_desc& p, const radmmm::EpilogueCtx& ec, float sc,
-                                                int m0, int n0, int tid, int lane, int wave, const float (&biasv)[4]) {
+                                                int m0, int n0, int tid, int lane, int wave, const float (&biasv)[4],
+                                                const EpiConst& kc, float& sat) {
   if constexpr (I < MB) {
+    const int c4 = (tid & 63) * 4;
+    const int rbase = m0 + I * 32 + (tid >> 6);
+    const bool live = FAST && (m0 + I * 32 < p.M) && (n0 + c4 < p.N);
+    // two register sets (A, B) of side inputs, one pair of rows each; named scalars, no arrays
+    float4 aA0, dA0, cA0, aA1, dA1, cA1, aB0, dB0, cB0, aB1, dB1, cB1;
+    aA0 = dA0 = cA0 = aA1 = dA1 = cA1 = aB0 = dB0 = cB0 = aB1 = dB1 = cB1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define RADMMM_EPI_FETCH(S, PAIR)                                                          \
+  fetch_side(p, live, rbase + (2 * (PAIR)) * 4, n0 + c4, a##S##0, d##S##0, c##S##0);       \
+  fetch_side(p, live, rbase + (2 * (PAIR) + 1) * 4, n0 + c4, a##S##1, d##S##1, c##S##1);
+#define RADMMM_EPI_ROW(S, K, PAIR)                                                         \
+  {                                                                                        \
+    const int rl = (2 * (PAIR) + (K)) * 4 + (tid >> 6);                                    \
+    const int row = m0 + I * 32 + rl;                                                      \
+    if (row < p.M) {                                                                       \
+      const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);              \
+      const float2 rf = rowf[I * 32 + rl];                                                 \
+      sat = fmaxf(sat, epilogue_row_fast(p, row, n0 + c4, a4, rf.x, rf.y, kc, a##S##K, d##S##K, c##S##K)); \
+    }                                                                                      \
+  }
+    if constexpr (FAST) { RADMMM_EPI_FETCH(A, 0) }
     if (I > 0) radmmm::lds_barrier();      // the previous block has been read out (its global stores stay in flight)
     float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
 #pragma unroll
@@ -110,31 +132,29 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
       for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[I][j][e] * sc;
     radmmm::lds_barrier();
     if (m0 + I * 32 < p.M) {
-      const int c4 = (tid & 63) * 4;
       if constexpr (FAST) {
         if (n0 + c4 < p.N) {
-#pragma unroll 2
-          for (int k = 0; k < 8; ++k) {
-            const int rl = k * 4 + (tid >> 6);
-            const int row = m0 + I * 32 + rl;
-            if (row < p.M) {
-              const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
-              const float2 rf = rowf[I * 32 + rl];
-              epilogue_row_fast(p, row, n0 + c4, a4, rf.x, rf.y, biasv[0], biasv[1], biasv[2], biasv[3]);
-            }
-          }
+          RADMMM_EPI_FETCH(B, 1)
+          RADMMM_EPI_ROW(A, 0, 0) RADMMM_EPI_ROW(A, 1, 0)
+          RADMMM_EPI_FETCH(A, 2)
+          RADMMM_EPI_ROW(B, 0, 1) RADMMM_EPI_ROW(B, 1, 1)
+          RADMMM_EPI_FETCH(B, 3)
+          RADMMM_EPI_ROW(A, 0, 2) RADMMM_EPI_ROW(A, 1, 2)
+          RADMMM_EPI_ROW(B, 0, 3) RADMMM_EPI_ROW(B, 1, 3)
         }
+#undef RADMMM_EPI_FETCH
+#undef RADMMM_EPI_ROW
       } else {
 #pragma unroll 1
         for (int k = 0; k < 8; ++k) {
           const int rl = k * 4 + (tid >> 6);
           const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
           const float2 rf = rowf[I * 32 + rl];
-          radmmm::epilogue_store4_pre(p, ec, m0 + I * 32 + rl, n0 + c4, a4, rf.x, rf.y, biasv);
+          sat = fmaxf(sat, radmmm::epilogue_store4_pre(p, ec, m0 + I * 32 + rl, n0 + c4, a4, rf.x, rf.y, biasv));
         }
       }
     }
-    epilogue_blocks<MB, I + 1, FAST>(acc, smf, rowf, p, ec, sc, m0, n0, tid, lane, wave, biasv);
+    epilogue_blocks<MB, I + 1, FAST>(acc, smf, rowf, p, ec, sc, m0, n0, tid, lane, wave, biasv, kc, sat);
   }
 }
 
@@ -152,12 +172,17 @@ constexpr int DPI = 2;          // DMA pieces issued per pipeline item
 // beyond M / N, frames outside the utterance or masked) get an out-of-range buffer offset and
 // the DMA writes zeros.  The tile for step s + 1 is issued, two pieces per item, early in step s into
 // the other LDS stage and has the rest of the step to land; the barrier's vmcnt(0) retires it.
-// PR = MFMA products per fp32 product: 3 (split-f16, fp32-class accuracy) or 1 (plain fp16 operands:
-// the hi halves only -- the "16-bit throughput mode", half the operand traffic and a third of the MFMAs)
+// PR = product scheme: 3 split-f16 (Ah.Bh + Ah.Bl + Al.Bh on the f16 pipe, fp32-class accuracy); 1 plain fp16
+// operands (the hi halves only -- the "16-bit throughput mode", half the operand traffic and a third of the MFMAs);
+// 2 "FP8 cross terms": Ah.Bh on the f16 pipe and Ah.Bl + Al.Bh as ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per
+// 32-deep k step and output tile, reading the 8-bit cross arrays (split_pack.h) through the very same LDS tile, DMA
+// pieces and ds_read_b128 pattern as the f16 lo arrays: chunk c of a 64-byte row is k 16c..16c+15 of hi8 (c < 2) or lo8
+// (c >= 2), and the instruction wants from lane (row, half h) exactly chunk h then chunk 2 + h (measured layout,
+// tools/mfma_f8_layout.hip).  MFMA time 2/3 of the split-f16 scheme, same operand bytes.
 template <int MB, int PR>
 struct Pieces {
-  static constexpr int A = PR == 3 ? MB : (2 * MB + 3) / 4;   // DMA pieces of A per wave
-  static constexpr int B = PR == 3 ? 8 : 4;
+  static constexpr int A = PR != 1 ? MB : (2 * MB + 3) / 4;   // DMA pieces of A per wave
+  static constexpr int B = PR != 1 ? 8 : 4;
   static constexpr int N = A + B;
 };
 
@@ -165,9 +190,9 @@ template <int MB, int T, int PR>
 __device__ __forceinline__ void pin_items_dma() {
   constexpr int NT = 2 * MB, NPT = Pieces<MB, PR>::N;
   if constexpr (T < NT - LOOKAHEAD) {
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 2 : 1, 0);
-    if constexpr (T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 : 2, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR != 1 ? 2 : 1, 0);
+    if constexpr (PR != 2 && T + LOOKAHEAD == MB) __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, PR == 2 ? (T == 0 ? 2 : 3) : 2 * PR, 0);
     constexpr int lo = DPI * T, hi = (DPI * (T + 1) < NPT) ? DPI * (T + 1) : NPT;
     if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, hi - lo, 0);
     pin_items_dma<MB, T + 1, PR>();
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   using G = Geo<MB>;
   constexpr int NT = 2 * MB, D = LOOKAHEAD, NG = 2 * MB;                // NG: 16-row groups of an A array
   constexpr int NPA = Pieces<MB, PR>::A, NP = Pieces<MB, PR>::N;        // DMA pieces per wave
-  static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP && (PR == 1 || PR == 3), "pipeline shape");
+  static_assert(MB >= 4 && MB <= 8 && D <= MB && DPI * (NT - D) >= NP && PR >= 1 && PR <= 3, "pipeline shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -214,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     const int c = 4 * k + wave;                       // wave-uniform
     // PR == 3: the 4*MB groups of {Ah, Al}; PR == 1: the 2*MB groups of Ah, the surplus (odd MB) is a
     // zero-writing piece into the dump area behind the stages
-    a_isl[k] = (PR == 3 && c >= NG) ? 1 : 0;
-    const bool real = PR == 3 || c < NG;
+    a_isl[k] = (PR != 1 && c >= NG) ? 1 : 0;
+    const bool real = PR != 1 || c < NG;
     const int j = a_isl[k] ? c - NG : c;
     const int r = m0 + 16 * j + d_row;
     a_t[k] = 0;
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     const int sbase = buf * G::STAGE;
     if (w < NPA) {
       const int dst = a_dst[w] < 0 ? 2 * G::STAGE + wave * 1024 : sbase + a_dst[w];
-      dma16((PR == 3 && a_isl[w]) ? rAl : rAh, (lds_u32_ptr)(sm + dst), a_vo[w] + kb * (BK * 2));
+      dma16((PR != 1 && a_isl[w]) ? rAl : rAh, (lds_u32_ptr)(sm + dst), a_vo[w] + kb * (BK * 2));
     } else {
       const int k = (w - NPA) & 3, arr = (w - NPA) >> 2;
       const int vo = b_voff[k] + (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
@@ -290,13 +315,17 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   for (int w = 0; w < NP; ++w) dma_piece(0, w, 0, 0);
   __syncthreads();
   f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
+  // item t of a K step = (k block kb, row block i): PR 1 / 3 run kb-major (all row blocks of k block 0, then of k block
+  // 1); PR 2 runs i-major (t = 2 i + kb) because its scaled FP8 MFMA needs both k blocks of a row block's cross fragment
+  auto item_kb = [](int t) { return PR == 2 ? (t & 1) : (t >= MB ? 1 : 0); };
+  auto item_i = [](int t) { return PR == 2 ? (t >> 1) : (t >= MB ? t - MB : t); };
   // fragment readers of LDS stage `bsel`
   auto read_a = [&](int bsel, int t) __attribute__((always_inline)) {
     const unsigned char* st = sm + bsel * G::STAGE;
-    const int fo = (t >= MB) ? f_off1 : f_off0;
-    const int i = t >= MB ? t - MB : t;
+    const int fo = item_kb(t) ? f_off1 : f_off0;
+    const int i = item_i(t);
     fah[t] = *reinterpret_cast<const f16x8*>(st + i * 32 * ROWB + fo);
-    if constexpr (PR == 3) fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
+    if constexpr (PR != 1) fal[t] = *reinterpret_cast<const f16x8*>(st + G::A_BYTES + i * 32 * ROWB + fo);
   };
   auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
     const unsigned char* sB = sm + bsel * G::STAGE + 2 * G::A_BYTES + wave * 64 * ROWB;
@@ -304,14 +333,33 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
-      if constexpr (PR == 3) bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+      if constexpr (PR != 1) bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
     }
   };
+  // PR 2: E8M0 block scales of the cross MFMA.  The scale byte of lane (row, half 0) applies to k block 0 = the first
+  // 16 bytes of both halves' fragments, that of lane (row, half 1) to the second 16 bytes: A = [hi8 | lo8 * 2^11],
+  // B = [lo8 * 2^11 | hi8], each further multiplied by 2^a8_exp / 2^b8_exp when it was written.
+  const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;
+  const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
+  auto cross = [&](int i, int j) __attribute__((always_inline)) {
+    const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, fal[2 * i]), __builtin_bit_cast(i32x4, fal[2 * i + 1]),
+                                             0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[0][j]), __builtin_bit_cast(i32x4, bl[1][j]),
+                                             0, 1, 2, 3, 4, 5, 6, 7);
+    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
+  };
   auto mfma_item = [&](int t) __attribute__((always_inline)) {
-    const int kb = t >= MB ? 1 : 0, i = t >= MB ? t - MB : t;
+    const int kb = item_kb(t), i = item_i(t);
     if constexpr (PR == 1) {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+    } else if constexpr (PR == 2) {
+      // 2 f16 + 1 scaled FP8 MFMA per item (the second cross MFMA of a row block rides with the next row block's first
+      // item, the last one follows the loop): every item carries the same MFMA time
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
+      if (kb == 1) cross(i, 0);
+      else if (i > 0) cross(i - 1, 1);
     } else {
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][0], acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], bh[kb][1], acc[i][1], 0, 0, 0);
@@ -323,6 +371,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   };
   // first fragments of step 0; every later step gets them from the tail of the previous one
   read_b(0, 0);
+  if constexpr (PR == 2) read_b(0, 1);
 #pragma unroll
   for (int t = 0; t < D; ++t) read_a(0, t);
   for (int step = 0; step < nsteps; ++step) {
@@ -333,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
 #pragma unroll
     for (int t = 0; t < NT - D; ++t) {
       read_a(buf, t + D);
-      if (t + D == MB) read_b(buf, 1);
+      if (PR != 2 && t + D == MB) read_b(buf, 1);
       mfma_item(t);
 #pragma unroll
       for (int q = 0; q < DPI; ++q)
@@ -341,17 +390,29 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     }
     pin_items_dma<MB, 0, PR>();
     // every read of stage `buf` has been issued: retire them and this wave's DMA, meet the other
-    // waves, then fetch the first fragments of the next step while the last D items' MFMAs run
+    // waves, then fetch the first fragments of the next step while the last D items' MFMAs run.
+    // PR 2: the last items still need this step's B cross fragments and their own A cross fragments, so the next
+    // step's fragments go to registers only after those MFMAs have been issued (program order below).
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    read_b(buf ^ 1, 0);
+    if constexpr (PR == 2) {
 #pragma unroll
-    for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
+      for (int t = NT - D; t < NT; ++t) mfma_item(t);
+      cross(MB - 1, 1);
+      read_b(buf ^ 1, 0);
+      read_b(buf ^ 1, 1);
 #pragma unroll
-    for (int t = NT - D; t < NT; ++t) mfma_item(t);
-    __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 + 2 * D : 2 + D, 0);
-    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR * D, 0);
+      for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
+    } else {
+      read_b(buf ^ 1, 0);
+#pragma unroll
+      for (int t = 0; t < D; ++t) read_a(buf ^ 1, t);
+#pragma unroll
+      for (int t = NT - D; t < NT; ++t) mfma_item(t);
+      __builtin_amdgcn_sched_group_barrier(SGB_DSR, PR == 3 ? 4 + 2 * D : 2 + D, 0);
+      __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 2 * PR * D, 0);
+    }
   }
   __syncthreads();                                   // stray fragment reads / DMA of the clamped extra tile
 
@@ -369,7 +430,10 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
 #pragma unroll
     for (int e = 0; e < 4; ++e) biasv[e] = (c + e < p.N) ? p.bias[c + e] : 0.f;
   }
-  epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv);
+  const EpiConst kc = {biasv[0], biasv[1], biasv[2], biasv[3], __builtin_ldexpf(1.f, p.ch_x8_exp), __builtin_ldexpf(1.f, p.c2h_x8_exp)};
+  float sat = 0.f;
+  epilogue_blocks<MB, 0, FASTEPI>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv, kc, sat);
+  radmmm::raise_sat_flag(p.sat_flag, sat);
 }
 
 template <int MB, int PR = 3, bool FASTEPI = false>
@@ -451,10 +515,18 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
                     (!p.C2 || (p.ldc2 % 4 == 0 && a16(p.C2) && fits(p.ldc2))) &&
                     (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && a8(p.Ch) && a8(p.Cl))) &&
                     (!p.C2h || (p.ldc2h % 4 == 0 && fits(p.ldc2h) && a8(p.C2h) && a8(p.C2l)));
+  // (the 8-bit split formats additionally need ld % 32 == 0 and 4-byte aligned cross arrays: checked by the caller
+  //  radmmm_rowgemm_h3 for every path)
 #define RADMMM_H3D_CASE(MBV, PRV)                                                 \
   case MBV:                                                                       \
     return fast ? launch_dma<MBV, PRV, true>(d, stream, a_bytes, b_bytes)         \
                 : launch_dma<MBV, PRV, false>(d, stream, a_bytes, b_bytes);
+  if (d.nprod == 2) {                                // FP8 cross terms
+    switch (mb) {
+      RADMMM_H3D_CASE(4, 2) RADMMM_H3D_CASE(5, 2) RADMMM_H3D_CASE(6, 2) RADMMM_H3D_CASE(7, 2)
+      default: return fast ? launch_dma<8, 2, true>(d, stream, a_bytes, b_bytes) : launch_dma<8, 2, false>(d, stream, a_bytes, b_bytes);
+    }
+  }
   if (d.nprod == 1) {                                // 16-bit throughput mode: hi halves only
     switch (mb) {
       RADMMM_H3D_CASE(4, 1) RADMMM_H3D_CASE(5, 1) RADMMM_H3D_CASE(6, 1) RADMMM_H3D_CASE(7, 1)

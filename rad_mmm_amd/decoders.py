@@ -139,8 +139,10 @@ class RADMMMFlow(nn.Module):
         self.decoder_cond_dims = decoder_cond_dims
         self.decoder_out_dims = n_mel_channels
         import os
-        # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA) or "h3" (split-f16 x3, fp32-class accuracy)
+        # GEMM arithmetic of the WN stack: "fp32" (fp32 MFMA), "h3" (split-f16 x3, fp32-class accuracy), "f8x" (f16 hi.hi
+        # product + FP8 cross terms), "f16" (single product: throughput mode)
         self.gemm_precision = os.environ.get("RADMMM_PRECISION", "h3")
+        self._grad_scale = None
         # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen)
         self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if use_context_lstm else "miopen"
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
@@ -175,6 +177,15 @@ class RADMMMFlow(nn.Module):
     def enable_inverse_cache(self):
         for f in self.flows:
             f.enable_inverse_cache()
+
+    def check_saturation(self):
+        """Synchronous form of the split-operand path's range check (ops.GradScale): raises FloatingPointError if a
+        gradient (or activation) element left the fp16 range of its split copy since the last check and was clamped.
+        Without this call the same error is raised, one pass late and without any host synchronisation, by the next
+        training pass.  The reference's fp32 path has no such range limit; call this before optimizer.step() to keep a
+        clamped gradient from being applied."""
+        if self._grad_scale is not None:
+            self._grad_scale.check()
 
     def remove_norms(self):
         """models/radmmm.py:150-166 ("call before inference"): strips the spectral / weight norm from the context
@@ -370,7 +381,11 @@ class RADMMMFlow(nn.Module):
         unfolded = _UnfoldedLens(out_lens, g, Tg)
 
         z_out, log_s_list, log_det_W_list = [], [], []
-        scale_box = {}                 # gradient scale of the split-f16 path, fixed by the first backward node
+        if getattr(self, "_grad_scale", None) is None:
+            self._grad_scale = ops.GradScale()
+        scale_box = self._grad_scale   # gradient scale + saturation flag of the split-operand path (no host sync in steady state)
+        if torch.is_grad_enabled():
+            scale_box.new_forward(mel.device)
         for i, flow in enumerate(self.flows):
             off = 0
             if i in self.exit_steps:

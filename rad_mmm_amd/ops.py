@@ -13,7 +13,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad, f32c, amp_fwd, amp_bwd
+from ._lib import (ACT, SCALE, lib, check, ptr, stream, rowgemm, wgrad, f32c, amp_fwd, amp_bwd, split_opts, SPLIT_F16,
+                   SPLIT_X8A, SPLIT_X8B)
 
 ZLD = 160            # row pitch of every flow-variable matrix (n_mel*group padded, see decoders.py)
 
@@ -175,7 +176,7 @@ class AffineFlowStepFn(torch.autograd.Function):
                 bias=b_eff)
         # 2. WN input cat((z0, context)) (common.py:819), K-padded
         X0 = _empty(N, Kp, like=z_in)
-        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, None, None, stream()), "wn_input_fwd")
+        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, None, None, None, stream()), "wn_input_fwd")
         # 3. weight-norm fold (common.py:791,813,174)
         perm = (h, D, 0)                             # ref cols [z0 | ctx] -> packed [ctx | z0 | 0]
         Ws, inv_s = weightnorm_fwd(start_v, start_g, Kp, perm)
@@ -263,7 +264,7 @@ class AffineFlowStepFn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             # through softplus of the res/skip branch
             check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, None, None, 0, 1.0,
-                                      stream()), "dact_mul")
+                                      None, stream()), "dact_mul")
             g_res[3 * j + 2] = colsum(gQ, Wc)
             slabs = wgrad_slabs(gQ, Wc, H[j + 1], Wc, Wc, T, None)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
@@ -406,7 +407,7 @@ class ConvNormFn(torch.autograd.Function):
         rowscale = 2 if partial else (1 if mask_out else 0)
         gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
-                                  taps, dil, None, None, 0, 1.0, stream()), "dact_mul")
+                                  taps, dil, None, None, 0, 1.0, None, stream()), "dact_mul")
         g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil) if ctx.has_bias else None
         ldw = W.shape[2]
         slabs = wgrad_slabs(gpre, Cout, x, Cin, ldw, T, lens, taps=taps, dil=dil, x_mask_mode=1 if partial else 0)
@@ -434,8 +435,8 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
     min_rows = int(os.environ.get("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
     prec = os.environ.get("RADMMM_PRECISION", "h3")
-    meta["nprod"] = 1 if prec == "f16" else 3
-    if (prec in ("h3", "f16") and Cin % 32 == 0 and (taps // 2) * dil <= 16
+    meta["nprod"] = NPROD.get(prec, 3)
+    if (prec in NPROD and Cin % 32 == 0 and (taps // 2) * dil <= 16
             and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
         return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
     return ConvNormFn.apply(meta, x, v, g, bias, lens)
@@ -508,6 +509,8 @@ def stft_mel(audio: torch.Tensor, basis: torch.Tensor, mel_basis: torch.Tensor, 
 from ._lib import rowgemm_h3  # noqa: E402
 
 W_SCALE = 256.0          # power-of-two scale of the split weights (|w| <= |g| ~ 1 after weight norm)
+# RADMMM_PRECISION / gemm_precision -> product scheme of radmmm_rowgemm_h3 ("fp32" uses the fp32-MFMA kernels instead)
+NPROD = {"h3": 3, "f8x": 2, "f16": 1}
 
 
 def _halves(*shape, like, zero=False):
@@ -515,31 +518,47 @@ def _halves(*shape, like, zero=False):
     return f(*shape, device=like.device, dtype=torch.float16), f(*shape, device=like.device, dtype=torch.float16)
 
 
-def split_weight(v, g, ldk, perm=(0, 0, 0)):
-    """v [Cout, Cin, taps] (+ weight-norm g or None) -> split packed W{h,l} [taps, Cout, ldk], inv_norm."""
+# 8-bit parts of the "FP8 cross terms" scheme (nprod = 2) are written as value * 2^e: activations
+# (softplus outputs, typically 0.01 .. 10) x4, gradients (scaled so that the pass's amax is 8 .. 16) x16, weights (x256
+# already, |w| <= ~1) x1 -- all stay below e4m3's 448 and 17 binades above its smallest subnormal
+X8_ACT_EXP, X8_GRAD_EXP, X8_W_EXP = 2, 4, 0
+
+
+def fmt_a(nprod: int) -> int:
+    return SPLIT_X8A if nprod == 2 else SPLIT_F16
+
+
+def fmt_b(nprod: int) -> int:
+    return SPLIT_X8B if nprod == 2 else SPLIT_F16
+
+
+def split_weight(v, g, ldk, perm=(0, 0, 0), nprod=3):
+    """v [Cout, Cin, taps] (+ weight-norm g or None) -> split packed W{h,l} [taps, Cout, ldk], inv_norm (nprod 2: Wl is
+    the B-role 8-bit cross array, same shape/dtype container)."""
     Cout, Cin, taps = v.shape
     Wh, Wl = _halves(taps, Cout, ldk, like=v, zero=(ldk != Cin or perm != (0, 0, 0)))
     inv = _empty(Cout, like=v) if g is not None else None
     check(lib.radmmm_weightnorm_fwd_h3(ptr(v), ptr(g), ptr(Wh), ptr(Wl), ptr(inv), Cout, Cin, taps, ldk, perm[0], perm[1],
-                                       perm[2], W_SCALE, stream()), "weightnorm_fwd_h3")
+                                       perm[2], W_SCALE, split_opts(fmt_b(nprod), X8_W_EXP), stream()), "weightnorm_fwd_h3")
     return Wh, Wl, inv
 
 
-def transpose_split(Wh, Wl, rows, cols, ld_dst):
+def transpose_split(Wh, Wl, rows, cols, ld_dst, nprod=3):
     """[taps][rows][ld] pair -> [taps][cols][ld_dst] (zero padded), i.e. the K-contiguous operand of the
     data-gradient GEMM."""
     taps = Wh.shape[0]
     Th, Tl = _halves(taps, cols, ld_dst, like=Wh, zero=(ld_dst != rows))
     check(lib.radmmm_transpose_f16_pair(ptr(Wh), ptr(Wl), Wh.shape[2], Wh.stride(0), ptr(Th), ptr(Tl), ld_dst, Th.stride(0),
-                                        taps, rows, cols, stream()), "transpose_f16_pair")
+                                        taps, rows, cols, fmt_b(nprod), X8_W_EXP, stream()), "transpose_f16_pair")
     return Th, Tl
 
 
-def split_f16(x, cols, scale, ldh=None):
+def split_f16(x, cols, scale, ldh=None, nprod=3, x8_exp=0, sat_flag=None):
     rows = x.shape[0]
-    ldh = ldh or round_up(cols, 8)
+    ldh = ldh or round_up(cols, 32 if nprod == 2 else 8)
     hi, lo = _halves(rows, ldh, like=x)
-    check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale, stream()), "split_f16")
+    check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale,
+                               split_opts(fmt_a(nprod), x8_exp, sat_flag), stream()), "split_f16")
     return hi, lo
 
 
@@ -607,33 +626,127 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     return P
 
 
+class GradScale:
+    """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
+    a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), a device-side
+    saturation flag OR-ed by every split producer that had to clamp, and the bookkeeping that keeps both off the host's
+    critical path.
+
+    Steady state has NO host synchronisation: the first backward node of pass k queues `amax(|g|)` of its incoming
+    gradient; the next forward queues an asynchronous copy of (amax, flag) to pinned memory behind an event and clears the
+    flag; the first backward node of a later pass polls that event (query, never wait), adopts the new S and raises
+    FloatingPointError if the flag was set -- the gradients of THAT earlier pass were clamped (dict-like access keeps
+    the "S" key of the former plain-dict box working).  Only the very first pass of a module synchronises once.
+    `check()` is the synchronous form (end of a step, tests); RADMMM_CHECK_SATURATION=1 calls it after every flow step."""
+
+    def __init__(self):
+        self.S = None
+        self.flag = None          # device int32[1]
+        self.amax = None          # device fp32[1]
+        self._host = None         # pinned fp32[2]: amax, flag
+        self._event = None
+        self._pending = False
+        self._fwd_id = 0
+        self._bwd_id = -1
+        self._stats_fwd = -1      # forward id whose backward produced the device stats
+
+    # dict-like compatibility ("S")
+    def get(self, k, d=None):
+        return self.S if k == "S" and self.S is not None else d
+
+    def __setitem__(self, k, v):
+        assert k == "S"
+        self.S = v
+
+    def _ensure(self, dev):
+        if self.flag is None or self.flag.device != dev:
+            self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.amax = torch.zeros(1, device=dev, dtype=torch.float32)
+            self._host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._event = torch.cuda.Event()
+            self._pending = False
+
+    @staticmethod
+    def _pow2(amax: float) -> float:
+        if not (amax > 0 and math.isfinite(amax)):
+            return 1.0
+        return float(2.0 ** max(-40, min(40, math.floor(math.log2(16.0 / amax)))))
+
+    def _consume(self):
+        """host copy is complete: adopt the scale, report a saturated pass"""
+        self._pending = False
+        amax, flag = float(self._host[0]), float(self._host[1])
+        self.S = self._pow2(amax) if amax > 0 else self.S
+        if flag != 0.0:
+            raise FloatingPointError(
+                "split-f16 gradient saturated in an earlier backward pass: a gradient element exceeded 2^12 x the first "
+                "gradient's maximum and was clamped (that pass's gradients are not exact; the scale has been refreshed)")
+
+    def new_forward(self, dev):
+        """called by the owning module at the start of a training forward"""
+        self._ensure(dev)
+        if self._pending and self._event.query():
+            self._consume()
+        if self._stats_fwd == self._fwd_id and not self._pending:
+            # publish the stats of the backward that followed the previous forward, then re-arm the flag
+            self._host[0:1].copy_(self.amax, non_blocking=True)
+            self._host[1:2].copy_(self.flag.float(), non_blocking=True)
+            self._event.record()
+            self.flag.zero_()
+            self._pending = True
+        self._fwd_id += 1
+
+    def scale(self, g: torch.Tensor) -> float:
+        """S for this backward pass; the first node of the pass (re)initialises the pass"""
+        self._ensure(g.device)
+        if self._bwd_id != self._fwd_id:
+            self._bwd_id = self._fwd_id
+            if self._pending and self._event.query():
+                self._consume()
+            if self.S is None:                              # first pass of this module: one synchronisation
+                self.S = self._pow2(float(g.abs().max()))
+            torch.amax(g.detach().abs().reshape(-1), dim=0, keepdim=True, out=self.amax)
+            self._stats_fwd = self._fwd_id
+        return self.S
+
+    def check(self) -> None:
+        """synchronous: raise FloatingPointError if a split producer has clamped since the flag was last cleared"""
+        if self._pending:
+            self._event.synchronize()
+            self._consume()
+        if self.flag is not None and int(self.flag.item()) != 0:
+            self.flag.zero_()
+            raise FloatingPointError("split-f16 gradient saturated: a gradient element exceeds 2^12 x the first gradient's "
+                                     "maximum of this backward pass and was clamped")
+
+
 def grad_scale(box, g: torch.Tensor) -> float:
-    """Power-of-two scale of the split GRADIENT tensors, fixed once per backward pass from the first
-    incoming gradient (one host sync per step): amax * S ~ 16 leaves 2^12 of fp16 headroom."""
+    """Power-of-two scale of the split GRADIENT tensors for this backward pass (see GradScale); a plain dict `box`
+    (stand-alone conv_norm calls) fixes it from the first gradient with one host sync."""
+    if isinstance(box, GradScale):
+        return box.scale(g)
     if box.get("S") is None:
-        amax = float(g.abs().max())
-        box["S"] = 1.0 if not (amax > 0 and math.isfinite(amax)) else float(2.0 ** max(0, min(40, math.floor(math.log2(16.0 / amax)))))
+        box["S"] = GradScale._pow2(float(g.abs().max()))
     return box["S"]
 
 
-_SAT = 60000.0           # the split kernels clamp scale*x to +-60000 before the fp16 conversion
+def sat_flag_of(box) -> Optional[torch.Tensor]:
+    return box.flag if isinstance(box, GradScale) else None
 
 
-def check_saturation(what: str, *his: torch.Tensor) -> None:
-    """RADMMM_CHECK_SATURATION=1 (debugging aid, one host sync per call): raise if a split gradient tensor hit the
-    fp16 clamp, i.e. a gradient element exceeded 2^12 x the first gradient's maximum this pass."""
-    if os.environ.get("RADMMM_CHECK_SATURATION", "0") != "1":
-        return
-    for hi in his:
-        if hi is not None and bool((hi.abs() >= _SAT).any()):
-            raise FloatingPointError(f"split-f16 gradient saturated in {what}: a gradient element exceeds 2^12 x the "
-                                     "first gradient's maximum of this backward pass")
+def check_saturation(box) -> None:
+    """RADMMM_CHECK_SATURATION=1 (debugging aid, one host sync per call): raise as soon as a split tensor hit the fp16
+    clamp instead of at the next pass."""
+    if os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1" and isinstance(box, GradScale):
+        box.check()
 
 
 class AffineFlowStepH3Fn(torch.autograd.Function):
-    """Same contract as AffineFlowStepFn; the WN convs run on radmmm_rowgemm_h3 (split-f16, fp32
-    accumulate).  The 160-wide invertible 1x1, all weight gradients (contraction over frames) and
-    every elementwise / reduction kernel stay fp32."""
+    """Same contract as AffineFlowStepFn; the WN convs run on radmmm_rowgemm_h3 (split operands on the f16 / fp8 matrix
+    cores, fp32 accumulate).  meta["nprod"]: 3 = split-f16 (three f16 products), 2 = f16 product + FP8 cross terms
+    (second array of every row-major split pair is then the 8-bit cross array), 1 = fp16 throughput mode.
+    The 160-wide invertible 1x1, all weight gradients (contraction over frames, always split-f16 on transposed copies
+    made from the fp32 tensors) and every elementwise / reduction kernel stay fp32."""
 
     @staticmethod
     @amp_fwd
@@ -641,7 +754,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 *layer_params):
         B, T, C, D, nl = meta["B"], meta["T"], meta["C"], meta["D"], meta["n_layers"]
         act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
-        NPR = meta.get("nprod", 3)               # MFMA products per fp32 product: 3 = split-f16, 1 = fp16 throughput mode
+        NPR = meta.get("nprod", 3)               # product scheme, see the class docstring
+        box = meta["scale_box"]
+        flag = sat_flag_of(box)
+        fa = fmt_a(NPR)
         h = C // 2
         N = B * T
         Wc = start_v.shape[0]
@@ -649,27 +765,30 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
         assert Wc % 32 == 0 and z_in.shape == (N, ZLD) and cond.shape == (N, D)
         inv_ws = 1.0 / W_SCALE
+        # keyword sets shared by the launches of this pass: operand exponents in, output format out
+        gin = dict(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, acc_scale=inv_ws, T=T, sat_flag=flag)
+        gout = dict(split_fmt=fa, ch_x8_exp=X8_ACT_EXP, c2h_x8_exp=X8_ACT_EXP)
 
         z1 = _empty(N, ZLD, like=z_in)
         rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
         X0 = _empty(N, Kp, like=z_in)
         X0h, X0l = _halves(N, Kp, like=z_in)
-        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l), stream()),
-              "wn_input_fwd")
+        check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l),
+                                      split_opts(fa, X8_ACT_EXP), stream()), "wn_input_fwd")
         perm = (h, D, 0)
-        Wsh, Wsl, inv_s = split_weight(start_v, start_g, Kp, perm)
+        Wsh, Wsl, inv_s = split_weight(start_v, start_g, Kp, perm, NPR)
         Wih, Wil, inv_i, Wrh, Wrl, inv_r = [], [], [], [], [], []
         for j in range(nl):
-            a, b, iv = split_weight(in_p[3 * j], in_p[3 * j + 1], Wc)
+            a, b, iv = split_weight(in_p[3 * j], in_p[3 * j + 1], Wc, nprod=NPR)
             Wih.append(a); Wil.append(b); inv_i.append(iv)
-            a, b, iv = split_weight(res_p[3 * j], res_p[3 * j + 1], Wc)
+            a, b, iv = split_weight(res_p[3 * j], res_p[3 * j + 1], Wc, nprod=NPR)
             Wrh.append(a); Wrl.append(b); inv_r.append(iv)
-        Weh, Wel, _ = split_weight(end_w, None, Wc)
+        Weh, Wel, _ = split_weight(end_w, None, Wc, nprod=NPR)
 
         H = [_empty(N, Wc, like=z_in)]
         Hh, Hl = _halves(N, Wc, like=z_in)
-        rowgemm_h3(nprod=NPR, Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, acc_scale=inv_ws, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
-                   T=T, bias=start_b, Ch=Hh, Cl=Hl, ldch=Wc, ch_scale=1.0)
+        rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
+                   bias=start_b, Ch=Hh, Cl=Hl, ldch=Wc, ch_scale=1.0, **gin, **gout)
         OUT = _empty(N, Wc, like=z_in)
         OUTh, OUTl = _halves(N, Wc, like=z_in)
         R = []
@@ -678,21 +797,21 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             Hn = _empty(N, Wc, like=z_in)
             Hnh, Hnl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(nprod=NPR, Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
-                       acc_scale=inv_ws, C=Hn, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, T=T, lens=lens,
+            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
+                       C=Hn, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, lens=lens,
                        a_mask_mode=1 if partial else 0, bias=in_p[3 * j + 2], pconv=1 if partial else 0, ratio_taps=kt,
-                       ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, ldch=Wc, ch_scale=1.0)
+                       ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, ldch=Wc, ch_scale=1.0, **gin, **gout)
             H.append(Hn)
             Hh, Hl = Hnh, Hnl
             Rj = _empty(N, Wc, like=z_in)
             last = j == nl - 1
-            rowgemm_h3(nprod=NPR, Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, acc_scale=inv_ws, C=Rj, ldc=Wc, M=N, N=Wc,
-                       K=Wc, T=T, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
-                       C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0)
+            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc,
+                       K=Wc, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
+                       C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0, **gin, **gout)
             R.append(Rj)
         O = _empty(N, ZLD, like=z_in)
-        rowgemm_h3(nprod=NPR, Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, acc_scale=inv_ws, C=O, ldc=ZLD, M=N, N=C, K=Wc,
-                   T=T, bias=end_b)
+        rowgemm_h3(Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, C=O, ldc=ZLD, M=N, N=C, K=Wc,
+                   bias=end_b, **gin)
         z_out = _empty(N, ZLD, like=z_in)
         log_s = _empty(N, h, like=z_in)
         check(lib.radmmm_affine_coupling_fwd(ptr(O), ZLD, ptr(z1), ZLD, ptr(z_out), ptr(log_s), N, h, scaling,
@@ -709,12 +828,12 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
     def backward(ctx, g_zout, g_logs):
         meta, nl = ctx.meta, ctx.nl
         NPR = meta.get("nprod", 3)
+        WPR = 3 if NPR == 2 else NPR             # weight gradients: split-f16 (or the throughput mode's single product)
         B, T, C, D = meta["B"], meta["T"], meta["C"], meta["D"]
         act, scaling, partial = meta["act"], meta["scaling"], meta["partial"]
         sv = ctx.saved_tensors
         z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel, start_b, end_b = sv[:17]
         p = 17
-        take = lambda n: sv[p: p + n]
         H = sv[p: p + nl + 1]; p += nl + 1
         R = sv[p: p + nl]; p += nl
         Wih = sv[p: p + nl]; p += nl
@@ -732,8 +851,14 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_zout = g_zout.contiguous()
         if g_logs is not None:
             g_logs = g_logs.contiguous()
-        SG = grad_scale(meta["scale_box"], g_zout)
+        box = meta["scale_box"]
+        SG = grad_scale(box, g_zout)
+        flag = sat_flag_of(box)
+        fa = fmt_a(NPR)
         inv_acc = 1.0 / (SG * W_SCALE)
+        gin = dict(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, acc_scale=inv_acc, T=T, sat_flag=flag)
+        gout = dict(split_fmt=fa, ch_x8_exp=X8_GRAD_EXP)
+        so_g = lambda: split_opts(fa, X8_GRAD_EXP, flag)
 
         gO = torch.zeros(N, ZLD, device=z_in.device, dtype=torch.float32)      # columns >= C stay zero (K = ZLD)
         gz1 = _empty(N, ZLD, like=z_in)
@@ -742,12 +867,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_end_b = colsum(gO, C, out=grad_out(end_b))
         g_end_w = grad_out(end_w)
         torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
-        gOh, gOl = split_f16(gO, ZLD, SG, ZLD)
-        check_saturation("flow step: coupling gradient", gOh)
-        WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD)                    # [1][Wc][ZLD]
+        gOh, gOl = split_f16(gO, ZLD, SG, ZLD, NPR, X8_GRAD_EXP, flag)
+        WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD, NPR)                    # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
-        rowgemm_h3(nprod=NPR, Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, acc_scale=inv_acc, C=gOUT, ldc=Wc, M=N, N=Wc,
-                   K=ZLD, T=T)
+        rowgemm_h3(Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, C=gOUT, ldc=Wc, M=N, N=Wc, K=ZLD, **gin)
         g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         G = None
@@ -759,51 +882,55 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
             check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
-                                      ptr(gQl), Wc, SG, stream()), "dact_mul")
+                                      ptr(gQl), Wc, SG, so_g(), stream()), "dact_mul")
             gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
                                                          sum_out=grad_out(res_p[3 * j + 2]))
-            # H[j+1]'s transposed copy is still in the pool from layer j+1's in_layer weight gradient (made with
-            # the length mask, which only changes frames where gQ is exactly zero)
+            # H[j+1]'s transposed copy may still be in the pool from layer j+1's in_layer weight gradient (x_prev, set
+            # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)
             x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
-            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, NPR)
+            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
-            WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc)
+            WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
             g_conv = _empty(N, Wc, like=z_in)
             gch, gcl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(nprod=NPR, Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, acc_scale=inv_acc, C=g_conv, ldc=Wc, M=N,
-                       N=Wc, K=Wc, T=T, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
-                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
+            rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, C=g_conv, ldc=Wc, M=N,
+                       N=Wc, K=Wc, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
+                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG,
+                       **gin, **gout)
             if (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
                                                             colsum=(2 if partial else 0, lens, kt, d),
                                                             sum_out=grad_out(in_p[3 * j + 2]))
                 x_t = transpose_split_act(H[j], Wc, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(d % 2 == 1))
-                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG, NPR)
-                x_prev = x_t if d % 2 == 0 else None
+                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, kt, d, 1.0 / SG, WPR)
+                # reusable by layer j-1's res_skip gradient (even dilation: no advanced copy in the way).  The copy was made
+                # with the length mask (partial padding), the res_skip gradient wants H[j] unmasked: the two are the same
+                # tensor because H[j], j >= 1, is exactly zero at frames >= len (in_layer j-1's epilogue multiplies by the
+                # mask, common.py:186-190) -- independent of the upstream gradient, so any loss is handled exactly
+                x_prev = x_t if (d % 2 == 0 and j >= 1) else None
             else:
                 x_prev = None
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
             g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
-            WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc)            # [taps][ci][co]
+            WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)            # [taps][ci][co]
             G = _empty(N, Wc, like=z_in)
             if j == 0:
                 Gh, Gl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(nprod=NPR, Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
-                       acc_scale=inv_acc, C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, T=T, lens=lens,
+            rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
+                       C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
-                       ldch=Wc, ch_scale=SG)
-            check_saturation(f"flow step: WN layer {j}", gQh, gch, Gh if j == 0 else None)
+                       ldch=Wc, ch_scale=SG, **gin, **gout)
+            check_saturation(box)
         perm = (h, D, 0)
         gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
                                               sum_out=grad_out(start_b))
         x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
-        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, NPR)
+        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, WPR)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
-        WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc)                      # [1][Kp][Wc]
+        WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)                      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)
-        rowgemm_h3(nprod=NPR, Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, acc_scale=inv_acc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc,
-                   T=T)
+        rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc, **gin)
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
         g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
@@ -815,7 +942,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
 
 
 class ConvNormH3Fn(torch.autograd.Function):
-    """ConvNormFn on the split-f16 GEMM path: same contract, Cin % 32 == 0.  The input is
+    """ConvNormFn on the split-operand GEMM path: same contract, Cin % 32 == 0.  The input is
     split on the fly, the weight gradient runs on transposed zero-gapped split copies, the bias gradient
     comes out of the transposing pass; Cout is padded to a multiple of 32 for the data gradient's K."""
 
@@ -825,14 +952,16 @@ class ConvNormH3Fn(torch.autograd.Function):
         B, T, dil = meta["B"], meta["T"], meta["dil"]
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
         NPR = meta.get("nprod", 3)
+        flag = sat_flag_of(meta["scale_box"])
         Cout, Cin, taps = v.shape
         N = B * T
         assert x.shape[0] == N and x.shape[1] >= Cin and x.is_contiguous()
-        xh, xl = split_f16(x, Cin, 1.0, Cin)
-        Wh, Wl, inv = split_weight(v, g, Cin)
+        xh, xl = split_f16(x, Cin, 1.0, Cin, NPR, X8_ACT_EXP, flag)
+        Wh, Wl, inv = split_weight(v, g, Cin, nprod=NPR)
         ldy = round_up(Cout, 4)
         y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
-        rowgemm_h3(nprod=NPR, Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin, b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
+        rowgemm_h3(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin,
+                   b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
                    C=y, ldc=ldy, M=N, N=Cout, K=Cin, taps=taps, dil=dil, sign=1, T=T, lens=lens,
                    a_mask_mode=1 if partial else 0, bias=bias, pconv=1 if partial else 0, ratio_taps=taps, ratio_dil=dil,
                    postmask=1 if mask_out else 0, act=act)
@@ -851,24 +980,25 @@ class ConvNormH3Fn(torch.autograd.Function):
         x, v, g, lens, Wh, Wl, inv, y = ctx.saved_tensors
         lens = lens if ctx.has_lens else None
         NPR = meta.get("nprod", 3)
+        WPR = 3 if NPR == 2 else NPR
         Cout, Cin, taps = v.shape
         N = B * T
         gy = gy.contiguous()
         ldy = y.shape[1]
-        SG = grad_scale(meta["scale_box"], gy)
+        box = meta["scale_box"]
+        SG = grad_scale(box, gy)
+        flag = sat_flag_of(box)
         Kp = round_up(Cout, 32)
         rowscale = 2 if partial else (1 if mask_out else 0)
         gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
-        gph, gpl = _halves(N, Kp, like=y)
-        if Kp != Cout:
-            gph[:, Cout:].zero_()
-            gpl[:, Cout:].zero_()
+        gph, gpl = _halves(N, Kp, like=y, zero=(Kp != Cout))       # K padding of the data gradient must read as zeros
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
-                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, stream()), "dact_mul")
+                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), X8_GRAD_EXP, flag), stream()),
+              "dact_mul")
         gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
                                            colsum=(2 if partial else 0, lens, taps, dil))
         x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
-        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, NPR)
+        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, WPR)
         if ctx.has_g:
             g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin)
         else:
@@ -876,8 +1006,10 @@ class ConvNormH3Fn(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[1]:
             gx = torch.zeros_like(x) if x.shape[1] != Cin else torch.empty_like(x)
-            WTh, WTl = transpose_split(Wh, Wl, Cout, Cin, Kp)                   # [taps][Cin][Kp]
-            rowgemm_h3(nprod=NPR, Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp, b_tap_stride_h=WTh.stride(0),
+            WTh, WTl = transpose_split(Wh, Wl, Cout, Cin, Kp, NPR)                   # [taps][Cin][Kp]
+            rowgemm_h3(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp,
+                       b_tap_stride_h=WTh.stride(0),
                        acc_scale=1.0 / (SG * W_SCALE), C=gx, ldc=x.shape[1], M=N, N=Cin, K=Kp, taps=taps, dil=dil, sign=-1,
                        T=T, lens=lens, a_mask_mode=0, premask=1 if partial else 0)
+        check_saturation(box)
         return None, gx, g_v, g_g, g_bias if ctx.has_bias else None, None

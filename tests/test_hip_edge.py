@@ -253,6 +253,51 @@ def test_saturation_check_flags_an_overflowing_gradient_scale(monkeypatch):
         step()
 
 
+def test_saturation_is_detected_by_default(monkeypatch):
+    """Without RADMMM_CHECK_SATURATION: a split producer that has to clamp raises the decoder's device-side flag; the
+    error surfaces (a) synchronously from decoder.check_saturation() and (b) without any synchronisation from a later
+    training pass.  A step in range raises nothing."""
+    import time
+    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.delenv("RADMMM_CHECK_SATURATION", raising=False)
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=3, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+
+    def step():
+        dec.zero_grad(set_to_none=True)
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+
+    for _ in range(3):
+        step()
+        dec.check_saturation()                               # in range: no complaint, scale carried between passes
+    real = ops.grad_scale
+    monkeypatch.setattr(ops, "grad_scale", lambda box, g: real(box, g) * 2.0 ** 30)
+    step()                                                   # saturates silently on the device ...
+    with pytest.raises(FloatingPointError, match="saturated"):
+        dec.check_saturation()                               # ... (a) reported synchronously
+    step()                                                   # saturates again; flag published by the next forward
+    monkeypatch.setattr(ops, "grad_scale", real)
+    with pytest.raises(FloatingPointError, match="saturated"):
+        for _ in range(4):                                   # (b) a later pass picks the flag up by polling
+            torch.cuda.synchronize()
+            time.sleep(0.01)
+            step()
+    step()
+    dec.check_saturation()                                   # recovered
+
+
 def test_batch_shape_changes_between_steps():
     """Real batches differ in size and length from step to step.  The pooled transposed operand buffers of the
     weight-gradient GEMMs are reused across steps: a step after a DIFFERENT shape (here one with the same padded

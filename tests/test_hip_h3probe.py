@@ -16,7 +16,7 @@ def _split(x, scale):
     ldh = (cols + 7) // 8 * 8
     hi = torch.empty(rows, ldh, dtype=torch.float16, device=DEV)
     lo = torch.empty(rows, ldh, dtype=torch.float16, device=DEV)
-    check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale, stream()), "split")
+    check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale, None, stream()), "split")
     return hi, lo
 
 
@@ -39,3 +39,44 @@ def test_h3gemm_accuracy(M, N, K, wscale):
     e_f32 = rel_err(C32.cpu().double(), ref)
     print(f"M={M} N={N} K={K}: split-f16 err {e_h3:.2e}, fp32 MFMA err {e_f32:.2e}")
     assert e_h3 < 5e-6
+
+
+def _decode_cross(cross, rows, K, role_b, x8_exp):
+    """8-bit cross array (stored in a half tensor [rows][ld]) -> (hi8, lo8) as fp32 [rows][K], undoing the exponents."""
+    by = cross.view(torch.uint8).reshape(rows, -1)[:, : 2 * K].reshape(rows, K // 32, 64)
+    first, second = by[..., :32], by[..., 32:]
+    hi8, lo8 = (second, first) if role_b else (first, second)
+    dec = lambda u: u.contiguous().view(torch.float8_e4m3fn).float().reshape(rows, K)
+    return dec(hi8) / 2.0 ** x8_exp, dec(lo8) / 2.0 ** (11 + x8_exp)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 1024), (1280, 1024, 1024), (12800, 1024, 1024)])
+def test_f8x_gemm_layout_and_accuracy(M, N, K):
+    """nprod = 2: C = Ah.Bh on the f16 cores + (Ah8.Bl8 + Al8.Bh8) as one block-scaled FP8 MFMA.  The
+    kernel's result must equal that sum formed on the host from the very arrays the producers wrote (decoded e4m3
+    bytes, fp64 accumulation): checks the cross-array layout, the lane/k-block/scale mapping of the instruction and the
+    exponents end to end.  Against the exact product the error is a few 1e-5 (the split-f16 x3 scheme: 2e-6)."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    g = torch.Generator().manual_seed(K + M)
+    A = torch.nn.functional.softplus(torch.randn(M, K, generator=g) * 2).to(DEV)
+    Bw = (torch.randn(N, K, 1, generator=g) * 0.03).to(DEV)
+    Ah, Ax = ops.split_f16(A, K, 1.0, K, nprod=2, x8_exp=ops.X8_ACT_EXP)
+    Bh, Bx, _ = ops.split_weight(Bw, None, K, nprod=2)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    rowgemm_h3(nprod=2, a8_exp=ops.X8_ACT_EXP, b8_exp=ops.X8_W_EXP, Ah=Ah, Al=Ax, lda_h=K, Bh=Bh, Bl=Bx, ldb_h=K,
+               acc_scale=1.0 / ops.W_SCALE, C=C, ldc=N, M=M, N=N, K=K, T=M)
+    a_hi8, a_lo8 = _decode_cross(Ax, M, K, False, ops.X8_ACT_EXP)
+    b_hi8, b_lo8 = _decode_cross(Bx[0], N, K, True, ops.X8_W_EXP)
+    # the 8-bit images are what they should be: hi8 ~ hi within e4m3's 2^-4, lo8 ~ the fp16 rounding residual
+    assert rel_err(a_hi8.cpu(), Ah.float().cpu()) < 0.07
+    resid = (A - Ah.float())
+    assert float((a_lo8 - resid).abs().max()) < 0.07 * float(resid.abs().max()) + 1e-9
+    d = torch.float64
+    model = (Ah.to(d) @ Bh[0].to(d).t() + a_hi8.to(d) @ b_lo8.to(d).t() + a_lo8.to(d) @ b_hi8.to(d).t()) / ops.W_SCALE
+    exact = A.to(d) @ Bw[:, :, 0].to(d).t()
+    e_model = rel_err(C.cpu().double(), model.cpu())
+    e_exact = rel_err(C.cpu().double(), exact.cpu())
+    print(f"M={M} N={N} K={K}: f8x vs its own operand model {e_model:.2e}, vs the exact product {e_exact:.2e}")
+    assert e_model < 3e-6
+    assert e_exact < 1e-4

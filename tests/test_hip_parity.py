@@ -375,7 +375,8 @@ def _build_decoder(g, precision="fp32"):
 @pytest.mark.parametrize("tag,precision", [("cfg1", "fp32"), ("cfg2_small", "fp32"), ("cfg5_small", "fp32"),
                                            ("cfg1", "h3"), ("cfg2_small", "h3"), ("cfg5_small", "h3"),
                                            ("cfg1", "h3-wide"), ("cfg2_small", "h3-wide"), ("cfg5_small", "h3-wide"),
-                                           ("cfg3_small", "fp32"), ("cfg3_small", "h3"), ("cfg3_small", "h3-wide")])
+                                           ("cfg3_small", "fp32"), ("cfg3_small", "h3"), ("cfg3_small", "h3-wide"),
+                                           ("cfg1", "f8x"), ("cfg2_small", "f8x"), ("cfg3_small", "f8x"), ("cfg5_small", "f8x")])
 def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     # "h3": also route the (small) FiLM convs through ConvNormH3Fn, which by default only takes frame-rate sizes.
     # Problems this small go to the 128 x 128 split-f16 kernel by default; "h3-wide" forces the one-workgroup-per-CU
@@ -383,7 +384,7 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     if precision == "h3-wide":
         precision = "h3"
         monkeypatch.setenv("RADMMM_H3_TILE", "256")
-    monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", "0" if precision == "h3" else "1000000000")
+    monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", "0" if precision in ("h3", "f8x") else "1000000000")
     monkeypatch.setenv("RADMMM_PRECISION", precision)
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
     cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture;
@@ -517,7 +518,8 @@ def test_decoder_full_size_item_independence(R):
     assert abs(nll_i - float(lo)) < 1e-4 * abs(float(lo))
 
 
-def test_decoder_full_size_backward_matches_oracle(R):
+@pytest.mark.parametrize("precision", ["h3", "f8x"])
+def test_decoder_full_size_backward_matches_oracle(R, precision, monkeypatch):
     """BASELINE config 2 at its full size (8 flows, B=32, T=800 ragged): forward, NLL and the WHOLE backward against the
     CPU oracle run on the same batch.  This is the only place the benchmark-shape launches are checked for gradient
     parity: the MB=7 wide tile at M=12 800, wgrad_h3 with Kt ~ 13 k and its split-K slab sums, and the gradient scale
@@ -532,9 +534,11 @@ def test_decoder_full_size_backward_matches_oracle(R):
               n_conv_layers_per_step=4, n_flows=8)
     cfg = O.DecoderConfig(**kw)
     sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    monkeypatch.setenv("RADMMM_PRECISION", precision)
     dec = RADMMMFlow(use_accent=True, **kw)
     dec.load_state_dict(sd)
     dec = dec.to(DEV).train()
+    assert dec.gemm_precision == precision
     b = T(O.synthetic_batch(32, 800, cfg, 4321, ragged=True))
     gb = {k: v.to(DEV) for k, v in b.items()}
     sl = SequenceLength(gb["lengths"])
@@ -572,5 +576,6 @@ def test_decoder_full_size_backward_matches_oracle(R):
         if abs(mine - gn) / (gn + 1e-6) > worst:
             worst, worst_n = abs(mine - gn) / (gn + 1e-6), n
         worst_el = max(worst_el, el)
-    print(f"full size: z rel {rel_err(zh * m, zo * m):.2e}, loss rel {abs(float(lm) - float(lo)) / abs(float(lo)):.2e}, "
+    dec.check_saturation()
+    print(f"full size [{precision}]: z rel {rel_err(zh * m, zo * m):.2e}, loss rel {abs(float(lm) - float(lo)) / abs(float(lo)):.2e}, "
           f"worst grad-norm rel {worst:.2e} ({worst_n}), worst elementwise grad rel {worst_el:.2e}")

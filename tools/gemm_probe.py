@@ -20,7 +20,9 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--nprod", type=int, default=3, help="3 split-f16, 2 f16 + FP8 cross terms, 1 single product")
     args = ap.parse_args()
+    NPR = args.nprod
     import rad_mmm_amd  # noqa: F401
     from rad_mmm_amd import ops
     from rad_mmm_amd._lib import rowgemm_h3
@@ -34,9 +36,9 @@ def main():
     v1 = (torch.randn(1024, 1024, 1, generator=g) * 0.03).to(dev)
     gg = torch.ones(1024, 1, 1, device=dev)
     bias = torch.zeros(1024, device=dev)
-    xh, xl = ops.split_f16(x, 1024, 1.0)
-    W5h, W5l, _ = ops.split_weight(v5, gg, 1024)
-    W1h, W1l, _ = ops.split_weight(v1, gg, 1024)
+    xh, xl = ops.split_f16(x, 1024, 1.0, 1024, NPR, ops.X8_ACT_EXP)
+    W5h, W5l, _ = ops.split_weight(v5, gg, 1024, nprod=NPR)
+    W1h, W1l, _ = ops.split_weight(v1, gg, 1024, nprod=NPR)
     y = torch.empty(N, 1024, device=dev)
     y2 = torch.zeros(N, 1024, device=dev)
     add = torch.randn(N, 1024, device=dev)
@@ -46,7 +48,8 @@ def main():
 
     def conv(taps, **kw):
         Wh, Wl = (W5h, W5l) if taps > 1 else (W1h, W1l)
-        base = dict(Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0), acc_scale=inv,
+        base = dict(nprod=NPR, a8_exp=ops.X8_ACT_EXP, b8_exp=ops.X8_W_EXP, split_fmt=ops.fmt_a(NPR), ch_x8_exp=ops.X8_ACT_EXP,
+                    Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0), acc_scale=inv,
                     C=y, ldc=1024, M=N, N=1024, K=1024, taps=taps, dil=2, sign=1, T=T, lens=lens)
         base.update(kw)
         return lambda: rowgemm_h3(**base)
@@ -81,7 +84,9 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         flop = 2.0 * N * 1024 * 1024 * taps
-        print(json.dumps({"case": name, "us": round(us, 1), "fp32_equiv_tflops": round(flop / us / 1e6, 1)}), flush=True)
+        print(json.dumps({"nprod": NPR, "case": name, "us": round(us, 1), "fp32_equiv_tflops": round(flop / us / 1e6, 1)}), flush=True)
+    if NPR != 3:
+        return
     # weight gradient incl. / excl. producers
     gy_t = ops.transpose_split_act(gy, 1024, B, T, None, 0, 1.0, "gy")
     x_t = ops.transpose_split_act(x, 1024, B, T, lens, 1, 1.0, "x")
@@ -102,6 +107,7 @@ def main():
     for name, fn in (("transpose_split_act gy + colsum", lambda: ops.transpose_split_act(gy, 1024, B, T, None, 0, 1.0, "gy", colsum=(0, None, 1, 1))),
                      ("transpose_split_act x (masked)", lambda: ops.transpose_split_act(x, 1024, B, T, lens, 1, 1.0, "x")),
                      ("weight split+norm in_layer (5 taps)", lambda: ops.split_weight(v5, gg, 1024)),
+                     ("weight split+norm in_layer, 8-bit cross", lambda: ops.split_weight(v5, gg, 1024, nprod=2)),
                      ("transpose_split W in_layer", lambda: ops.transpose_split(W5h, W5l, 1024, 1024, 1024))):
         for _ in range(3):
             fn()
