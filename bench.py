@@ -99,25 +99,26 @@ def time_dominant_kernel(N, T, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * N * 1024 * 5 * 1024
 
 
-def time_dominant_kernel_h3(N, T, reps=20):
-    """Same launch as time_dominant_kernel on the split-f16 path (the default precision):
+def time_dominant_kernel_h3(N, T, reps=20, nprod=3):
+    """Same launch as time_dominant_kernel on the split-operand path (nprod 3: split-f16, 2: f16 + FP8 cross terms):
     rowgemm_h3 as the WN in_layer forward conv, split activations in, fp32 + split copies out."""
     from rad_mmm_amd._lib import rowgemm_h3
     from rad_mmm_amd import ops
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(N, 1024, generator=g).to(dev)
+    x = torch.nn.functional.softplus(torch.randn(N, 1024, generator=g)).to(dev)
     v = (torch.randn(1024, 1024, 5, generator=g) * 0.02).to(dev)
     gg = torch.ones(1024, 1, 1, device=dev)
     b = torch.zeros(1024, device=dev)
-    xh, xl = ops.split_f16(x, 1024, 1.0)
-    Wh, Wl, _ = ops.split_weight(v, gg, 1024)
+    xh, xl = ops.split_f16(x, 1024, 1.0, 1024, nprod, ops.X8_ACT_EXP)
+    Wh, Wl, _ = ops.split_weight(v, gg, 1024, nprod=nprod)
     y = torch.empty(N, 1024, device=dev)
     yh, yl = torch.empty_like(xh), torch.empty_like(xl)
     lens = torch.full((N // T,), T, dtype=torch.int32, device=dev)
 
     def launch():
-        rowgemm_h3(Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0),
+        rowgemm_h3(nprod=nprod, a8_exp=ops.X8_ACT_EXP, b8_exp=ops.X8_W_EXP, split_fmt=ops.fmt_a(nprod), ch_x8_exp=ops.X8_ACT_EXP,
+                   Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0),
                    acc_scale=1.0 / ops.W_SCALE, C=y, ldc=1024, M=N, N=1024, K=1024, taps=5, dil=2, sign=1, T=T, lens=lens,
                    a_mask_mode=1, bias=b, pconv=1, ratio_taps=5, ratio_dil=2, postmask=1, act=1, Ch=yh, Cl=yl, ldch=1024,
                    ch_scale=1.0)
@@ -303,6 +304,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("RADMMM_FORCE_DIST") == "1"   # the latter: RCCL smoke test on 1 GPU
+    if world > 1:
+        from rad_mmm_amd.ddp import reserve_collective_cus    # before the library's first launch and before RCCL starts
+        reserve_collective_cus()
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -375,16 +379,20 @@ def main():
 
     if rank == 0:
         N = B * (T // cfg.n_group_size)
-        h3 = dec.gemm_precision == "h3"
+        h3 = dec.gemm_precision in ("h3", "f8x")
+        f8x = dec.gemm_precision == "f8x"
         if h3:
             # split-f16 path: every fp32 product is three f16 MFMA products (Ah*Bh + Ah*Bl + Al*Bh) on the f16 matrix
             # cores.  `achieved` counts the ALGORITHMIC flops of the launch (2*M*N*K*taps) against the dense
             # f16 MFMA peak the kernel runs on; `executed_*` counts the 3x MFMA flops really issued (pipe utilisation).
-            kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size)
-            nprod, peak = 3.0, PEAK_F16_MFMA_TFLOPS
-            kname = ("rowgemm_h3d_kernel<MB> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA products "
-                     "per fp32 product)") % N
-            prec = "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)"
+            kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size, nprod=2 if f8x else 3)
+            # executed MFMA work in f16-equivalent products: 3 f16 products, or 1 f16 + 2 FP8 products at twice the rate
+            nprod, peak = (2.0 if f8x else 3.0), PEAK_F16_MFMA_TFLOPS
+            kname = ("rowgemm_h3d_kernel<MB,%d> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, %s)"
+                     % (2 if f8x else 3, N, "hi.hi f16 MFMA + both cross terms in one block-scaled FP8 MFMA per 32-deep k step"
+                        if f8x else "3 f16 MFMA products per fp32 product"))
+            prec = ("f16 hi.hi product + FP8 (e4m3) cross terms, fp32 accumulate (z max rel err 4e-5, NLL < 4e-6 vs the CPU reference)"
+                    if f8x else "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)")
         else:
             kdur, kflop = time_dominant_kernel(N, T // cfg.n_group_size)
             nprod, peak = 1.0, PEAK_FP32_MFMA_TFLOPS
@@ -439,27 +447,39 @@ def main():
                          "achieved": by * B * T / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": by * B * T / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        def side_leg(mode, steps=5):
+            """time `steps` steps with the decoder switched to another product scheme (same weights, same batch)"""
+            prev = dec.gemm_precision
+            dec.gemm_precision = mode
+            os.environ["RADMMM_PRECISION"] = mode
+            for _ in range(2):
+                lv = step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                lv = step()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / steps
+            dec.gemm_precision = prev
+            os.environ["RADMMM_PRECISION"] = prev
+            return dts, float(lv.detach())
+
+        if world == 1 and f8x and not args.no_throughput_mode:
+            # the three-f16-product scheme (2e-6 instead of 4e-5 on z): same kernels, 3/2 of the MFMA work
+            dt3, l3 = side_leg("h3")
+            res["exact_split_mode"] = {"dtype": "split-f16 x3 MFMA products (RADMMM_PRECISION=h3), fp32 accumulate", "steps": 5,
+                                       "ms_per_step": dt3 * 1e3, "value": B * T / dt3, "unit": "mel-frames/s", "loss_mel": l3,
+                                       "loss_rel_diff_vs_default_mode": abs(l3 - loss_val) / abs(loss_val),
+                                       "within_parity_bar": True}
         if world == 1 and h3 and not args.no_throughput_mode:
             # BASELINE's config label for this workload says "bf16": the same kernels with ONE fp16 MFMA product per
             # fp32 product (operands rounded to fp16, fp32 accumulate).  Reported beside, never as, `value`: this mode is
             # outside north_star's 1e-4 parity bar (DESIGN.md §4.4).
-            dec.gemm_precision = "f16"
-            os.environ["RADMMM_PRECISION"] = "f16"
-            for _ in range(2):
-                l16 = step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                l16 = step()
-            torch.cuda.synchronize()
-            dt16 = (time.perf_counter() - t1) / 5
-            l16 = float(l16.detach())
+            dt16, l16 = side_leg("f16")
             res["throughput_mode"] = {"dtype": "f16 operands (single MFMA product), fp32 accumulate", "steps": 5,
                                       "ms_per_step": dt16 * 1e3, "value": B * T / dt16, "unit": "mel-frames/s",
                                       "loss_mel": l16, "loss_rel_diff_vs_parity_mode": abs(l16 - loss_val) / abs(loss_val),
                                       "within_parity_bar": False}
-            dec.gemm_precision = "h3"
-            os.environ["RADMMM_PRECISION"] = "h3"
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd)
     if use_dist:

@@ -81,6 +81,10 @@ __device__ __forceinline__ float epilogue_row_fast(const radmmm_rowgemm_desc& p,
 }
 
 // side inputs of one output row (4 columns) of the fused epilogue, requested ahead of their use
+struct Side {
+  float4 a, d, c;      // add, dact_src, C2
+};
+
 __device__ __forceinline__ void fetch_side(const radmmm_rowgemm_desc& p, bool live, int row, int col, float4& a, float4& d,
                                            float4& c) {
   a = d = c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,8 +100,7 @@ __device__ __forceinline__ void fetch_side(const radmmm_rowgemm_desc& p, bool li
 // on coalesced float4 rows.  A thread owns rows rl = 4 k + (tid >> 6), k = 0..7, of the block and handles them in four
 // pairs; the side inputs (add, dact_src, C2) of the first pair are requested before the park and those of pair n + 1
 // before pair n is processed, so that no global-load latency sits between the LDS read-out and the stores (one
-// workgroup per CU: nothing else would hide it).  Plain arrays with compile-time indices only: anything whose address
-// escapes into a closure ends up in scratch.
+// workgroup per CU: nothing else would hide it).
 template <int MB, int I, bool FAST>
 __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], float* smf, const float2* rowf,
                                                 const radmmm_rowgemm_desc& p, const radmmm::EpilogueCtx& ec, float sc,
@@ -107,23 +110,14 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
     const int c4 = (tid & 63) * 4;
     const int rbase = m0 + I * 32 + (tid >> 6);
     const bool live = FAST && (m0 + I * 32 < p.M) && (n0 + c4 < p.N);
-    // two register sets (A, B) of side inputs, one pair of rows each; named scalars, no arrays
-    float4 aA0, dA0, cA0, aA1, dA1, cA1, aB0, dB0, cB0, aB1, dB1, cB1;
-    aA0 = dA0 = cA0 = aA1 = dA1 = cA1 = aB0 = dB0 = cB0 = aB1 = dB1 = cB1 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define RADMMM_EPI_FETCH(S, PAIR)                                                          \
-  fetch_side(p, live, rbase + (2 * (PAIR)) * 4, n0 + c4, a##S##0, d##S##0, c##S##0);       \
-  fetch_side(p, live, rbase + (2 * (PAIR) + 1) * 4, n0 + c4, a##S##1, d##S##1, c##S##1);
-#define RADMMM_EPI_ROW(S, K, PAIR)                                                         \
-  {                                                                                        \
-    const int rl = (2 * (PAIR) + (K)) * 4 + (tid >> 6);                                    \
-    const int row = m0 + I * 32 + rl;                                                      \
-    if (row < p.M) {                                                                       \
-      const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);              \
-      const float2 rf = rowf[I * 32 + rl];                                                 \
-      sat = fmaxf(sat, epilogue_row_fast(p, row, n0 + c4, a4, rf.x, rf.y, kc, a##S##K, d##S##K, c##S##K)); \
-    }                                                                                      \
-  }
-    if constexpr (FAST) { RADMMM_EPI_FETCH(A, 0) }
+    // side inputs of the pair being processed (c*) and of the next pair (n*); plain structs, no arrays.  The row loop
+    // stays ROLLED (one pair per trip): seven blocks x eight fully unrolled rows of this epilogue are ~130 KB of code,
+    // twice the instruction cache, and cost ~50 us per launch in instruction fetch (measured: 1-tap launch 107 -> 162 us)
+    Side c0, c1, n0s, n1s;
+    if constexpr (FAST) {
+      fetch_side(p, live, rbase, n0 + c4, c0.a, c0.d, c0.c);
+      fetch_side(p, live, rbase + 4, n0 + c4, c1.a, c1.d, c1.c);
+    }
     if (I > 0) radmmm::lds_barrier();      // the previous block has been read out (its global stores stay in flight)
     float* wbase = smf + (4 * (lane >> 5)) * BN + wave * 64 + (lane & 31);
 #pragma unroll
@@ -134,16 +128,26 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
     if (m0 + I * 32 < p.M) {
       if constexpr (FAST) {
         if (n0 + c4 < p.N) {
-          RADMMM_EPI_FETCH(B, 1)
-          RADMMM_EPI_ROW(A, 0, 0) RADMMM_EPI_ROW(A, 1, 0)
-          RADMMM_EPI_FETCH(A, 2)
-          RADMMM_EPI_ROW(B, 0, 1) RADMMM_EPI_ROW(B, 1, 1)
-          RADMMM_EPI_FETCH(B, 3)
-          RADMMM_EPI_ROW(A, 0, 2) RADMMM_EPI_ROW(A, 1, 2)
-          RADMMM_EPI_ROW(B, 0, 3) RADMMM_EPI_ROW(B, 1, 3)
+#pragma unroll 1
+          for (int pr = 0; pr < 4; ++pr) {
+            const int rl0 = (2 * pr) * 4 + (tid >> 6), rl1 = rl0 + 4;
+            // next pair's side inputs (the last trip fetches nothing: its rows lie beyond the block -> `live` off)
+            fetch_side(p, live && pr < 3, rbase + (2 * pr + 2) * 4, n0 + c4, n0s.a, n0s.d, n0s.c);
+            fetch_side(p, live && pr < 3, rbase + (2 * pr + 3) * 4, n0 + c4, n1s.a, n1s.d, n1s.c);
+            if (m0 + I * 32 + rl0 < p.M) {
+              const float4 a4 = *reinterpret_cast<const float4*>(smf + rl0 * BN + c4);
+              const float2 rf = rowf[I * 32 + rl0];
+              sat = fmaxf(sat, epilogue_row_fast(p, m0 + I * 32 + rl0, n0 + c4, a4, rf.x, rf.y, kc, c0.a, c0.d, c0.c));
+            }
+            if (m0 + I * 32 + rl1 < p.M) {
+              const float4 a4 = *reinterpret_cast<const float4*>(smf + rl1 * BN + c4);
+              const float2 rf = rowf[I * 32 + rl1];
+              sat = fmaxf(sat, epilogue_row_fast(p, m0 + I * 32 + rl1, n0 + c4, a4, rf.x, rf.y, kc, c1.a, c1.d, c1.c));
+            }
+            c0 = n0s;
+            c1 = n1s;
+          }
         }
-#undef RADMMM_EPI_FETCH
-#undef RADMMM_EPI_ROW
       } else {
 #pragma unroll 1
         for (int k = 0; k < 8; ++k) {

@@ -20,6 +20,25 @@ import torch
 import torch.distributed as dist
 
 
+RCCL_CUS = 8     # CUs left to RCCL's channel kernels in data-parallel runs (see reserve_collective_cus)
+
+
+def reserve_collective_cus(n: int = RCCL_CUS, total_cus: int = 256) -> None:
+    """Call BEFORE dist.init_process_group and before the first GEMM launch of a multi-GPU process.
+
+    The GEMM kernels of this package run ONE workgroup per CU and size their grids to fill whole rounds of the CUs (232 of
+    256 for the dominant launch, weight-gradient split-K factors chosen to fill all 256): an all-reduce whose channel
+    kernels land during such a launch would push part of the grid into a second round -- up to 2x on that launch.  So the
+    collective gets its own CUs: RCCL is pinned to `n` channels (one workgroup = one CU each; a 106 MB bucket hidden under
+    ~5 ms of one flow step's backward needs ~25 GB/s, far below what 8 channels move over xGMI), and the GEMM grids are
+    sized for `total_cus - n` workgroup slots (RADMMM_GEMM_CUS, read once by libradmmm_hip.so).  Explicit settings of
+    either variable in the environment win."""
+    import os
+    os.environ.setdefault("NCCL_MIN_NCHANNELS", str(n))
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    os.environ.setdefault("RADMMM_GEMM_CUS", str(total_cus - n))
+
+
 def default_bucket_key(name: str) -> str:
     """flows.3.coupling_tfn... -> 'flows.3', also below a parent module (decoder.flows.3... -> 'decoder.flows.3':
     the reducer wrapped around the whole training step); everything else (LSTM, embeddings, text encoder,
@@ -71,12 +90,20 @@ class BucketedGradReducer:
                 self._views[id(p)] = view
                 self._direct[id(p)] = d_
                 off += p.numel()
-            b = dict(key=key, params=params, flat=flat, pending=len(params), handle=None, n_direct=n_direct)
+            b = dict(key=key, params=params, flat=flat, pending=len(params), handle=None, n_direct=n_direct, ready=False)
             self.buckets.append(b)
             for p in params:
                 self._by_param[id(p)] = b
                 p.register_post_accumulate_grad_hook(self._make_hook(b))
         self.total_bytes = sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+        # Collectives are issued in ONE fixed, rank-independent order: the reverse of the registration order, which is the
+        # order backward completes the buckets in (last flow first, the context LSTM / everything upstream last).  A
+        # bucket that becomes ready early waits for its predecessors; one that never completes on some rank (a parameter
+        # without gradient there) is issued from finish(), still in sequence -- ranks can never disagree on which
+        # all-reduce comes next (torch DDP guards the same hazard with find_unused_parameters).
+        self._order = list(reversed(range(len(self.buckets))))
+        self._next = 0
+        self._sink_keys: List[int] = []
 
     def _make_hook(self, bucket):
         def hook(param):
@@ -90,34 +117,52 @@ class BucketedGradReducer:
                                    "gradients that are already being all-reduced; accumulate locally without a process "
                                    "group or call prepare()/finish() around every backward")
             if bucket["pending"] == 0 and self.active:
-                # RCCL stream waits for the kernels already queued on the compute stream, then
-                # runs concurrently with the rest of backward
-                bucket["handle"] = dist.all_reduce(bucket["flat"], op=dist.ReduceOp.SUM, group=self.pg,
-                                                   async_op=True)
+                bucket["ready"] = True
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self, force: bool = False) -> None:
+        """issue the all-reduces of the leading ready buckets of the fixed order (all remaining ones with force)"""
+        while self._next < len(self._order):
+            b = self.buckets[self._order[self._next]]
+            if not (b["ready"] or force):
+                return
+            # RCCL's stream waits for the kernels already queued on the compute stream, then runs concurrently with the
+            # rest of backward
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._next += 1
 
     def prepare(self) -> None:
         """Re-arm the hooks (call before backward): accumulate-style parameters get a zeroed .grad view,
         direct ones .grad = None plus a registered sink (their node overwrites the bucket slice)."""
         from . import ops
-        ops.GRAD_SINKS.clear()
+        self._drop_sinks()
+        self._next = 0
         for b in self.buckets:
             if b["n_direct"] < b["flat"].numel():
                 b["flat"][b["n_direct"]:].zero_()
             b["pending"] = len(b["params"])
             b["handle"] = None
+            b["ready"] = False
             for p in b["params"]:
                 view = self._views[id(p)]
                 if self._direct[id(p)]:
                     p.grad = None
                     ops.GRAD_SINKS[p.data_ptr()] = view
+                    self._sink_keys.append(p.data_ptr())
                 elif p.grad is None or p.grad.data_ptr() != view.data_ptr():
                     p.grad = view
 
+    def _drop_sinks(self) -> None:
+        """remove THIS reducer's sinks only (another reducer in the process keeps its direct writes)"""
+        from . import ops
+        for k in self._sink_keys:
+            ops.GRAD_SINKS.pop(k, None)
+        self._sink_keys = []
+
     def finish(self) -> None:
         """Wait for the outstanding reductions and turn sums into means (call after backward)."""
-        from . import ops
-        ops.GRAD_SINKS.clear()
+        self._drop_sinks()
         for b in self.buckets:                # direct parameters that received no gradient this step
             for p in b["params"]:
                 if p.grad is None:
@@ -126,9 +171,7 @@ class BucketedGradReducer:
                     p.grad = view
         if not self.active:
             return
-        for b in self.buckets:
-            if b["handle"] is None:           # a parameter without gradient this step
-                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._launch_ready(force=True)        # buckets with a parameter without gradient this step, in sequence
         inv = 1.0 / self.world
         for b in self.buckets:
             b["handle"].wait()

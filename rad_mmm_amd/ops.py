@@ -434,8 +434,11 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     # split-f16 path for the frame-rate convs (FiLM stacks: N = B*T' rows); text-rate convs (encoder,
     # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
     min_rows = int(os.environ.get("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
-    prec = os.environ.get("RADMMM_PRECISION", "h3")
-    meta["nprod"] = NPROD.get(prec, 3)
+    prec = os.environ.get("RADMMM_PRECISION", "f8x")
+    # "f8x" (FP8 cross terms) is for the WN stack of the affine flows; the FiLM convs of the spline flows keep the three
+    # f16 products: the piecewise-quadratic transform's log-Jacobian amplifies errors of its 65 parameters per element
+    # (measured: flow-0 log_s off by > 1e-4 with f8x FiLM convs, tests/test_hip_parity.py cfg5_small)
+    meta["nprod"] = 3 if prec == "f8x" else NPROD.get(prec, 3)
     if (prec in NPROD and Cin % 32 == 0 and (taps // 2) * dil <= 16
             and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
         return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
@@ -578,7 +581,8 @@ def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False
     # one set of flat buffers per (role, C): batches of a real run differ in B and T, so the [C, ldk] views are cut
     # from storage sized for the largest shape seen, and whenever the shape changes the used region is cleared
     # (the kernel rewrites data and gaps only; front, tail and the round-up columns must read as zeros)
-    key = (x.device, C, role, need_odd)
+    # (one pool per stream: buffers are reused in launch order, which only a single stream guarantees)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, C, role, need_odd)
     ent = _ts_pool.get(key)
     need = C * ldk
     if ent is None or ent["cap"] < need:

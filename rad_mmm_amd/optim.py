@@ -115,10 +115,21 @@ class FlatRAdam:
                                         ptr(self._clip), beta1, beta2, self.eps, step_size, self.weight_decay * self.lr,
                                         1 if n_sma >= 5 else 0, stream()), "radam_step")
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad semantics for the standard loop `opt.zero_grad(); loss.backward(); opt.step()`:
+        without a reducer the parameters' own .grad tensors are what autograd accumulates into, so they are reset here
+        (the flat copies are refilled from them by step()); with a reducer the buckets ARE the gradients and
+        reducer.prepare() re-arms them."""
         for b in self.buckets:
-            if b["gflat"] is not None:
+            if b["gflat"] is not None and b["own_g"]:
                 b["gflat"].zero_()
+            if b["own_g"]:
+                for p in b["params"]:
+                    if p.grad is not None:
+                        if set_to_none:
+                            p.grad = None
+                        else:
+                            p.grad.zero_()
 
     # -- reference-compatible state ---------------------------------------------------------------
     def state_dict(self):

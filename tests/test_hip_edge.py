@@ -322,6 +322,9 @@ def test_batch_shape_changes_between_steps():
         b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(B, Tn, cfg, seed=seed, ragged=(B != 3)).items()}
         sl = SequenceLength(b["lengths"])
         dec.zero_grad(set_to_none=True)
+        # the power-of-two gradient scale is carried from pass to pass (ops.GradScale): start every run from the same
+        # state so that "bit for bit" compares the pooled buffers and nothing else
+        dec._grad_scale = None
         out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
         crit(out, None, sl, 0)["loss_mel"][0].backward()
         return {n: p.grad.detach().clone() for n, p in dec.named_parameters()}
@@ -433,8 +436,12 @@ def test_context_options_of_the_constructor(opt):
         assert rel_err(params[n].grad.cpu(), p[n].grad) < 1e-3, n
 
 
-def test_relu_activation_in_the_wn():
-    """affine_activation='relu' (common.py:776-835 takes either): fused epilogue / activation-gradient kernels vs the oracle"""
+def test_relu_activation_in_the_wn(monkeypatch):
+    """affine_activation='relu' (common.py:776-835 takes either): fused epilogue / activation-gradient kernels vs the oracle.
+    Run on the exact split-f16 products: relu' is discontinuous, every activation within rounding of 0 flips a whole
+    gradient term, and the default FP8-cross scheme's 2e-5 rounding flips ten times more of them than the 2e-3 bar below
+    allows for (no shipped config uses relu; the product scheme is not what this test is about)."""
+    monkeypatch.setenv("RADMMM_PRECISION", "h3")
     kw = dict(BASE, n_flows=2, n_text_dim=64, affine_activation="relu")
     lens = [64, 50]
     r = _run_both(kw, 2, 64, lens)

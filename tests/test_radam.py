@@ -143,3 +143,37 @@ def test_checkpoint_resume_continues_bit_exactly():
     step(dec2, red2, opt2, batches[2])
     for n, p in dec2.named_parameters():
         assert torch.equal(p.detach(), want[n]), n
+
+
+@pytest.mark.gpu
+def test_standard_loop_with_zero_grad_does_not_accumulate():
+    """`opt.zero_grad(); loss.backward(); opt.step()` with NO reducer: autograd accumulates into p.grad, so zero_grad()
+    has to reset those tensors -- two iterations must use each iteration's own gradient, not the running sum
+    (checked against a second optimizer fed the per-iteration gradients by assignment)."""
+    from rad_mmm_amd.optim import FlatRAdam
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    w0 = [torch.randn(7, 5), torch.randn(11)]
+    x = [torch.randn(3, 5, device=dev), torch.randn(3, 5, device=dev)]
+
+    def make():
+        ps = [("flows.0.a", torch.nn.Parameter(w0[0].clone().to(dev))), ("misc.b", torch.nn.Parameter(w0[1].clone().to(dev)))]
+        return ps, FlatRAdam(ps, lr=1e-2)
+
+    def loss_of(ps, xi):
+        return ((xi @ ps[0][1].t()) ** 2).sum() + (ps[1][1] ** 3).sum()
+
+    ps_a, opt_a = make()
+    ps_b, opt_b = make()
+    for it in range(3):
+        opt_a.zero_grad()                                    # the loop under test
+        loss_of(ps_a, x[it % 2]).backward()
+        opt_a.step()
+        gs = torch.autograd.grad(loss_of(ps_b, x[it % 2]), [p for _, p in ps_b])   # reference: fresh gradients by assignment
+        for (_, p), g in zip(ps_b, gs):
+            p.grad = g
+        opt_b.step()
+        for (_, pa), (_, pb) in zip(ps_a, ps_b):
+            assert torch.equal(pa.detach(), pb.detach()), it
+    opt_a.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for _, p in ps_a)
