@@ -259,8 +259,9 @@ def main():
         import rad_mmm_amd  # noqa: F401
         torch.cuda.set_device(0)
         N, Tg = args.batch * (args.frames // 2), args.frames // 2
-        hdur, hflop = time_dominant_kernel_h3(N, Tg)
-        print(json.dumps({"kernel": "rowgemm_h3 in_layer fwd", "M": N, "avg_launch_ms": hdur * 1e3,
+        npr = {"h3": 3, "f8x": 2}.get(os.environ.get("RADMMM_PRECISION", "f8x"), 2)      # the default product scheme
+        hdur, hflop = time_dominant_kernel_h3(N, Tg, nprod=npr)
+        print(json.dumps({"kernel": "rowgemm_h3 in_layer fwd", "nprod": npr, "M": N, "avg_launch_ms": hdur * 1e3,
                           "fp32_equiv_tflops": hflop / hdur / 1e12}))
         return
     if args.kernel_only:

@@ -13,28 +13,49 @@ using radmmm::block_sum;
 
 // W{h,l}[tap][co][col(ci)] = split(scale * g[co] * v[co][ci][tap] / ||v[co]||); columns not hit by
 // col() must have been zeroed by the caller.  g == NULL: plain conv weights (no normalisation).
+// One workgroup per output channel: the checkpoint row v[co][ci][tap] (tap fastest) is read once, coalesced, into LDS;
+// each tap plane is then written as whole 4-column groups (8-byte fp16 stores, 4-byte stores of the 8-bit parts) with
+// consecutive lanes on consecutive columns.  (The first version wrote element by element in [ci][tap] order: adjacent
+// lanes hit different tap planes, 2-byte scattered stores -- 1.7 ms per step for 849 MB of weights.)
 __global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
     const float* __restrict__ v, const float* __restrict__ g, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
     float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi,
-    float scale, int fmt, float x8_mul) {
+    float scale, int fmt, float x8_mul, int vec_ok) {
+  extern __shared__ float row[];        // [Cin * taps]
   __shared__ float sh[17];
   const int co = blockIdx.x;
   const int n = Cin * taps;
   const float* vr = v + (long long)co * n;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = vr[i];
+    row[i] = x;
+    ss = fmaf(x, x, ss);
+  }
   float wn = 1.f;                      // g / ||v||  (1 for plain weights)
   if (g) {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(vr[i], vr[i], ss);
     ss = block_sum(ss, sh);
     const float nrm = sqrtf(ss);
     if (threadIdx.x == 0) inv_norm[co] = 1.f / nrm;
     wn = g[co] / nrm;
+  } else {
+    __syncthreads();
   }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int ci = i / taps, k = i - ci * taps;
-    const int col = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi;
-    // same rounding as the fp32 path (w = v * (g / ||v||)), then the exact power-of-two scale
-    radmmm::store_split1_fmt(Wh, Wl, ((long long)k * Cout + co) * ldk, col, fmt, x8_mul, scale, vr[i] * wn);
+  // same rounding as the fp32 path (w = v * (g / ||v||)), then the exact power-of-two scale
+  for (int k = 0; k < taps; ++k) {
+    const long long base = ((long long)k * Cout + co) * ldk;
+    if (vec_ok) {
+      for (int ci = threadIdx.x * 4; ci < Cin; ci += blockDim.x * 4) {
+        const int col = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi;
+        radmmm::store_split4_fmt(Wh, Wl, base, col, fmt, x8_mul, scale, row[ci * taps + k] * wn, row[(ci + 1) * taps + k] * wn,
+                                 row[(ci + 2) * taps + k] * wn, row[(ci + 3) * taps + k] * wn);
+      }
+    } else {
+      for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+        const int col = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi;
+        radmmm::store_split1_fmt(Wh, Wl, base, col, fmt, x8_mul, scale, row[ci * taps + k] * wn);
+      }
+    }
   }
 }
 
@@ -121,9 +142,14 @@ extern "C" int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh
   RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldk >= Cin && ldk % 8 == 0, "weightnorm_fwd_h3: bad dims");
   const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
   RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || (ldk % 32 == 0 && abs(so->x8_exp) <= 16), "weightnorm_fwd_h3: 8-bit format needs ldk %% 32 == 0");
-  hipLaunchKernelGGL(weightnorm_fwd_h3_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), v, g,
+  const size_t smem = (size_t)Cin * taps * sizeof(float);
+  RADMMM_REQUIRE(smem <= 60 * 1024, "weightnorm_fwd_h3: Cin*taps=%d too large for the row buffer", Cin * taps);
+  // 4-column groups need every piece of the column permutation and the row pitch to keep 4-element alignment
+  const int vec_ok = (Cin % 4 == 0 && perm_split % 4 == 0 && off_lo % 4 == 0 && off_hi % 4 == 0 && ldk % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(Wh) & 7) == 0 && (reinterpret_cast<uintptr_t>(Wl) & 7) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(weightnorm_fwd_h3_kernel, dim3(Cout), dim3(256), smem, static_cast<hipStream_t>(stream), v, g,
                      static_cast<_Float16*>(Wh), static_cast<_Float16*>(Wl), inv_norm, Cout, Cin, taps, ldk, perm_split,
-                     off_lo, off_hi, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0));
+                     off_lo, off_hi, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0), vec_ok);
   return radmmm::check_launch("weightnorm_fwd_h3");
 }
 

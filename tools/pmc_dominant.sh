@@ -5,8 +5,9 @@
 # counts 16-B/lane loads (global_load and buffer_load..lds alike) at half their bytes -> doubled; both are in KiB.
 # usage: tools/pmc_dominant.sh <outdir> <tag>
 set -u
-OUT="$1"; TAG="${2:-r02}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$1"; TAG="${2:-r02}"
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT" ;; esac        # rocprofv3 runs from /tmp: keep the output path absolute
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
