@@ -194,6 +194,19 @@ int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int 
                         float* gz, int ldz, int rows, int D, int h, radmmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Squeeze = nn.Unfold(kernel=(g,1), stride=g) of the reference (decoders.py:118-122,178; models/radmmm.py:114-120)
+ * straight from the reference layout into channels-last rows of a wider matrix:
+ *   out[(b*T' + t') * ld + col0 + c*g + k] = in[(b*C + c)*T + t'*g + k],  T' = T / g (frames beyond g*T' are dropped)
+ * so the flow variable and the context LSTM's input are assembled without a permuted copy or a concatenation.
+ * radmmm_unsqueeze_rows is its gradient: gin[b, c, t] = gout[row(t / g)][col0 + c*g + t % g] for t < g*T', else 0.
+ * g must divide 64.
+ * ------------------------------------------------------------------------------------ */
+int radmmm_squeeze_rows(const float* in /* [B, C, T] */, float* out, int B, int C, int T, int g, int ld, int col0,
+                        radmmm_stream_t stream);
+int radmmm_unsqueeze_rows(const float* gout, float* gin /* [B, C, T] */, int B, int C, int T, int g, int ld, int col0,
+                          radmmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Affine coupling (AffineTransformationLayer.forward, common.py:1163-1185):
  *   su = O[r, 0:h], b = O[r, h:2h]; (s, log_s) = scaling(su)
  *   zout[r, 0:h] = z[r, 0:h]; zout[r, h:2h] = s * z[r, h:2h] + b; zout[r, 2h:ldz] = z[...]

@@ -112,6 +112,8 @@ def _load() -> C.CDLL:
         "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p],
         "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p, p, so, p],
         "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
+        "radmmm_squeeze_rows": [p, p, i, i, i, i, i, i, p],
+        "radmmm_unsqueeze_rows": [p, p, i, i, i, i, i, i, p],
         "radmmm_affine_coupling_fwd": [p, i, p, i, p, p, i, i, i, p],
         "radmmm_affine_coupling_bwd": [p, i, p, i, p, p, p, p, i, i, i, p],
         "radmmm_dact_mul": [p, i, p, i, p, i, i, i, i, i, i, p, i, i, p, p, i, f, so, p],

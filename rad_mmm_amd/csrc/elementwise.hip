@@ -69,23 +69,42 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(
 // output channel is staged in LDS in checkpoint order ([ci][tap]), reading dW plane by plane with ci
 // fastest (the kernel above walks [ci][tap] directly and touches `taps` planes per 64-byte sector,
 // twice).  Needs Cin * taps * 4 bytes of LDS.
+template <bool VEC>
 __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
     const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
     const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
     float* __restrict__ dg, int Cout, int Cin, int taps, int ldw, int perm_split, int off_lo,
     int off_hi) {
-  extern __shared__ float gw[];          // [Cin * taps]
+  extern __shared__ __attribute__((aligned(16))) float gw[];          // [Cin * taps]
   __shared__ float sh[17];
   const int co = blockIdx.x;
   const int n = Cin * taps;
   const float* vr = v + (long long)co * n;
   for (int k = 0; k < taps; ++k) {
     const float* plane = dW + ((long long)k * Cout + co) * ldw;
-    for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
-      const int col = perm_col(ci, perm_split, off_lo, off_hi);
-      float s0 = 0.f;
-      for (int sp = 0; sp < splits; ++sp) s0 += plane[sp * split_stride + col];
-      gw[ci * taps + k] = s0;
+    if constexpr (VEC) {
+      // 16-byte loads of 4 consecutive input channels (the host checked that the column permutation keeps groups
+      // of 4 together and aligned); the split-K slabs are independent loads, issued back to back
+      for (int ci = threadIdx.x * 4; ci < Cin; ci += blockDim.x * 4) {
+        const int col = perm_col(ci, perm_split, off_lo, off_hi);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int sp = 0; sp < splits; ++sp) {
+          const float4 t = *reinterpret_cast<const float4*>(plane + sp * split_stride + col);
+          s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+        }
+        gw[ci * taps + k] = s0.x;
+        gw[(ci + 1) * taps + k] = s0.y;
+        gw[(ci + 2) * taps + k] = s0.z;
+        gw[(ci + 3) * taps + k] = s0.w;
+      }
+    } else {
+      for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+        const int col = perm_col(ci, perm_split, off_lo, off_hi);
+        float s0 = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s0 += plane[sp * split_stride + col];
+        gw[ci * taps + k] = s0;
+      }
     }
   }
   __syncthreads();
@@ -95,7 +114,16 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
   const float inv = inv_norm[co], gg = g[co];
   if (threadIdx.x == 0) dg[co] = dot * inv;
   const float a = gg * inv, b = gg * dot * inv * inv * inv;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dv[(long long)co * n + i] = a * gw[i] - b * vr[i];
+  if (VEC && n % 4 == 0) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(vr + i);
+      const float4 gv = *reinterpret_cast<const float4*>(gw + i);
+      *reinterpret_cast<float4*>(dv + (long long)co * n + i) =
+          make_float4(a * gv.x - b * vv.x, a * gv.y - b * vv.y, a * gv.z - b * vv.z, a * gv.w - b * vv.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dv[(long long)co * n + i] = a * gw[i] - b * vr[i];
+  }
 }
 
 // ------------------------------------------------------------------ WN input assembly
@@ -439,8 +467,15 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
   RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldw >= Cin && splits >= 1, "weightnorm_bwd: bad dims");
   const size_t lds = (size_t)Cin * taps * sizeof(float);
   if (lds <= 48 * 1024) {
-    hipLaunchKernelGGL(weightnorm_bwd_lds_kernel, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
-                       splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = Cin % 4 == 0 && perm_split % 4 == 0 && off_lo % 4 == 0 && off_hi % 4 == 0 && ldw % 4 == 0 &&
+                     split_stride % 4 == 0 && a16(dW) && a16(v) && a16(dv);
+    if (vec)
+      hipLaunchKernelGGL(weightnorm_bwd_lds_kernel<true>, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
+                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+    else
+      hipLaunchKernelGGL(weightnorm_bwd_lds_kernel<false>, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
+                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
   } else {
     hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW,
                        splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split,
@@ -573,4 +608,74 @@ extern "C" int radmmm_fused_add_tanh_sigmoid_multiply(const float* a, const floa
   hipLaunchKernelGGL(fatsm_kernel, dim3(grid_for((long long)rows * n)), dim3(256), 0, ST(stream), a, b,
                      ld, y, ldy, rows, n);
   return radmmm::check_launch("fused_add_tanh_sigmoid_multiply");
+}
+
+// ------------------------------------------------------------------ squeeze (nn.Unfold(kernel=(g,1), stride=g))
+// out[(b*Tg + t') * ld + col0 + c*g + k] = in[(b*C + c)*T + t'*g + k]   (decoders.py:118-122,178; models/radmmm.py:114-120)
+// straight from the reference layout [B, C, T] into channels-last rows of a wider matrix (the LSTM input, the flow
+// variable), so neither the permuted copy nor the concatenation exists as a separate pass.  32 channels x 64 samples per
+// workgroup through LDS: reads coalesced along t, writes along the 32*g consecutive columns of a row.
+// INVERSE: the gradient scatter, gin[b, c, t] = gout[row(t / g)][col0 + c*g + t % g] for t < Tg*g, else 0.
+namespace {
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void squeeze_rows_kernel(float* __restrict__ in, float* __restrict__ out, int C, int T,
+                                                           int g, int Tg, int ld, int col0) {
+  __shared__ float tile[32][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const int rows_per_tile = 64 / g, cols_per_row = 32 * g;
+  const long long row0 = (long long)b * Tg + t0 / g;
+  if (!INVERSE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i * 4 + (tid >> 6), t = t0 + (tid & 63);
+      tile[i * 4 + (tid >> 6)][tid & 63] = (c < C && t < Tg * g) ? in[((long long)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 256 * j;
+      const int r = e / cols_per_row, cc = e - r * cols_per_row;
+      const int c = cc / g, k = cc - c * g;
+      if (c0 + c < C && t0 / g + r < Tg) out[(row0 + r) * ld + col0 + (c0 + c) * g + k] = tile[c][r * g + k];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 256 * j;
+      const int r = e / cols_per_row, cc = e - r * cols_per_row;
+      const int c = cc / g, k = cc - c * g;
+      tile[c][r * g + k] = (c0 + c < C && t0 / g + r < Tg) ? out[(row0 + r) * ld + col0 + (c0 + c) * g + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i * 4 + (tid >> 6), t = t0 + (tid & 63);
+      if (c < C && t < T) in[((long long)b * C + c) * T + t] = (t < Tg * g) ? tile[i * 4 + (tid >> 6)][tid & 63] : 0.f;
+    }
+  }
+  (void)rows_per_tile;
+}
+}  // namespace
+
+extern "C" int radmmm_squeeze_rows(const float* in, float* out, int B, int C, int T, int g, int ld, int col0,
+                                   radmmm_stream_t stream) {
+  RADMMM_REQUIRE(in && out, "squeeze_rows: null pointer");
+  RADMMM_REQUIRE(B > 0 && C > 0 && T > 0 && g >= 1 && 64 % g == 0 && T / g > 0 && col0 >= 0 && ld >= col0 + C * g,
+                 "squeeze_rows: bad dims (group size must divide 64)");
+  const int Tg = T / g;
+  hipLaunchKernelGGL(squeeze_rows_kernel<false>, dim3((Tg * g + 63) / 64, (C + 31) / 32, B), dim3(256), 0, ST(stream),
+                     const_cast<float*>(in), out, C, T, g, Tg, ld, col0);
+  return radmmm::check_launch("squeeze_rows");
+}
+
+extern "C" int radmmm_unsqueeze_rows(const float* gout, float* gin, int B, int C, int T, int g, int ld, int col0,
+                                     radmmm_stream_t stream) {
+  RADMMM_REQUIRE(gin && gout, "unsqueeze_rows: null pointer");
+  RADMMM_REQUIRE(B > 0 && C > 0 && T > 0 && g >= 1 && 64 % g == 0 && T / g > 0 && col0 >= 0 && ld >= col0 + C * g,
+                 "unsqueeze_rows: bad dims (group size must divide 64)");
+  const int Tg = T / g;
+  hipLaunchKernelGGL(squeeze_rows_kernel<true>, dim3((T + 63) / 64, (C + 31) / 32, B), dim3(256), 0, ST(stream), gin,
+                     const_cast<float*>(gout), C, T, g, Tg, ld, col0);
+  return radmmm::check_launch("unsqueeze_rows");
 }

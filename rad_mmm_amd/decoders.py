@@ -284,30 +284,19 @@ class RADMMMFlow(nn.Module):
         mel = z.reshape(B, Tg, C0 // g, g).permute(0, 2, 1, 3).reshape(B, C0 // g, Tg * g)
         return {"mel": mel.contiguous()}
 
-    def _squeeze_cl(self, x: torch.Tensor) -> torch.Tensor:
-        """[B, C, T] -> channels-last grouped [B, T//g, C*g] with channel c*g+k
-        (nn.Unfold order, decoders.py:118-122; models/radmmm.py:114-120)."""
-        g = self.n_group_size
-        B, C, T = x.shape
-        Tg = T // g
-        return x[:, :, : Tg * g].reshape(B, C, Tg, g).permute(0, 2, 1, 3).reshape(B, Tg, C * g)
-
     def preprocess_context_cl(self, context, spk_vecs, seq_lens: SequenceLength, f0=None, energy_avg=None,
                               accent_vecs=None):
         """models/radmmm.py:103-148, producing channels-last [B, T', D]."""
         g = self.n_group_size
-        ctx = self._squeeze_cl(context)
-        B, Tg, _ = ctx.shape
-        parts = [ctx, spk_vecs[:, None, :].expand(-1, Tg, -1)]
+        B, _, T = context.shape
+        Tg = T // g
         if self.use_accent_emb_for_decoder:
             assert accent_vecs is not None
-            parts.append(accent_vecs[:, None, :].expand(-1, Tg, -1))
-        if self.context_w_f0_and_energy:
-            if f0 is not None:
-                parts.append(self._squeeze_cl(f0[:, None]))
-            if energy_avg is not None:
-                parts.append(self._squeeze_cl(energy_avg[:, None]))
-        x = torch.cat(parts, 2)
+        use_tracks = self.context_w_f0_and_energy
+        # squeeze + concatenation in one assembly pass (ops.LstmInputFn): [context (c*g+k) | spk | accent | f0 | energy]
+        x = ops.LstmInputFn.apply(g, context, spk_vecs.float(), accent_vecs.float() if self.use_accent_emb_for_decoder else None,
+                                  f0.float() if (use_tracks and f0 is not None) else None,
+                                  energy_avg.float() if (use_tracks and energy_avg is not None) else None)
         if not self.use_context_lstm:
             return x.contiguous()
         ul = torch.div(seq_lens.lengths_host, g, rounding_mode="floor")
@@ -374,9 +363,8 @@ class RADMMMFlow(nn.Module):
         g = self.n_group_size
         cond = self.preprocess_context_cl(context.float(), spk_vecs.float(), out_lens, f0, energy_avg, accent_vecs)
         B, Tg, D = cond.shape
-        z3 = self._squeeze_cl(mel.float())                       # [B, T', C0]
-        C0 = z3.shape[2]
-        z = F.pad(z3, (0, ZLD - C0)).reshape(B * Tg, ZLD).contiguous() if C0 != ZLD else z3.reshape(B * Tg, ZLD).contiguous()
+        C0 = mel.shape[1] * g
+        z = ops.squeeze_rows(mel.float(), g, ZLD, 0)             # [B*T', ZLD]: squeeze + zero padding in one pass
         cond2 = cond.reshape(B * Tg, D)
         lens32 = torch.div(out_lens.lengths, g, rounding_mode="floor").to(torch.int32)
         unfolded = _UnfoldedLens(out_lens, g, Tg)

@@ -300,6 +300,101 @@ class AffineFlowStepFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------
+# squeeze (nn.Unfold group g) folded into the assembly of the channels-last operands
+# ---------------------------------------------------------------------------------------
+class SqueezeRowsFn(torch.autograd.Function):
+    """x [B, C, T] (reference layout) -> channels-last rows [B*T', ld], T' = T // g, the C*g squeezed channels (order
+    c*g + k, nn.Unfold's) at columns [col0, col0 + C*g), zeros elsewhere (decoders.py:118-122,178)."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, x, g, ld, col0):
+        B, C, T = x.shape
+        x = f32c(x)
+        Tg = T // g
+        out = (torch.zeros if ld != C * g else torch.empty)(B * Tg, ld, device=x.device, dtype=torch.float32)
+        check(lib.radmmm_squeeze_rows(ptr(x), ptr(out), B, C, T, g, ld, col0, stream()), "squeeze_rows")
+        ctx.dims = (B, C, T, g, ld, col0)
+        return out
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, gout):
+        B, C, T, g, ld, col0 = ctx.dims
+        gin = torch.empty(B, C, T, device=gout.device, dtype=torch.float32)
+        check(lib.radmmm_unsqueeze_rows(ptr(f32c(gout)), ptr(gin), B, C, T, g, ld, col0, stream()), "unsqueeze_rows")
+        return gin, None, None, None
+
+
+def squeeze_rows(x: torch.Tensor, g: int, ld: int, col0: int = 0) -> torch.Tensor:
+    return SqueezeRowsFn.apply(x, g, ld, col0)
+
+
+class LstmInputFn(torch.autograd.Function):
+    """Input of the context LSTM (models/radmmm.py:114-134): cat(unfold(context), spk, [accent], unfold(f0),
+    unfold(energy)) as channels-last rows [B, T', I] written in place -- the squeeze kernel puts the context into its
+    columns, the per-utterance vectors are broadcast and the one-channel tracks are plain views (channel c*g + k with
+    C = 1 is sample t'*g + k).  No permuted copy, no concatenation."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, g, context, spk, accent, f0, energy):
+        B, Ct, T = context.shape
+        Tg = T // g
+        widths = [Ct * g, spk.shape[1], accent.shape[1] if accent is not None else 0, g if f0 is not None else 0,
+                  g if energy is not None else 0]
+        I = sum(widths)
+        x = torch.empty(B, Tg, I, device=context.device, dtype=torch.float32)
+        check(lib.radmmm_squeeze_rows(ptr(f32c(context)), ptr(x), B, Ct, T, g, I, 0, stream()), "squeeze_rows")
+        o = widths[0]
+        x[:, :, o: o + widths[1]] = spk[:, None, :]
+        o += widths[1]
+        if accent is not None:
+            x[:, :, o: o + widths[2]] = accent[:, None, :]
+            o += widths[2]
+        if f0 is not None:
+            x[:, :, o: o + g] = f0[:, : Tg * g].reshape(B, Tg, g)
+            o += g
+        if energy is not None:
+            x[:, :, o: o + g] = energy[:, : Tg * g].reshape(B, Tg, g)
+        ctx.dims = (B, Ct, T, g, I, widths)
+        ctx.flags = (accent is not None, f0 is not None, energy is not None)
+        return x
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, gx):
+        B, Ct, T, g, I, widths = ctx.dims
+        has_acc, has_f0, has_en = ctx.flags
+        Tg = T // g
+        gx = f32c(gx)
+        need = ctx.needs_input_grad
+        gctx = None
+        if need[1]:
+            gctx = torch.empty(B, Ct, T, device=gx.device, dtype=torch.float32)
+            check(lib.radmmm_unsqueeze_rows(ptr(gx), ptr(gctx), B, Ct, T, g, I, 0, stream()), "unsqueeze_rows")
+        o = widths[0]
+        gspk = gx[:, :, o: o + widths[1]].sum(1) if need[2] else None
+        o += widths[1]
+        gacc = None
+        if has_acc:
+            gacc = gx[:, :, o: o + widths[2]].sum(1) if need[3] else None
+            o += widths[2]
+
+        def track(off):
+            gt = torch.zeros(B, T, device=gx.device, dtype=torch.float32)
+            gt[:, : Tg * g] = gx[:, :, off: off + g].reshape(B, Tg * g)
+            return gt
+        gf0 = gen = None
+        if has_f0:
+            gf0 = track(o) if need[4] else None
+            o += g
+        if has_en:
+            gen = track(o) if need[5] else None
+        return None, gctx, gspk, gacc, gf0, gen
+
+
+# ---------------------------------------------------------------------------------------
 # masked reductions for the flow NLL (loss.py:85-110)
 # ---------------------------------------------------------------------------------------
 class MaskedReduceFn(torch.autograd.Function):

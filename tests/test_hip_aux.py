@@ -272,3 +272,31 @@ def test_attention_full_size_with_device_prior():
         idx = h.argmax(1)
         assert int(idx[0]) == 0 and int(idx[-1]) == n - 1 and torch.all((idx[1:] - idx[:-1] >= 0) & (idx[1:] - idx[:-1] <= 1))
         assert torch.all(hard[b, t:] == 0) and torch.all(hard[b, :, n:] == 0)
+
+
+@pytest.mark.parametrize("B,C,T,g,ld,col0", [(3, 80, 101, 2, 160, 0), (2, 37, 64, 2, 96, 10), (2, 5, 130, 4, 24, 4), (1, 512, 800, 2, 1052, 0),
+                                             (2, 9, 70, 1, 12, 3)])
+def test_squeeze_rows_matches_unfold(B, C, T, g, ld, col0):
+    """radmmm_squeeze_rows / radmmm_unsqueeze_rows against nn.Unfold(kernel=(g,1), stride=g) and its autograd
+    (decoders.py:118-122,178): channel order c*g + k, frames beyond g*(T//g) dropped, other columns left zero."""
+    from rad_mmm_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, T, generator=gen)
+    Tg = T // g
+    ref_in = x.clone().requires_grad_(True)
+    # nn.Unfold on [B, C, T, 1] with kernel (g, 1), stride g: output [B, C*g, Tg], channel index c*g + k
+    unf = torch.nn.Unfold(kernel_size=(g, 1), stride=g)(ref_in[:, :, : Tg * g, None])
+    assert unf.shape == (B, C * g, Tg)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.squeeze_rows(xd, g, ld, col0)
+    assert out.shape == (B * Tg, ld)
+    got = out.view(B, Tg, ld)
+    assert torch.equal(got[:, :, col0: col0 + C * g].cpu(), unf.detach().transpose(1, 2))
+    mask = torch.ones(ld, dtype=torch.bool)
+    mask[col0: col0 + C * g] = False
+    if mask.any():
+        assert float(got[:, :, mask].abs().max()) == 0.0
+    w = torch.randn(B, Tg, ld, generator=gen)
+    (got * w.to(DEV)).sum().backward()
+    (unf.transpose(1, 2) * w[:, :, col0: col0 + C * g]).sum().backward()
+    assert torch.equal(xd.grad.cpu(), ref_in.grad)
