@@ -379,6 +379,15 @@ int radmmm_transpose_split_act_colsum(const float* x, int ld, int C, int B, int 
                                       void* o1l, int ldk, float* part, int sum_weight, int sum_taps, int sum_dil,
                                       radmmm_stream_t stream);
 int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, radmmm_stream_t stream);
+/* y = g * act'(saved) (radmmm_dact_mul without row weights) written three ways in one pass, with no fp32 copy of y:
+ * the row-major split pair yh/yl [rows][ldyh] of scale*y in so's format (feeds the data-gradient GEMM), the transposed
+ * zero-gapped split-f16 pair oh/ol [C][ldk] of scale*y (radmmm_transpose_split_act's layout: feeds radmmm_wgrad_h3), and
+ * the column sums of y as part [B * ceil(Tp / 64)][C] (radmmm_colsum_final adds them: the bias gradient).
+ * C, ldg, lds multiples of 4; yh may be NULL. */
+int radmmm_dact_mul_transposed(const float* g, int ldg, const float* saved, int lds, int C, int B, int T, int Tp,
+                               int front, int dact, float scale, void* yh, void* yl, int ldyh,
+                               const radmmm_split_opts* so, void* oh, void* ol, int ldk, float* part,
+                               radmmm_stream_t stream);
 /* number of workgroup tiles radmmm_wgrad_h3 launches per split (the caller picks `splits` so that
  * tiles * splits fills whole rounds of the CUs: one workgroup per CU) */
 int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);

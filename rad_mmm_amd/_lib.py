@@ -138,6 +138,7 @@ def _load() -> C.CDLL:
         "radmmm_radam_step": [p, p, p, p, i64, p, f, f, f, f, f, i, p],
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
         "radmmm_colsum_final": [p, p, i, i, p],
+        "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],

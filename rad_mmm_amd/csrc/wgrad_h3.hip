@@ -12,7 +12,10 @@
 //
 // Kernel = the NT split-f16 GEMM of h3_gemm.hip (128x128x32 tile, 3 MFMA per product block)
 // plus a scalar column offset on the B operand and split-K slabs.
+#include <math.h>
+
 #include "common.h"
+#include "split_pack.h"
 
 namespace {
 
@@ -332,6 +335,74 @@ __global__ __launch_bounds__(256) void transpose_split_act_kernel(
   }
 }
 
+// y = g * act'(saved) (the step from dL/d(act output) to dL/d(conv accumulator), radmmm_dact_mul without row weights)
+// written THREE ways in one pass over g and saved, with no fp32 copy of y: (1) the row-major split pair that feeds the
+// data-gradient GEMM (any split format, saturation flag), (2) the transposed zero-gapped split-f16 pair that feeds the
+// weight-gradient GEMM (radmmm_transpose_split_act's layout, no mask, no advanced copy: the consumer is a 1-tap
+// gradient), (3) the column sums of y (bias gradient) as one row of partials per block.  Replaces radmmm_dact_mul +
+// radmmm_transpose_split_act_colsum for the res/skip branch: 104 MB less HBM traffic per layer at the benchmark size.
+// 64 frames x 64 channels per workgroup.
+__global__ __launch_bounds__(256) void dact_transposed_kernel(
+    const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds, int C, int T, int Tp, int front, int dact,
+    float scale, void* __restrict__ yh, void* __restrict__ yl, int ldyh, int fmt, float x8_mul, int* __restrict__ sat_flag,
+    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part) {
+  __shared__ float tile[64][65];
+  __shared__ float red[16][65];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 float4 columns x 16 rows per pass
+  const int c = c0 + tx * 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sat = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tl = i * 16 + ty, t = t0 + tl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T && c < C) {                                       // C % 4 == 0: whole groups of 4 columns
+      const long long row = (long long)b * T + t;
+      const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + c);
+      v = gv;
+      if (dact) {
+        const float4 sv = *reinterpret_cast<const float4*>(saved + row * lds + c);
+        v.x = gv.x * radmmm::dact_from_out(sv.x, dact);
+        v.y = gv.y * radmmm::dact_from_out(sv.y, dact);
+        v.z = gv.z * radmmm::dact_from_out(sv.z, dact);
+        v.w = gv.w * radmmm::dact_from_out(sv.w, dact);
+      }
+      if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w));
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    tile[tl][tx * 4 + 0] = v.x * scale;
+    tile[tl][tx * 4 + 1] = v.y * scale;
+    tile[tl][tx * 4 + 2] = v.z * scale;
+    tile[tl][tx * 4 + 3] = v.w * scale;
+  }
+  red[ty][tx * 4 + 0] = s0; red[ty][tx * 4 + 1] = s1; red[ty][tx * 4 + 2] = s2; red[ty][tx * 4 + 3] = s3;
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    float t16 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t16 += red[w][threadIdx.x];
+    part[((long long)b * gridDim.y + blockIdx.y) * C + c0 + threadIdx.x] = t16;
+  }
+  // transposed copy: lanes run along time (64 consecutive frames of one channel = 128 contiguous bytes per array);
+  // frames in [T, Tp) are the zero gap after the utterance and are (re)written here as zeros (tile rows hold zeros there)
+  const int fl = threadIdx.x & 63, cl0 = threadIdx.x >> 6;
+  const int t = t0 + fl;
+  if (t < Tp) {
+    const long long k = (long long)front + (long long)b * Tp + t;
+    for (int ci = cl0; ci < 64; ci += 4) {
+      const int cc = c0 + ci;
+      if (cc < C) {
+        const float v = radmmm::clamp_f16(tile[fl][ci]);
+        const _Float16 h = (_Float16)v;
+        oh[(long long)cc * ldk + k] = h;
+        ol[(long long)cc * ldk + k] = (_Float16)(v - (float)h);
+      }
+    }
+  }
+  radmmm::raise_sat_flag(sat_flag, sat);
+}
+
 }  // namespace
 
 static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp, int front, const int32_t* lens,
@@ -412,4 +483,24 @@ extern "C" int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh,
     case 5: return launch_wgrad<5>(a, st);
     default: return launch_wgrad<4>(a, st);
   }
+}
+
+
+extern "C" int radmmm_dact_mul_transposed(const float* g, int ldg, const float* saved, int lds, int C, int B, int T, int Tp,
+                                          int front, int dact, float scale, void* yh, void* yl, int ldyh,
+                                          const radmmm_split_opts* so, void* oh, void* ol, int ldk, float* part,
+                                          radmmm_stream_t stream) {
+  RADMMM_REQUIRE(g && oh && ol && part && (saved || !dact), "dact_mul_transposed: null pointer");
+  RADMMM_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && T > 0 && Tp >= T && front >= 1 && ldk % 8 == 0 && ldk >= front + B * Tp &&
+                     ldg >= C && ldg % 4 == 0 && (!dact || (lds >= C && lds % 4 == 0)),
+                 "dact_mul_transposed: bad dims (C, ldg, lds multiples of 4)");
+  RADMMM_REQUIRE(radmmm::aligned16(g) && (!dact || radmmm::aligned16(saved)), "dact_mul_transposed: 16-byte aligned inputs");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(!yh || (yl && ldyh >= C && ldyh % 4 == 0 && (fmt == RADMMM_SPLIT_F16 || ldyh % 32 == 0)),
+                 "dact_mul_transposed: row-major split output (ldyh %% 4 == 0; 8-bit formats: %% 32)");
+  hipLaunchKernelGGL(dact_transposed_kernel, dim3((C + 63) / 64, (Tp + 63) / 64, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, ldg, saved, lds, C, T, Tp, front, dact, scale, yh, yl, ldyh, fmt,
+                     ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr, static_cast<_Float16*>(oh),
+                     static_cast<_Float16*>(ol), ldk, part);
+  return radmmm::check_launch("dact_mul_transposed");
 }

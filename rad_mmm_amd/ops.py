@@ -664,12 +664,8 @@ _TS_FRONT = 16           # leading zero columns / zero gap between utterances (>
 _ts_pool = {}
 
 
-def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None, sum_out=None):
-    """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
-    Buffers come from a small zero-initialised pool keyed by role: the pads are never written, the data
-    and the gaps are rewritten on every call (single stream => reuse is ordered).
-    colsum = (row_weight, lens, taps, dil): also return the weighted column sums of x (the bias
-    gradient) computed in the same pass -> (copy tuple, sums [C])."""
+def _ts_buffers(device, C, B, T, role, need_odd):
+    """pooled [C, ldk] fp16 buffers of a transposed zero-gapped split copy -> (list of views, Tp, Kt, ldk)"""
     Tp = T + _TS_FRONT
     Kt = round_up(B * Tp, 32)                 # contracted columns [FRONT, FRONT + Kt)
     ldk = Kt + 2 * _TS_FRONT
@@ -677,19 +673,45 @@ def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False
     # from storage sized for the largest shape seen, and whenever the shape changes the used region is cleared
     # (the kernel rewrites data and gaps only; front, tail and the round-up columns must read as zeros)
     # (one pool per stream: buffers are reused in launch order, which only a single stream guarantees)
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, C, role, need_odd)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, C, role, need_odd)
     ent = _ts_pool.get(key)
     need = C * ldk
     if ent is None or ent["cap"] < need:
         n = 4 if need_odd else 2
-        ent = {"flat": [torch.zeros(need, device=x.device, dtype=torch.float16) for _ in range(n)], "cap": need,
+        ent = {"flat": [torch.zeros(need, device=device, dtype=torch.float16) for _ in range(n)], "cap": need,
                "shape": (B, Tp)}
         _ts_pool[key] = ent
     elif ent["shape"] != (B, Tp):
         for f in ent["flat"]:
             f[:need].zero_()
         ent["shape"] = (B, Tp)
-    bufs = [f[:need].view(C, ldk) for f in ent["flat"]]
+    return [f[:need].view(C, ldk) for f in ent["flat"]], Tp, Kt, ldk
+
+
+def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp, sat_flag, sum_out=None):
+    """y = g * act'(saved) written as the row-major split pair yh/yl (format fmt), as the transposed zero-gapped
+    split-f16 copy (pool `role`) and as column sums, in one pass and without an fp32 y (radmmm_dact_mul_transposed)
+    -> (transposed-copy tuple, sums [C])."""
+    bufs, Tp, Kt, ldk = _ts_buffers(g.device, C, B, T, role, False)
+    oh, ol = bufs[0], bufs[1]
+    nparts = B * (-(-Tp // 64))
+    part = _empty(nparts, C, like=g)
+    sums = sum_out if (sum_out is not None and sum_out.numel() == C) else _empty(C, like=g)
+    check(lib.radmmm_dact_mul_transposed(ptr(g), g.shape[1], ptr(saved), saved.shape[1] if saved is not None else 0, C, B, T, Tp,
+                                         _TS_FRONT, act, scale, ptr(yh), ptr(yl), yh.shape[1] if yh is not None else 0,
+                                         split_opts(fmt, x8_exp, sat_flag), ptr(oh), ptr(ol), ldk, ptr(part), stream()),
+          "dact_mul_transposed")
+    check(lib.radmmm_colsum_final(ptr(part), ptr(sums), nparts, C, stream()), "colsum_final")
+    return (oh, ol, None, None, Kt), sums
+
+
+def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None, sum_out=None):
+    """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
+    Buffers come from a small zero-initialised pool keyed by role: the pads are never written, the data
+    and the gaps are rewritten on every call (single stream => reuse is ordered).
+    colsum = (row_weight, lens, taps, dil): also return the weighted column sums of x (the bias
+    gradient) computed in the same pass -> (copy tuple, sums [C])."""
+    bufs, Tp, Kt, ldk = _ts_buffers(x.device, C, B, T, role, need_odd)
     oh, ol = bufs[0], bufs[1]
     o1h, o1l = (bufs[2], bufs[3]) if need_odd else (None, None)
     if colsum is None:
@@ -957,7 +979,6 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         inv_acc = 1.0 / (SG * W_SCALE)
         gin = dict(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, acc_scale=inv_acc, T=T, sat_flag=flag)
         gout = dict(split_fmt=fa, ch_x8_exp=X8_GRAD_EXP)
-        so_g = lambda: split_opts(fa, X8_GRAD_EXP, flag)
 
         gO = torch.zeros(N, ZLD, device=z_in.device, dtype=torch.float32)      # columns >= C stay zero (K = ZLD)
         gz1 = _empty(N, ZLD, like=z_in)
@@ -974,15 +995,14 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         G = None
         Gh = Gl = None
-        gQ = _empty(N, Wc, like=z_in)
         gQh, gQl = _halves(N, Wc, like=z_in)
         x_prev = None
         for j in range(nl - 1, -1, -1):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
-            check(lib.radmmm_dact_mul(ptr(gOUT), Wc, ptr(R[j]), Wc, ptr(gQ), Wc, N, Wc, act, 0, T, None, 1, 1, ptr(gQh),
-                                      ptr(gQl), Wc, SG, so_g(), stream()), "dact_mul")
-            gy_t, g_res[3 * j + 2] = transpose_split_act(gQ, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
+            # through softplus of the res/skip branch: gQ = gOUT * act'(R_j), written as the dgrad GEMM's row-major split
+            # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
+            gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, "gy", gQh, gQl, fa, X8_GRAD_EXP, flag,
                                                          sum_out=grad_out(res_p[3 * j + 2]))
             # H[j+1]'s transposed copy may still be in the pool from layer j+1's in_layer weight gradient (x_prev, set
             # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)

@@ -300,3 +300,32 @@ def test_squeeze_rows_matches_unfold(B, C, T, g, ld, col0):
     (got * w.to(DEV)).sum().backward()
     (unf.transpose(1, 2) * w[:, :, col0: col0 + C * g]).sum().backward()
     assert torch.equal(xd.grad.cpu(), ref_in.grad)
+
+
+@pytest.mark.parametrize("B,T,C,fmt", [(2, 70, 96, 0), (3, 64, 1024, 1), (1, 129, 32, 0)])
+def test_dact_mul_transposed_matches_the_two_pass_path(B, T, C, fmt):
+    """radmmm_dact_mul_transposed (one pass, no fp32 product) against radmmm_dact_mul followed by
+    radmmm_transpose_split_act_colsum: the row-major split pair, the transposed split pair and the column sums."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import lib, check, ptr, stream, split_opts
+    gen = torch.Generator().manual_seed(B * 100 + C)
+    N = B * T
+    g = (torch.randn(N, C, generator=gen) * 3e-3).to(DEV)
+    saved = torch.nn.functional.softplus(torch.randn(N, C, generator=gen) * 2).to(DEV)
+    S = 2048.0
+    ld = ops.round_up(C, 32)
+    x8 = ops.X8_GRAD_EXP
+    # two-pass reference
+    y = torch.empty(N, C, device=DEV)
+    yh0, yl0 = ops._halves(N, ld, like=y, zero=True)
+    check(lib.radmmm_dact_mul(ptr(g), C, ptr(saved), C, ptr(y), C, N, C, 1, 0, T, None, 1, 1, ptr(yh0), ptr(yl0), ld, S,
+                              split_opts(fmt, x8), stream()), "dact_mul")
+    ref_t, ref_sum = ops.transpose_split_act(y, C, B, T, None, 0, S, "ref_gy", colsum=(0, None, 1, 1))
+    ref_t = [t.clone() for t in ref_t[:2]]
+    # fused
+    yh1, yl1 = ops._halves(N, ld, like=y, zero=True)
+    got_t, got_sum = ops.dact_mul_transposed(g, saved, C, B, T, 1, S, "fused_gy", yh1, yl1, fmt, x8, None)
+    assert torch.equal(yh1.view(torch.int16), yh0.view(torch.int16)) and torch.equal(yl1.view(torch.int16), yl0.view(torch.int16))
+    assert torch.equal(got_t[0].view(torch.int16), ref_t[0].view(torch.int16))
+    assert torch.equal(got_t[1].view(torch.int16), ref_t[1].view(torch.int16))
+    assert rel_err(got_sum.cpu(), y.sum(0).cpu()) < 1e-5 and rel_err(ref_sum.cpu(), y.sum(0).cpu()) < 1e-5
