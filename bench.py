@@ -435,7 +435,8 @@ def main():
                          "frac_algorithmic": achieved / peak, "frac_executed": nprod * achieved / peak,
                          "avg_launch_ms": kdur * 1e3, "flop_per_launch": kflop, "executed_mfma_flop_per_launch": nprod * kflop,
                          "executed_mfma_tflops": nprod * achieved,
-                         "algorithmic_bytes_per_launch": (N * 1024 * 4 + 5 * 1024 * 1024 * 4 + N * 1024 * 4) if h3 else None,
+                         # split A operand (4 B/element) + split weights (4 B) + fp32 output (4 B) + its split copy (4 B), each once
+                         "algorithmic_bytes_per_launch": (N * 1024 * 12 + 5 * 1024 * 1024 * 4) if h3 else None,
                          "traffic": traffic, "traffic_static": traffic is not None, "traffic_source": traffic_src,
                          # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
                          # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
