@@ -308,11 +308,15 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   const int f_off1 = f_row + (((2 + (lane >> 5)) ^ f_swz) << 4);
 
   int l_tap = 0, l_kb = 0;                             // tile being fetched; clamped to the last one
+  // Taps run INNERMOST: for one 32-channel k slice the taps re-read the same operand rows shifted by <= 2*dil frames,
+  // i.e. lines that the previous tap brought into this XCD's L2 a K step ago.  With the taps outermost (round 1) a tap's
+  // pass over all k slices pushed 10 MB through the 4 MB L2 before the next tap came back to the same rows: the A panel
+  // was fetched from the Infinity Cache five times per launch (FETCH_SIZE 464 MB against 220 MB of per-XCD unique data).
   auto advance = [&]() __attribute__((always_inline)) {
     const bool last = (l_tap == p.taps - 1) && (l_kb == kpt - 1);
-    const bool wrap = l_kb == kpt - 1;
-    l_kb = last ? l_kb : (wrap ? 0 : l_kb + 1);
-    l_tap = (wrap && !last) ? l_tap + 1 : l_tap;
+    const bool wrap = l_tap == p.taps - 1;
+    l_tap = last ? l_tap : (wrap ? 0 : l_tap + 1);
+    l_kb = (wrap && !last) ? l_kb + 1 : l_kb;
   };
   set_tap(0);
 #pragma unroll

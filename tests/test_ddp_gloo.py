@@ -111,3 +111,21 @@ def test_bucket_key():
     assert default_bucket_key("decoder.flows.11.invtbl_conv.lower") == "decoder.flows.11"      # reducer around the whole step
     assert default_bucket_key("f0_predictor.feat_pred.lstm.weight_hh_l0") == "misc"
     assert default_bucket_key("context_lstm.weight_ih_l0") == "misc"
+
+
+def test_collective_cu_reservation_reaches_the_library():
+    """ddp.reserve_collective_cus() (what bench.py calls for N > 1 before RCCL starts) pins RCCL's channel count and makes
+    libradmmm_hip.so size its GEMM grids for the remaining CUs (radmmm_gemm_cu_slots reads RADMMM_GEMM_CUS once per
+    process, hence the child process)."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "for k in ('NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'RADMMM_GEMM_CUS'): os.environ.pop(k, None)\n"
+            "from rad_mmm_amd.ddp import reserve_collective_cus, RCCL_CUS\n"
+            "reserve_collective_cus()\n"
+            "from rad_mmm_amd._lib import lib\n"
+            "print(os.environ['NCCL_MAX_NCHANNELS'], os.environ['NCCL_MIN_NCHANNELS'], os.environ['RADMMM_GEMM_CUS'], "
+            "lib.radmmm_gemm_cu_slots(), RCCL_CUS)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    mx, mn, cus, slots, n = out.stdout.split()[-5:]
+    assert mx == mn == n == "8" and cus == "248" and slots == "248"
