@@ -34,7 +34,9 @@ RADTTS = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8,
 
 # BASELINE configs[4]: 16 kHz / RADMMM dims (n_text_dim 520, accent not in decoder) with 2 spline steps
 RADMMM_SPLINES = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
-CONFIGS = {"radtts": RADTTS, "radmmm_splines": RADMMM_SPLINES}
+# BASELINE configs[2]: the shipped RADMMM decoder (configs/RADMMM_model_config.yaml:16-39): 8 affine flows, D = 1056
+RADMMM = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False)
+CONFIGS = {"radtts": RADTTS, "radmmm": RADMMM, "radmmm_splines": RADMMM_SPLINES}
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
@@ -244,7 +246,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="radtts",
-                    help="radtts = BASELINE configs[1] (headline); radmmm_splines = configs[4] architecture")
+                    help="radtts = BASELINE configs[1] (headline); radmmm = configs[2] (shipped RADMMM decoder); "
+                         "radmmm_splines = configs[4] architecture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra leg that times the 16-bit (single fp16 product) throughput mode")
@@ -421,6 +424,8 @@ def main():
             "data": "synthetic (procedural random-init weights, N(2.5,0.5) mel, fixed length)",
             "config": {"workload": ("RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
                                     "D=1048) fwd+NLL+bwd") if args.config == "radtts" else
+                                   ("RADMMM flow decoder (configs/RADMMM_model_config.yaml: 8 flows, WN 1024x4, D=1056) "
+                                    "fwd+NLL+bwd") if args.config == "radmmm" else
                                    ("RADMMM 16 kHz-dims flow decoder (configs/RADMMM_16khz_model_config.yaml + "
                                     "n_splines=2: 2 spline/FiLM + 6 affine/WN flows, D=1056) fwd+NLL+bwd"),
                        "batch_per_gpu": B, "n_mel": 80, "frames": T,

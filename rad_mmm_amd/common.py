@@ -8,6 +8,8 @@ appears only at the decoder boundary (decoders.RADMMMFlow).
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional, Tuple
 
@@ -229,9 +231,14 @@ class AffineTransformationLayer(nn.Module):
         halves only = plain fp16 operands, fp32 accumulate (16-bit throughput mode, NOT within the 1e-4 bar)."""
         wn = self.affine_param_predictor
         head, layers = wn.flat_params()
+        nprod = ops.NPROD.get(precision, 3)
+        if nprod == 2 and B * T < int(os.environ.get("RADMMM_F8X_MIN_ROWS", "4096")):
+            # below half a round of the one-workgroup-per-CU kernel's smallest tile the split GEMMs run on the 128 x 128
+            # two-workgroups-per-CU kernel, which has the three-f16-product scheme only (B = 8, T = 800: 38.7 vs 40.9 ms)
+            nprod = 3
         meta = dict(B=B, T=T, C=self.n_mel_channels, D=self.n_context_dim, n_layers=wn.n_layers,
                     act=ACT[wn.affine_activation], scaling=SCALE[self.scaling_fn],
                     partial=bool(wn.use_partial_padding), scale_box=scale_box if scale_box is not None else {},
-                    nprod=ops.NPROD.get(precision, 3))
+                    nprod=nprod)
         fn = ops.AffineFlowStepH3Fn if (precision in ops.NPROD and wn.n_channels % 32 == 0) else ops.AffineFlowStepFn
         return fn.apply(meta, z_cl, cond_cl, lens32, W_eff, b_eff, *head, *layers)

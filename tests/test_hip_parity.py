@@ -385,6 +385,7 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
         precision = "h3"
         monkeypatch.setenv("RADMMM_H3_TILE", "256")
     monkeypatch.setenv("RADMMM_CONVNORM_H3_MIN_ROWS", "0" if precision in ("h3", "f8x") else "1000000000")
+    monkeypatch.setenv("RADMMM_F8X_MIN_ROWS", "0")      # keep the FP8-cross scheme on these small batches (default: >= 4096 rows)
     monkeypatch.setenv("RADMMM_PRECISION", precision)
     """Full-width decoder (WN 1024) fwd + NLL + bwd vs the reference run (procedural weights).
     cfg1 = BASELINE config 1 (2 flows, B=2, T=256 ragged); cfg2_small = config-2 architecture;
