@@ -288,7 +288,7 @@ int wgrad_mb(int Mc) {
 __global__ __launch_bounds__(256) void transpose_split_act_kernel(
     const float* __restrict__ x, int ld, int C, int T, int Tp, int front, const int* __restrict__ lens, int mask_mode,
     float scale, _Float16* __restrict__ oh, _Float16* __restrict__ ol, _Float16* __restrict__ o1h,
-    _Float16* __restrict__ o1l, int ldk, float* __restrict__ part, int sum_weight, int sum_taps, int sum_dil) {
+    _Float16* __restrict__ o1l, int ldk, float* __restrict__ part, int sum_weight, int sum_taps, int sum_dil, int vec4) {
   __shared__ float tile[64][33];
   __shared__ float red[8][33];
   const int b = blockIdx.z;
@@ -314,6 +314,37 @@ __global__ __launch_bounds__(256) void transpose_split_act_kernel(
   }
   // lanes run along time: for one channel, 64 consecutive frames = 128 contiguous bytes per array.
   // Frames t in [T, Tp) are the zero gap after the utterance and are (re)written here as zeros.
+  if (vec4) {
+    // four consecutive frames per lane (8-byte stores; front, Tp multiples of 4 keep them aligned): a quarter of the
+    // store instructions of the element-wise form below
+    const int q = threadIdx.x & 15, cl0 = threadIdx.x >> 4;          // 16 frame quads x 16 channels per pass
+    const int t = t0 + 4 * q;
+    if (t < Tp) {                                                       // Tp % 4 == 0: whole quads
+      const long long k = (long long)front + (long long)b * Tp + t;
+      for (int ci = cl0; ci < 32; ci += 16) {
+        const int c = c0 + ci;
+        if (c < C) {
+          radmmm::f16x4_t h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = radmmm::clamp_f16(tile[4 * q + e][ci]);
+            h[e] = (_Float16)v;
+            l[e] = (_Float16)(v - (float)h[e]);
+          }
+          *reinterpret_cast<radmmm::f16x4_t*>(oh + (long long)c * ldk + k) = h;
+          *reinterpret_cast<radmmm::f16x4_t*>(ol + (long long)c * ldk + k) = l;
+          if (o1h) {                                 // advanced by one column: X1[k-1] = X[k] (2-byte aligned only)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o1h[(long long)c * ldk + k - 1 + e] = h[e];
+              o1l[(long long)c * ldk + k - 1 + e] = l[e];
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   const int fl = threadIdx.x & 63, cl0 = threadIdx.x >> 6;   // 64 x 4
   const int t = t0 + fl;
   if (t < Tp) {
@@ -345,7 +376,7 @@ __global__ __launch_bounds__(256) void transpose_split_act_kernel(
 __global__ __launch_bounds__(256) void dact_transposed_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds, int C, int T, int Tp, int front, int dact,
     float scale, void* __restrict__ yh, void* __restrict__ yl, int ldyh, int fmt, float x8_mul, int* __restrict__ sat_flag,
-    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part) {
+    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part, int vec4) {
   __shared__ float tile[64][65];
   __shared__ float red[16][65];
   const int b = blockIdx.z;
@@ -386,17 +417,39 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
   }
   // transposed copy: lanes run along time (64 consecutive frames of one channel = 128 contiguous bytes per array);
   // frames in [T, Tp) are the zero gap after the utterance and are (re)written here as zeros (tile rows hold zeros there)
-  const int fl = threadIdx.x & 63, cl0 = threadIdx.x >> 6;
-  const int t = t0 + fl;
-  if (t < Tp) {
-    const long long k = (long long)front + (long long)b * Tp + t;
-    for (int ci = cl0; ci < 64; ci += 4) {
-      const int cc = c0 + ci;
-      if (cc < C) {
-        const float v = radmmm::clamp_f16(tile[fl][ci]);
-        const _Float16 h = (_Float16)v;
-        oh[(long long)cc * ldk + k] = h;
-        ol[(long long)cc * ldk + k] = (_Float16)(v - (float)h);
+  if (vec4) {
+    const int q = threadIdx.x & 15, cl0 = threadIdx.x >> 4;          // 16 frame quads x 16 channels per pass, 8-byte stores
+    const int t = t0 + 4 * q;
+    if (t < Tp) {
+      const long long k = (long long)front + (long long)b * Tp + t;
+      for (int ci = cl0; ci < 64; ci += 16) {
+        const int cc = c0 + ci;
+        if (cc < C) {
+          radmmm::f16x4_t h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = radmmm::clamp_f16(tile[4 * q + e][ci]);
+            h[e] = (_Float16)v;
+            l[e] = (_Float16)(v - (float)h[e]);
+          }
+          *reinterpret_cast<radmmm::f16x4_t*>(oh + (long long)cc * ldk + k) = h;
+          *reinterpret_cast<radmmm::f16x4_t*>(ol + (long long)cc * ldk + k) = l;
+        }
+      }
+    }
+  } else {
+    const int fl = threadIdx.x & 63, cl0 = threadIdx.x >> 6;
+    const int t = t0 + fl;
+    if (t < Tp) {
+      const long long k = (long long)front + (long long)b * Tp + t;
+      for (int ci = cl0; ci < 64; ci += 4) {
+        const int cc = c0 + ci;
+        if (cc < C) {
+          const float v = radmmm::clamp_f16(tile[fl][ci]);
+          const _Float16 h = (_Float16)v;
+          oh[(long long)cc * ldk + k] = h;
+          ol[(long long)cc * ldk + k] = (_Float16)(v - (float)h);
+        }
       }
     }
   }
@@ -416,7 +469,9 @@ static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp,
   hipLaunchKernelGGL(transpose_split_act_kernel, dim3((C + 31) / 32, ty, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ld, C, T, Tp, front, lens, mask_mode, scale,
                      static_cast<_Float16*>(oh), static_cast<_Float16*>(ol), static_cast<_Float16*>(o1h),
-                     static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil);
+                     static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil,
+                     (front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0);
   return radmmm::check_launch("transpose_split_act");
 }
 
@@ -501,6 +556,8 @@ extern "C" int radmmm_dact_mul_transposed(const float* g, int ldg, const float* 
   hipLaunchKernelGGL(dact_transposed_kernel, dim3((C + 63) / 64, (Tp + 63) / 64, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g, ldg, saved, lds, C, T, Tp, front, dact, scale, yh, yl, ldyh, fmt,
                      ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr, static_cast<_Float16*>(oh),
-                     static_cast<_Float16*>(ol), ldk, part);
+                     static_cast<_Float16*>(ol), ldk, part,
+                     (front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0);
   return radmmm::check_launch("dact_mul_transposed");
 }
