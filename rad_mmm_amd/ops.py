@@ -771,6 +771,17 @@ class GradScale:
         self._bwd_id = -1
         self._stats_fwd = -1      # forward id whose backward produced the device stats
 
+    # the state is per process and per device (a CUDA event, pinned memory): copies / pickles of the owning module start
+    # fresh (copy.deepcopy(model) for an EMA copy, torch.save(model))
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def __deepcopy__(self, memo):
+        return GradScale()
+
     # dict-like compatibility ("S")
     def get(self, k, d=None):
         return self.S if k == "S" and self.S is not None else d

@@ -25,7 +25,12 @@ class FlatRAdam:
 
     named_params: iterable of (name, Parameter) (e.g. module.named_parameters()); parameters with
     requires_grad False are ignored.  If `reducer` (a BucketedGradReducer over the same module) is
-    given its flat gradient buckets are used, otherwise gradients are gathered into own flats."""
+    given its flat gradient buckets are used, otherwise gradients are gathered into own flats.
+
+    Deliberate deviations from radam.py (both invisible when every parameter gets a gradient every step, which holds for
+    the decoder): a parameter whose .grad is None is treated as having a ZERO gradient (its moments decay and weight decay
+    applies; the reference skips it entirely, radam.py `if p.grad is None: continue`), and there is one step counter for
+    all parameters (the reference counts per parameter; load_state_dict takes the last entry's `step`)."""
 
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], lr: float = 1e-3,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,

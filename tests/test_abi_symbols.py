@@ -138,3 +138,16 @@ def test_ctypes_signatures_have_the_declared_types():
         want = [c_class(p) for p in params.split(",")]
         got = [py_class(t) for t in fn.argtypes]
         assert want == got, (name, want, got)
+
+
+def test_grad_scale_state_survives_module_copies():
+    """ops.GradScale holds a CUDA event and pinned memory once used: deep copies / pickles of the owning module must get a
+    fresh state instead of failing (EMA copies, torch.save(model))."""
+    import copy
+    import pickle
+    from rad_mmm_amd import ops
+    gs = ops.GradScale()
+    gs.S = 4.0
+    assert copy.deepcopy(gs).S is None
+    assert pickle.loads(pickle.dumps(gs)).S is None
+    assert gs.get("S") == 4.0 and gs.get("other", 7) == 7
