@@ -296,6 +296,17 @@ int radmmm_film_bwd(const float* h2, int ldh, const float* c1, int ldc, const fl
                     int ldgc, float* gx1r, int ldgx, float* gw, float* gb, float* scratch, int rows,
                     int C, int use_bn, radmmm_stream_t stream);
 int64_t radmmm_film_bwd_scratch_floats(int rows, int C);
+/* radmmm_film_bwd in two halves, for synchronised masked batch-norm statistics under data parallelism
+ * (maskedbatchnorm1d.py:88-95; MaskedBatchNorm1d.distributed_sync, tts_lightning_modules.py:238-243): _sums leaves this
+ * rank's S = [sum g_y | sum g_y xhat] ([2][C]) at scratch + ceil(rows/64)*2*C ... (radmmm_film_bwd_scratch_floats - 2*C)
+ * and copies it to gb / gw; the caller all-reduces S in place; _apply uses it with n_valid = the global frame count. */
+int radmmm_film_bwd_sums(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
+                         const float* mean, const float* invstd, const float* w, const float* b, float* gw, float* gb,
+                         float* scratch, int rows, int C, radmmm_stream_t stream);
+int radmmm_film_bwd_apply(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
+                          const float* mean, const float* invstd, const float* w, const float* b, float n_valid, int T,
+                          const int32_t* lens, float* gh2, int ldgh, float* gc1, int ldgc, float* gx1r, int ldgx,
+                          const float* scratch, int rows, int C, radmmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Alignment attention (ConvAttention.forward, common.py:1262-1277), from projected

@@ -123,6 +123,8 @@ def _load() -> C.CDLL:
         "radmmm_fused_add_tanh_sigmoid_multiply": [p, p, i, p, i, i, i, p],
         "radmmm_film_fwd": [p, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p],
         "radmmm_film_bwd": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, p, p, i, i, i, p],
+        "radmmm_film_bwd_sums": [p, i, p, i, p, i, p, p, p, p, p, p, p, i, i, p],
+        "radmmm_film_bwd_apply": [p, i, p, i, p, i, p, p, p, p, f, i, p, p, i, p, i, p, i, p, i, i, p],
         "radmmm_split_f16": [p, i, p, p, i, i, i, f, so, p],
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],

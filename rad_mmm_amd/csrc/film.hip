@@ -126,6 +126,46 @@ extern "C" int64_t radmmm_film_bwd_scratch_floats(int rows, int C) {
   return (int64_t)((rows + FR - 1) / FR) * 2 * C + 2 * C;
 }
 
+// The two halves of radmmm_film_bwd, for synchronised masked batch-norm under data parallelism
+// (maskedbatchnorm1d.py:88-95 all-reduces the statistics with an autograd-aware collective, i.e. forward AND backward):
+// _sums leaves S = [sum g_y | sum g_y xhat] of THIS rank's frames at scratch + nparts*2*C (and copies it to gb / gw: the
+// affine parameters' gradients stay local sums, DDP averages them like any other parameter gradient); the caller
+// all-reduces S in place; _apply then uses the global S with n_valid = the global frame count.
+extern "C" int radmmm_film_bwd_sums(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
+                                    const float* mean, const float* invstd, const float* w, const float* b, float* gw,
+                                    float* gb, float* scratch, int rows, int C, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(h2 && c1 && gout && scratch && mean && invstd && w && b && gw && gb, "film_bwd_sums: null pointer");
+  RADMMM_REQUIRE(rows > 0 && C > 0 && ldh >= C && ldc >= 2 * C && ldg >= C, "film_bwd_sums: bad dims");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nparts = (rows + FR - 1) / FR;
+  float* S = scratch + (long long)nparts * 2 * C;
+  hipLaunchKernelGGL(film_bwd_reduce_kernel, dim3((C + 255) / 256, nparts), dim3(256), 0, s, h2, ldh, c1, ldc, gout, ldg,
+                     mean, invstd, w, b, scratch, rows, C);
+  hipLaunchKernelGGL(film_bwd_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, scratch, nparts, C, S);
+  if (hipMemcpyAsync(gb, S, sizeof(float) * C, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(gw, S + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    radmmm::set_error("film_bwd_sums: hipMemcpyAsync failed");
+    return -2;
+  }
+  return radmmm::check_launch("film_bwd_sums");
+}
+
+extern "C" int radmmm_film_bwd_apply(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
+                                     const float* mean, const float* invstd, const float* w, const float* b,
+                                     float n_valid, int T, const int32_t* lens, float* gh2, int ldgh, float* gc1, int ldgc,
+                                     float* gx1r, int ldgx, const float* scratch, int rows, int C,
+                                     radmmm_stream_t stream) {
+  RADMMM_REQUIRE(h2 && c1 && gout && gh2 && gc1 && gx1r && scratch && mean && invstd && w && b, "film_bwd_apply: null pointer");
+  RADMMM_REQUIRE(rows > 0 && C > 0 && ldh >= C && ldc >= 2 * C && ldg >= C && ldgh >= C && ldgc >= 2 * C && ldgx >= C &&
+                     n_valid > 0 && T > 0 && rows % T == 0, "film_bwd_apply: bad dims");
+  const int nparts = (rows + FR - 1) / FR;
+  const float* S = scratch + (long long)nparts * 2 * C;
+  hipLaunchKernelGGL(film_bwd_apply_kernel, dim3(grid_for((long long)rows * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h2, ldh, c1, ldc, gout, ldg, mean, invstd, w, b, S, 1.f / n_valid, T,
+                     lens, gh2, ldgh, gc1, ldgc, gx1r, ldgx, rows, C, 1);
+  return radmmm::check_launch("film_bwd_apply");
+}
+
 extern "C" int radmmm_film_bwd(const float* h2, int ldh, const float* c1, int ldc, const float* gout, int ldg,
                                const float* mean, const float* invstd, const float* w, const float* b, float n_valid,
                                int T, const int32_t* lens, float* gh2, int ldgh, float* gc1, int ldgc, float* gx1r,

@@ -19,11 +19,16 @@ from .common import _PlainConv, _WNConv
 
 class MaskedBatchNorm1d(nn.Module):
     """Parameter/buffer holder with the reference's names; the arithmetic is fused into
-    ops_film (training-mode statistics over unmasked frames, maskedbatchnorm1d.py:77-109)."""
+    ops_film (training-mode statistics over unmasked frames, maskedbatchnorm1d.py:77-109).
+    `distributed_sync` (the reference's attribute, set by TTSModel.toggle_syncbnorm, tts_lightning_modules.py:241-243):
+    with an initialised process group the masked sums [sum x, sum x^2, n] are all-reduced in forward and the two
+    gradient sums in backward (maskedbatchnorm1d.py:88-95: an autograd-aware all_reduce), 6 KB per block each way."""
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1):
         super().__init__()
         self.eps, self.momentum = eps, momentum
+        self.distributed_sync = False
+        self.process_group = None
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
         self.register_buffer("running_mean", torch.zeros(num_features))
@@ -43,7 +48,9 @@ class FiLMPostFn(torch.autograd.Function):
 
     @staticmethod
     @amp_fwd
-    def forward(ctx, h2, c1, x1r, bn_w, bn_b, mean, invstd, lens, T, n_valid, use_bn):
+    def forward(ctx, h2, c1, x1r, bn_w, bn_b, mean, invstd, lens, T, n_valid, use_bn, sync_group=False):
+        """sync_group: False = local statistics; None or a process group = synchronised statistics (mean / invstd /
+        n_valid are then the GLOBAL ones and backward all-reduces its two gradient sums over that group)."""
         rows, C = h2.shape[0], x1r.shape[1]
         out = torch.empty(rows, C, device=h2.device, dtype=torch.float32)
         check(lib.radmmm_film_fwd(ptr(h2), h2.shape[1], ptr(c1), c1.shape[1], ptr(x1r), x1r.shape[1], ptr(mean),
@@ -52,6 +59,7 @@ class FiLMPostFn(torch.autograd.Function):
         ctx.save_for_backward(h2, c1, bn_w if use_bn else h2, bn_b if use_bn else h2, mean if use_bn else h2,
                               invstd if use_bn else h2, lens if lens is not None else h2)
         ctx.meta = (T, float(n_valid), use_bn, lens is not None, C)
+        ctx.sync_group = sync_group
         return out
 
     @staticmethod
@@ -66,14 +74,26 @@ class FiLMPostFn(torch.autograd.Function):
         gx1r = torch.empty(rows, C, device=h2.device, dtype=torch.float32)
         gw = torch.empty(C, device=h2.device) if use_bn else None
         gb = torch.empty(C, device=h2.device) if use_bn else None
-        scratch = torch.empty(int(lib.radmmm_film_bwd_scratch_floats(rows, C)), device=h2.device)
+        nscr = int(lib.radmmm_film_bwd_scratch_floats(rows, C))
+        scratch = torch.empty(nscr, device=h2.device)
+        if use_bn and ctx.sync_group is not False:
+            import torch.distributed as dist
+            check(lib.radmmm_film_bwd_sums(ptr(h2), h2.shape[1], ptr(c1), c1.shape[1], ptr(gout), gout.shape[1], ptr(mean),
+                                           ptr(invstd), ptr(bn_w), ptr(bn_b), ptr(gw), ptr(gb), ptr(scratch), rows, C,
+                                           stream()), "film_bwd_sums")
+            dist.all_reduce(scratch[nscr - 2 * C:], op=dist.ReduceOp.SUM, group=ctx.sync_group)     # S = [2][C], in place
+            check(lib.radmmm_film_bwd_apply(ptr(h2), h2.shape[1], ptr(c1), c1.shape[1], ptr(gout), gout.shape[1], ptr(mean),
+                                            ptr(invstd), ptr(bn_w), ptr(bn_b), n_valid, T, ptr(lens) if has_lens else None,
+                                            ptr(gh2), gh2.shape[1], ptr(gc1), gc1.shape[1], ptr(gx1r), C, ptr(scratch), rows,
+                                            C, stream()), "film_bwd_apply")
+            return gh2, gc1, gx1r, gw, gb, None, None, None, None, None, None, None
         check(lib.radmmm_film_bwd(ptr(h2), h2.shape[1], ptr(c1), c1.shape[1], ptr(gout), gout.shape[1],
                                   ptr(mean) if use_bn else None, ptr(invstd) if use_bn else None,
                                   ptr(bn_w) if use_bn else None, ptr(bn_b) if use_bn else None, n_valid, T,
                                   ptr(lens) if has_lens else None, ptr(gh2), gh2.shape[1], ptr(gc1), gc1.shape[1],
                                   ptr(gx1r), C, ptr(gw), ptr(gb), ptr(scratch), rows, C, 1 if use_bn else 0,
                                   stream()), "film_bwd")
-        return gh2, gc1, gx1r, gw, gb, None, None, None, None, None, None
+        return gh2, gc1, gx1r, gw, gb, None, None, None, None, None, None, None
 
 
 class FiLMResBlock(nn.Module):
@@ -97,12 +117,21 @@ class FiLMResBlock(nn.Module):
         h2 = cn(self.hidden_conv, x1r, "none")
         C = self.out_channels
         mean = invstd = None
+        sync_group = False
         if self.use_bn:
             bn = self.bn
             if self.training and n_valid > 1:
                 with torch.no_grad():
                     s1 = ops.colsum(h2, C, 1, T, lens32)
                     s2 = ops.colsum(h2, C, 1, T, lens32, square=True)
+                    if bn.distributed_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
+                        # maskedbatchnorm1d.py:88-95: [sum x, sum x^2, n] all-reduced at once; everything downstream uses
+                        # the global mean / variance / frame count
+                        sync_group = bn.process_group
+                        st = torch.stack((s1, s2, torch.full_like(s1, float(n_valid))))
+                        torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.SUM, group=sync_group)
+                        s1, s2 = st[0], st[1]
+                        n_valid = float(st[2, 0])            # one host sync per block and step (opt-in path)
                     mean = s1 / n_valid
                     var = s2 / n_valid - mean * mean
                     invstd = torch.rsqrt(var + bn.eps)
@@ -117,7 +146,7 @@ class FiLMResBlock(nn.Module):
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + bn.eps)
         return FiLMPostFn.apply(h2, c1, x1r, bn.weight if self.use_bn else None, bn.bias if self.use_bn else None,
-                                mean, invstd, lens32, T, n_valid, self.use_bn)
+                                mean, invstd, lens32, T, n_valid, self.use_bn, sync_group)
 
 
 class FiLMStack(nn.Module):
@@ -230,3 +259,12 @@ class SplineTransformationLayer(nn.Module):
         z_out = torch.cat((z1[:, :h], z1o, z1[:, 2 * h:]), 1)
         log_s = logj[:, None] + h * (math.log(self.top - self.bottom) - math.log(self.right - self.left))
         return z_out, log_s
+
+
+def toggle_syncbnorm(module: nn.Module, use_syncbnorm: bool = False, process_group=None) -> None:
+    """TTSModel.toggle_syncbnorm (tts_lightning_modules.py:241-243): switch every MaskedBatchNorm1d below `module` to
+    statistics synchronised over the process group (default group if None)."""
+    for md in module.modules():
+        if isinstance(md, MaskedBatchNorm1d):
+            md.distributed_sync = bool(use_syncbnorm)
+            md.process_group = process_group

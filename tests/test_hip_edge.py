@@ -547,3 +547,81 @@ def test_three_training_steps_follow_the_oracle_trajectory():
     for n, q in dec.named_parameters():
         d = float((q.detach().cpu() - p[n].detach()).abs().max())
         assert d <= 2e-2 * lr + 1e-6 * float(p[n].detach().abs().max()), (n, d)      # 3 steps of <= lr each; 1 % of a step
+
+
+def test_sync_masked_batchnorm_two_rank_emulation(monkeypatch):
+    """MaskedBatchNorm1d.distributed_sync (maskedbatchnorm1d.py:88-95; switched by toggle_syncbnorm as
+    tts_lightning_modules.py:241-243 does): two data-parallel ranks with synchronised statistics must reproduce the single
+    process run on the concatenated batch -- outputs per item, and parameter gradients as the rank mean.
+
+    One GPU, so the two ranks are emulated by record / replay: torch.distributed.all_reduce is replaced by a stand-in that
+    returns the cross-rank sum for every call index already resolved; each pass over both ranks resolves at least the next
+    index (its inputs only depend on earlier, resolved, collectives), forward calls first, backward calls after."""
+    import torch.distributed as dist
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.spline_layers import toggle_syncbnorm
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=False, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=3,
+              n_splines=2, use_bn=True)
+    cfg = S.DecoderConfig(**kw)
+    sd = T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    full = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(4, 64, cfg, seed=21, ragged=False).items()}
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+
+    def run(batch, sync):
+        dec = RADMMMFlow(use_accent=True, **kw)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).train()
+        toggle_syncbnorm(dec, sync)
+        sl = SequenceLength(batch["lengths"])
+        out = dec(batch["mel"], batch["spk"], batch["context"], sl, batch["f0"], batch["energy"], batch["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+        torch.cuda.synchronize()
+        return out["z_mel"].detach().clone(), {n: p.grad.detach().clone() for n, p in dec.named_parameters()}
+
+    z_full, g_full = run(full, False)
+    halves = [{k: v[:2] for k, v in full.items()}, {k: v[2:] for k, v in full.items()}]
+
+    known, state = {}, {"idx": 0, "rec": None}
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        i = state["idx"]
+        state["idx"] += 1
+        state["rec"].append(t.detach().clone())
+        if i in known:
+            t.copy_(known[i])
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    n_calls, results = None, None
+    for _ in range(80):
+        recs, results = [], []
+        for h in halves:
+            state["idx"], state["rec"] = 0, []
+            results.append(run(h, True))
+            recs.append(state["rec"])
+        n_calls = len(recs[0])
+        assert len(recs[1]) == n_calls and n_calls == 2 * 2 * 4 * 1          # 2 spline flows x 4 blocks, forward + backward
+        nxt = len(known)
+        if nxt == n_calls:
+            break
+        known[nxt] = recs[0][nxt] + recs[1][nxt]      # inputs of call `nxt` were computed from resolved collectives only
+    assert len(known) == n_calls
+    (zA, gA), (zB, gB) = results
+    assert rel_err(torch.cat((zA, zB)).cpu(), z_full.cpu()) < 2e-5
+    worst = 0.0
+    for n in g_full:
+        ref = g_full[n]
+        got = 0.5 * (gA[n] + gB[n])
+        scale = float(ref.abs().max())
+        # the per-channel scale and bias of the conv that feeds a batch-norm have an analytically ZERO gradient (the
+        # normalisation removes both): what is left is rounding residue, not comparable in relative terms
+        if scale < 1e-9 or n.endswith(("hidden_conv.conv.weight_g", "hidden_conv.conv.bias")):
+            continue
+        e = float((got - ref).abs().max()) / scale
+        worst = max(worst, e)
+        assert e < 5e-4, (n, e)
+    print(f"sync masked batch-norm, 2 emulated ranks vs concatenated batch: worst parameter-gradient rel err {worst:.2e}")
