@@ -137,6 +137,11 @@ typedef struct {
                                  2: Ah.Bh on the f16 pipe + both cross terms in ONE block-scaled FP8 MFMA per 32-deep k
                                     step: Al / Bl are then the 8-bit cross arrays RADMMM_SPLIT_X8A / RADMMM_SPLIT_X8B */
   int a8_exp, b8_exp;         /* nprod 2: exponents e the 8-bit parts of A / B were written with (values * 2^e) */
+  /* optional EXTRA K segment after the taps: one more "tap" with shift 0 whose A rows start extra_a_rows rows below row 0
+   * of Ah/Al (a second activation matrix stored behind the first in the same allocation, same lda_h) and whose weights
+   * are tap index `taps` of Bh/Bl: acc += A2 . B[taps].  Sums two GEMMs that share their output (the data gradient of a
+   * k-tap conv and of a 1x1 conv reaching the same tensor) in one launch, without the intermediate tensor. */
+  int extra_tap; int extra_a_rows;
 } radmmm_rowgemm_h3_desc;
 
 int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);

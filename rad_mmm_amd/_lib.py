@@ -73,6 +73,7 @@ class RowGemmH3Desc(C.Structure):
         ("acc_scale", C.c_float),
         ("nprod", C.c_int),
         ("a8_exp", C.c_int), ("b8_exp", C.c_int),
+        ("extra_tap", C.c_int), ("extra_a_rows", C.c_int),
     ]
 
 
@@ -217,7 +218,8 @@ def rowgemm(**kw) -> None:
     check(lib.radmmm_rowgemm_f32(C.byref(d), stream()), "radmmm_rowgemm_f32")
 
 
-_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale", "nprod", "a8_exp", "b8_exp"}
+_H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_scale", "nprod", "a8_exp", "b8_exp", "extra_tap",
+            "extra_a_rows"}
 
 
 def rowgemm_h3(**kw) -> None:

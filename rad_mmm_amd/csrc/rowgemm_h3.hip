@@ -198,8 +198,11 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   RADMMM_REQUIRE(d->nprod != 2 || (abs(d->a8_exp) <= 16 && abs(d->b8_exp) <= 16 && d->lda_h % 32 == 0 && d->ldb_h % 32 == 0 &&
                                    d->b_tap_stride_h % 32 == 0),
                  "rowgemm_h3: nprod 2 needs ld %% 32 == 0 and |x8_exp| <= 16");
-  const long long a_bytes = (long long)p.M * d->lda_h * 2;
-  const long long b_bytes = ((long long)(p.taps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
+  RADMMM_REQUIRE(!d->extra_tap || (d->extra_a_rows >= p.M && p.taps >= 1 && !p.a_mask_mode),
+                 "rowgemm_h3: the extra K segment needs extra_a_rows >= M (second matrix behind the first) and a_mask_mode 0");
+  const int ntaps = p.taps + (d->extra_tap ? 1 : 0);
+  const long long a_bytes = ((long long)p.M + (d->extra_tap ? d->extra_a_rows : 0)) * d->lda_h * 2;
+  const long long b_bytes = ((long long)(ntaps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "rowgemm_h3: operand >= 2 GiB");
   // default: the wide-tile kernel (rowgemm_h3w.hip), one workgroup per CU.  A small batch does not give it enough
   // tiles (M = 3200: 100 workgroups of its smallest 128 x 256 tile on 256 CUs): below half a round this file's
@@ -213,7 +216,7 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   }();
   const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
   // (the FP8 cross-term scheme exists on the wide kernel only)
-  const bool narrow = d->nprod != 2 && (forced == 128 || (forced != 256 && wide_wgs < 128));
+  const bool narrow = d->nprod != 2 && !d->extra_tap && (forced == 128 || (forced != 256 && wide_wgs < 128));
   if (!narrow && !(narrow_1x1 && p.taps == 1))
     return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {

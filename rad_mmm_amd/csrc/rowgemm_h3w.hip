@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   const int tm = tile / ntn, tn = tile - tm * ntn;
   const int m0 = tm * G::BMR, n0 = tn * BN;
   const int kpt = p.K / BK;
-  const int nsteps = kpt * p.taps;
+  const int ntaps = p.taps + (q.extra_tap ? 1 : 0);     // + the optional extra K segment (include/radmmm_hip.h)
+  const int nsteps = kpt * ntaps;
+  const int extra_bytes = q.extra_a_rows * q.lda_h * 2; // byte distance of the extra segment's A rows
 
   // DMA pieces of one wave per step: MB pieces of A (the 4*MB 16-row groups of {Ah, Al} dealt round
   // robin to the 4 waves) + 8 pieces of B (4 groups of Bh, 4 of Bl).  This lane's row and chunk:
@@ -274,12 +276,14 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   // per-lane A offsets of the tap being fetched, branch-free (control flow would split the pinned
   // schedule): out-of-item / masked frames get OOB.  OOB + (k offset) stays >= 2^31 = out of range.
   auto set_tap = [&](int tap) __attribute__((always_inline)) {
-    const int s = p.sign * (tap - p.taps / 2) * p.dil;
+    const bool ex = tap >= p.taps;                                 // the extra segment: no shift, rows of the second matrix
+    const int s = ex ? 0 : p.sign * (tap - p.taps / 2) * p.dil;
+    const int xb = ex ? extra_bytes : 0;
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
       const int ts = a_t[k] + s;
       const int ok = -(int)((ts >= 0) & (ts < a_lim[k]));        // all ones when the frame is readable
-      a_vo[k] = ((a_base[k] + ts * q.lda_h * 2) & ok) | (OOB & ~ok);
+      a_vo[k] = ((a_base[k] + ts * q.lda_h * 2 + xb) & ok) | (OOB & ~ok);
     }
   };
   // piece w of 0 .. NP-1 of tile (tap, kb) into stage `buf`
@@ -313,8 +317,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   // pass over all k slices pushed 10 MB through the 4 MB L2 before the next tap came back to the same rows: the A panel
   // was fetched from the Infinity Cache five times per launch (FETCH_SIZE 464 MB against 220 MB of per-XCD unique data).
   auto advance = [&]() __attribute__((always_inline)) {
-    const bool last = (l_tap == p.taps - 1) && (l_kb == kpt - 1);
-    const bool wrap = l_tap == p.taps - 1;
+    const bool last = (l_tap == ntaps - 1) && (l_kb == kpt - 1);
+    const bool wrap = l_tap == ntaps - 1;
     l_tap = last ? l_tap : (wrap ? 0 : l_tap + 1);
     l_kb = (wrap && !last) ? l_kb + 1 : l_kb;
   };

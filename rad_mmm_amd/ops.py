@@ -641,11 +641,15 @@ def split_weight(v, g, ldk, perm=(0, 0, 0), nprod=3):
     return Wh, Wl, inv
 
 
-def transpose_split(Wh, Wl, rows, cols, ld_dst, nprod=3):
+def transpose_split(Wh, Wl, rows, cols, ld_dst, nprod=3, out=None):
     """[taps][rows][ld] pair -> [taps][cols][ld_dst] (zero padded), i.e. the K-contiguous operand of the
-    data-gradient GEMM."""
+    data-gradient GEMM.  out = (Th, Tl): write into these [taps][cols][ld_dst] views (slices of a larger tap stack)."""
     taps = Wh.shape[0]
-    Th, Tl = _halves(taps, cols, ld_dst, like=Wh, zero=(ld_dst != rows))
+    if out is not None:
+        Th, Tl = out
+        assert Th.shape == (taps, cols, ld_dst) and Th.is_contiguous() and ld_dst == rows
+    else:
+        Th, Tl = _halves(taps, cols, ld_dst, like=Wh, zero=(ld_dst != rows))
     check(lib.radmmm_transpose_f16_pair(ptr(Wh), ptr(Wl), Wh.shape[2], Wh.stride(0), ptr(Th), ptr(Tl), ld_dst, Th.stride(0),
                                         taps, rows, cols, fmt_b(nprod), X8_W_EXP, stream()), "transpose_f16_pair")
     return Th, Tl
@@ -1006,11 +1010,23 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         G = None
         Gh = Gl = None
-        gQh, gQl = _halves(N, Wc, like=z_in)
+        # dL/dH_{j+1} = (k-tap data gradient of in_layer j+1) + (1x1 data gradient of res_skip j): the two GEMMs share their
+        # output, so they run as ONE launch -- the 1x1 part is an extra K segment of the k-tap GEMM (radmmm_rowgemm_h3's
+        # extra_tap) -- and dL/dH_{j+1} itself never exists in memory.  For that the split copies of g_conv_{j+1} and of
+        # gQ_j live in one [2N, Wc] pair (rows [0, N) / [N, 2N)) and the transposed weights of in_layer j+1 and res_skip j
+        # in one [taps + 1] tap stack.  RADMMM_FUSED_DGRAD=0 keeps the two-launch arrangement (A/B runs).
+        fuse = os.environ.get("RADMMM_FUSED_DGRAD", "1") != "0"
+        pair_h = pair_l = None           # [2N, Wc]: g_conv_{j+1} split in the first half, gQ_j goes into the second
+        WT_prev = None                   # (WiT stack [kt+1][Wc][Wc] of layer j+1 with its last slot free, kt, dil)
         x_prev = None
         for j in range(nl - 1, -1, -1):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
+            fused = fuse and pair_h is not None
+            if fused:
+                gQh, gQl = pair_h[N:], pair_l[N:]
+            else:
+                gQh, gQl = _halves(N, Wc, like=z_in)
             # through softplus of the res/skip branch: gQ = gOUT * act'(R_j), written as the dgrad GEMM's row-major split
             # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
             gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, "gy", gQh, gQl, fa, X8_GRAD_EXP, flag,
@@ -1020,13 +1036,20 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
-            WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
             g_conv = _empty(N, Wc, like=z_in)
-            gch, gcl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, C=g_conv, ldc=Wc, M=N,
-                       N=Wc, K=Wc, lens=lens, add=G, ldadd=Wc, dact_src=H[j + 1], lddact=Wc, dact=act,
-                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG,
-                       **gin, **gout)
+            keep_pair = fuse and j > 0               # g_conv_j's split copy becomes the first half of the next pair
+            nh, nlo = _halves(2 * N if keep_pair else N, Wc, like=z_in)
+            gch, gcl = nh[:N], nlo[:N]
+            epi = dict(C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens, dact_src=H[j + 1], lddact=Wc, dact=act,
+                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
+            if fused:
+                WTh, WTl, ktn, dn = WT_prev
+                transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
+                rowgemm_h3(Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=WTh, Bl=WTl, ldb_h=Wc, b_tap_stride_h=WTh.stride(0), taps=ktn,
+                           dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout)
+            else:
+                WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
+                rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout)
             if (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
                                                             colsum=(2 if partial else 0, lens, kt, d),
@@ -1043,14 +1066,24 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
             g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
-            WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)            # [taps][ci][co]
-            G = _empty(N, Wc, like=z_in)
-            if j == 0:
-                Gh, Gl = _halves(N, Wc, like=z_in)
-            rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
-                       C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
-                       a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
-                       ldch=Wc, ch_scale=SG, **gin, **gout)
+            if keep_pair:
+                # in_layer j's data gradient is deferred into layer j-1's fused launch: transposed weights into a tap
+                # stack with one free slot for res_skip j-1's
+                WTh, WTl = _halves(kt + 1, Wc, Wc, like=z_in)
+                transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR, out=(WTh[:kt], WTl[:kt]))
+                WT_prev = (WTh, WTl, kt, d)
+                pair_h, pair_l = nh, nlo
+                G = None
+            else:
+                WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)            # [taps][ci][co]
+                G = _empty(N, Wc, like=z_in)
+                if j == 0:
+                    Gh, Gl = _halves(N, Wc, like=z_in)
+                rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
+                           C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
+                           a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
+                           ldch=Wc, ch_scale=SG, **gin, **gout)
+                pair_h = pair_l = None
             check_saturation(box)
         perm = (h, D, 0)
         gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
