@@ -80,3 +80,43 @@ def test_f8x_gemm_layout_and_accuracy(M, N, K):
     print(f"M={M} N={N} K={K}: f8x vs its own operand model {e_model:.2e}, vs the exact product {e_exact:.2e}")
     assert e_model < 3e-6
     assert e_exact < 1e-4
+
+
+@pytest.mark.parametrize("nprod", [3, 2])
+def test_extra_k_segment_sums_two_gemms(nprod):
+    """radmmm_rowgemm_h3's extra_tap: acc = sum_taps A1[r + shift] . B[tap] + A2[r] . B[taps] in ONE launch (the data
+    gradients of a k-tap conv and of a 1x1 conv that reach the same tensor) against the two launches it replaces, with the
+    intermediate tensor passed through `add`.  Same operands, same products: only the fp32 accumulation order differs."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    B, T, Wc, taps, dil = 4, 96, 256, 5, 2
+    N = B * T
+    gen = torch.Generator().manual_seed(17 + nprod)
+    a1 = (torch.randn(N, Wc, generator=gen) * 3e-3).to(DEV)
+    a2 = (torch.randn(N, Wc, generator=gen) * 3e-3).to(DEV)
+    w1 = (torch.randn(Wc, Wc, taps, generator=gen) * 0.03).to(DEV)
+    w2 = (torch.randn(Wc, Wc, 1, generator=gen) * 0.03).to(DEV)
+    lens = torch.tensor([96, 80, 96, 57], dtype=torch.int32, device=DEV)
+    S = 2048.0
+    pair_h, pair_l = ops._halves(2 * N, Wc, like=a1)
+    for src, lo in ((a1, 0), (a2, N)):
+        h, l = ops.split_f16(src, Wc, S, Wc, nprod, ops.X8_GRAD_EXP)
+        pair_h[lo: lo + N], pair_l[lo: lo + N] = h, l
+    W1h, W1l, _ = ops.split_weight(w1, None, Wc, nprod=nprod)            # [taps][co][ci]: used as [tap][n][k] directly
+    W2h, W2l, _ = ops.split_weight(w2, None, Wc, nprod=nprod)
+    stack_h, stack_l = ops._halves(taps + 1, Wc, Wc, like=a1)
+    stack_h[:taps], stack_l[:taps], stack_h[taps:], stack_l[taps:] = W1h, W1l, W2h, W2l
+    common = dict(nprod=nprod, a8_exp=ops.X8_GRAD_EXP, b8_exp=ops.X8_W_EXP, acc_scale=1.0 / (S * ops.W_SCALE), ldc=Wc, M=N,
+                  N=Wc, K=Wc, T=T, lens=lens, lda_h=Wc, ldb_h=Wc)
+    # two launches: k-tap part -> G, then the 1x1 part with add = G
+    G = torch.empty(N, Wc, device=DEV)
+    rowgemm_h3(Ah=pair_h[:N], Al=pair_l[:N], Bh=W1h, Bl=W1l, b_tap_stride_h=W1h.stride(0), C=G, taps=taps, dil=dil, sign=-1,
+               a_mask_mode=0, **common)
+    ref = torch.empty(N, Wc, device=DEV)
+    rowgemm_h3(Ah=pair_h[N:], Al=pair_l[N:], Bh=W2h, Bl=W2l, C=ref, add=G, ldadd=Wc, rowscale=1, **common)
+    # one launch
+    got = torch.full((N, Wc), float("nan"), device=DEV)
+    rowgemm_h3(Ah=pair_h, Al=pair_l, Bh=stack_h, Bl=stack_l, b_tap_stride_h=stack_h.stride(0), C=got, taps=taps, dil=dil,
+               sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, rowscale=1, **common)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-6
+    assert float(got.abs().max()) > 0
