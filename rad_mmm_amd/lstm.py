@@ -8,9 +8,11 @@ the T' sequential recurrent steps run as one fused HIP launch per step for both 
 bias_hh_l0 and their _reverse twins), same output: y [B, T, 2H] with zeros at frames >= length."""
 from __future__ import annotations
 
+import os
+
 import torch
 
-from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd
+from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd, rowgemm_h3
 
 
 def _scratch(B, H, which, like):
@@ -30,7 +32,20 @@ class BiLSTMFn(torch.autograd.Function):
         x2 = x.reshape(B * T, I).contiguous()
         W_ih = torch.cat((w_ih_f, w_ih_r), 0)                    # [8H, I]
         bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r))     # [8H]
-        G = torch.addmm(bias, x2, W_ih.t())                      # [B*T, 8H]
+        if (8 * H) % 4 == 0 and B * T >= 4096 and os.environ.get("RADMMM_LSTM_PROJ", "hip") != "torch":
+            # frame-rate inputs: the input projection on the split-f16 row GEMM (three f16 products, 2e-6): 114 GFLOP at
+            # the benchmark size in ~0.4 ms instead of 0.91 ms on the fp32 library GEMM; W_ih [8H, I] is already the
+            # K-contiguous B operand.  (The projection's GRADIENT GEMMs stay on the library: moving them too was measured
+            # twice and did not pay)
+            from . import ops
+            Kp = ops.round_up(I, 32)
+            xh, xl = ops.split_f16(x2, I, 1.0, Kp)
+            Wh, Wl = ops.split_f16(W_ih, I, ops.W_SCALE, Kp)
+            G = torch.empty(B * T, 8 * H, device=x.device, dtype=torch.float32)
+            rowgemm_h3(nprod=3, Ah=xh, Al=xl, lda_h=Kp, Bh=Wh, Bl=Wl, ldb_h=Kp, acc_scale=1.0 / ops.W_SCALE, C=G, ldc=8 * H,
+                       M=B * T, N=8 * H, K=Kp, T=T, bias=bias)
+        else:
+            G = torch.addmm(bias, x2, W_ih.t())                  # [B*T, 8H]
         W_hh = torch.stack((w_hh_f, w_hh_r)).contiguous()        # [2, 4H, H]
         y = torch.empty(B * T, 2 * H, device=x.device, dtype=torch.float32)
         c = torch.empty(B * T, 2 * H, device=x.device, dtype=torch.float32)
