@@ -218,6 +218,15 @@ def test_mel_filterbank_selfcheck():
     # Slaney scale is linear below 1 kHz: first centres are 200/3 Hz-mel apart
     mel_pts = O._mel_to_hz_slaney(np.linspace(O._hz_to_mel_slaney(0.0), O._hz_to_mel_slaney(8000.0), 82))
     assert abs((mel_pts[2] - mel_pts[1]) - (mel_pts[1] - mel_pts[0])) < 1e-6
+    # The one PUBLISHED value available offline: the example in librosa.filters.mel's docstring (0.8.x),
+    # `melfb = librosa.filters.mel(22050, 2048)` -> `array([[ 0.   ,  0.016, ...,  0.   ,  0.   ], ...` (128 mels, fmax = sr/2,
+    # Slaney scale and norm), i.e. melfb[0, 0] = 0.000 and melfb[0, 1] = 0.016 to the three decimals printed there.  A
+    # weak pin (two rounded entries) -- the basis stays "parity unpinned" in DESIGN.md -- but it does tie the restated
+    # scale, the triangle construction and the Slaney area normalisation to librosa's own numbers.
+    doc = O.mel_filterbank_slaney(22050, 2048, 128, 0.0, None)
+    assert doc.shape == (128, 1025)
+    assert round(float(doc[0, 0]), 3) == 0.0 and round(float(doc[0, 1]), 3) == 0.016
+    assert float(doc[-1, -1]) == 0.0 and float(doc[1, 0]) == 0.0
 
 
 @pytest.mark.parametrize("tag,n_flows,n_splines", [("cfg1", 2, 0), ("cfg2_small", 8, 0),
