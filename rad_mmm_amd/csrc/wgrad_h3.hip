@@ -13,6 +13,7 @@
 // Kernel = the NT split-f16 GEMM of h3_gemm.hip (128x128x32 tile, 3 MFMA per product block)
 // plus a scalar column offset on the B operand and split-K slabs.
 #include <math.h>
+#include <cstdlib>
 
 #include "common.h"
 #include "split_pack.h"
@@ -366,6 +367,77 @@ __global__ __launch_bounds__(256) void transpose_split_act_kernel(
   }
 }
 
+// The same pass on 64-frame x 64-channel tiles with 16-byte loads (256 contiguous bytes per frame row instead of 128)
+// and 8-byte transposed stores: the shape every flow-step call has (C % 4 == 0, front / Tp / ldk multiples of 4).
+// 105 MB of traffic per call at the benchmark size; measured against the 32-channel kernel above in DESIGN.md §4.6.
+__global__ __launch_bounds__(256) void transpose_split_act64_kernel(
+    const float* __restrict__ x, int ld, int C, int T, int Tp, int front, const int* __restrict__ lens, int mask_mode,
+    float scale, _Float16* __restrict__ oh, _Float16* __restrict__ ol, _Float16* __restrict__ o1h,
+    _Float16* __restrict__ o1l, int ldk, float* __restrict__ part, int sum_weight, int sum_taps, int sum_dil) {
+  __shared__ float tile[64][65];
+  __shared__ float red[16][65];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int len = (mask_mode && lens) ? lens[b] : T;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 float4 columns x 16 rows per pass
+  const int c = c0 + tx * 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tl = i * 16 + ty, t = t0 + tl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T && c < C) {                                       // C % 4 == 0: whole groups of 4 columns
+      v = *reinterpret_cast<const float4*>(x + ((long long)b * T + t) * ld + c);
+      if (part) {
+        const float w = radmmm::colsum_row_weight(b * T + t, sum_weight, T, lens, sum_taps, sum_dil);
+        s0 = fmaf(w, v.x, s0); s1 = fmaf(w, v.y, s1); s2 = fmaf(w, v.z, s2); s3 = fmaf(w, v.w, s3);
+      }
+    }
+    const float m = t < len ? scale : 0.f;                      // 0 in gap / masked frames
+    tile[tl][tx * 4 + 0] = v.x * m;
+    tile[tl][tx * 4 + 1] = v.y * m;
+    tile[tl][tx * 4 + 2] = v.z * m;
+    tile[tl][tx * 4 + 3] = v.w * m;
+  }
+  if (part) {
+    red[ty][tx * 4 + 0] = s0; red[ty][tx * 4 + 1] = s1; red[ty][tx * 4 + 2] = s2; red[ty][tx * 4 + 3] = s3;
+  }
+  __syncthreads();
+  if (part && threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    float t16 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t16 += red[w][threadIdx.x];
+    part[((long long)b * gridDim.y + blockIdx.y) * C + c0 + threadIdx.x] = t16;
+  }
+  const int q = threadIdx.x & 15, cl0 = threadIdx.x >> 4;      // 16 frame quads x 16 channels per pass
+  const int t = t0 + 4 * q;
+  if (t < Tp) {                                                 // Tp % 4 == 0: whole quads
+    const long long k = (long long)front + (long long)b * Tp + t;
+#pragma unroll
+    for (int ci = cl0; ci < 64; ci += 16) {
+      const int cc = c0 + ci;
+      if (cc < C) {
+        radmmm::f16x4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = radmmm::clamp_f16(tile[4 * q + e][ci]);
+          h[e] = (_Float16)v;
+          l[e] = (_Float16)(v - (float)h[e]);
+        }
+        *reinterpret_cast<radmmm::f16x4_t*>(oh + (long long)cc * ldk + k) = h;
+        *reinterpret_cast<radmmm::f16x4_t*>(ol + (long long)cc * ldk + k) = l;
+        if (o1h) {                                   // advanced by one column: X1[k-1] = X[k] (2-byte aligned only)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o1h[(long long)cc * ldk + k - 1 + e] = h[e];
+            o1l[(long long)cc * ldk + k - 1 + e] = l[e];
+          }
+        }
+      }
+    }
+  }
+}
+
 // y = g * act'(saved) (the step from dL/d(act output) to dL/d(conv accumulator), radmmm_dact_mul without row weights)
 // written THREE ways in one pass over g and saved, with no fp32 copy of y: (1) the row-major split pair that feeds the
 // data-gradient GEMM (any split format, saturation flag), (2) the transposed zero-gapped split-f16 pair that feeds the
@@ -466,12 +538,20 @@ static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp,
                  "transpose_split_act: bad dims");
   // the output must be pre-zeroed by the caller (front columns, row tails); gaps are written here
   const int ty = (Tp + 63) / 64;
+  const bool vec_out = front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(ol) & 7) == 0;
+  static const bool narrow = getenv("RADMMM_TRANSPOSE32") != nullptr;       // A/B switch: the 32-channel kernel
+  if (vec_out && !narrow && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    hipLaunchKernelGGL(transpose_split_act64_kernel, dim3((C + 63) / 64, ty, B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ld, C, T, Tp, front, lens, mask_mode, scale,
+                       static_cast<_Float16*>(oh), static_cast<_Float16*>(ol), static_cast<_Float16*>(o1h),
+                       static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil);
+    return radmmm::check_launch("transpose_split_act");
+  }
   hipLaunchKernelGGL(transpose_split_act_kernel, dim3((C + 31) / 32, ty, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ld, C, T, Tp, front, lens, mask_mode, scale,
                      static_cast<_Float16*>(oh), static_cast<_Float16*>(ol), static_cast<_Float16*>(o1h),
-                     static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil,
-                     (front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0);
+                     static_cast<_Float16*>(o1l), ldk, part, sum_weight, sum_taps, sum_dil, vec_out ? 1 : 0);
   return radmmm::check_launch("transpose_split_act");
 }
 
