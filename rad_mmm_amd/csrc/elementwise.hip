@@ -143,6 +143,55 @@ __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
   }
 }
 
+// the same assembly, four columns per thread (16-byte loads / stores): D, ldctx, ldz, ldx0 multiples of 4 and 16-byte
+// aligned bases -- every shape of the shipped configs; h is arbitrary (79, 78, 77 after the early exits): the last
+// group of the z part goes element by element
+__global__ __launch_bounds__(256) void wn_input_fwd4_kernel(
+    const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz, float* __restrict__ X0, int ldx0,
+    int rows, int D, int h, _Float16* __restrict__ Xh, _Float16* __restrict__ Xl, int fmt, float x8_mul) {
+  const int q = ldx0 >> 2;
+  const long long total = (long long)rows * q;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / q), c = (int)(i - (long long)r * q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) v = *reinterpret_cast<const float4*>(ctx + (long long)r * ldctx + c);
+    else if (c + 3 < D + h) v = *reinterpret_cast<const float4*>(z + (long long)r * ldz + (c - D));
+    else if (c < D + h) {
+      const float* zp = z + (long long)r * ldz + (c - D);
+      v.x = zp[0];
+      if (c + 1 < D + h) v.y = zp[1];
+      if (c + 2 < D + h) v.z = zp[2];
+    }
+    *reinterpret_cast<float4*>(X0 + (long long)r * ldx0 + c) = v;
+    if (Xh) radmmm::store_split4_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v.x, v.y, v.z, v.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_input_bwd4_kernel(
+    const float* __restrict__ gX0, int ldx0, float* __restrict__ gctx, int ldctx, int ctx_accum,
+    float* __restrict__ gz, int ldz, int rows, int D, int h) {
+  const int q = (D + h + 3) >> 2;
+  const long long total = (long long)rows * q;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / q), c = (int)(i - (long long)r * q) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(gX0 + (long long)r * ldx0 + c);     // ldx0 >= round_up(D + h, 4)
+    if (c >= D && c + 3 >= D + h) {                                                       // ragged end of the z part
+      float* zp = gz + (long long)r * ldz + (c - D);
+      zp[0] += v.x;
+      if (c + 1 < D + h) zp[1] += v.y;
+      if (c + 2 < D + h) zp[2] += v.z;
+      continue;
+    }
+    float4* p = reinterpret_cast<float4*>(c < D ? gctx + (long long)r * ldctx + c : gz + (long long)r * ldz + (c - D));
+    float4 o = v;
+    if (c >= D || ctx_accum) {
+      const float4 t = *p;
+      o = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w);
+    }
+    *p = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void wn_input_bwd_kernel(
     const float* __restrict__ gX0, int ldx0, float* __restrict__ gctx, int ldctx, int ctx_accum,
     float* __restrict__ gz, int ldz, int rows, int D, int h) {
@@ -491,6 +540,15 @@ extern "C" int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, 
   RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_fwd: bad dims");
   const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
   RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || !Xh || (ldx0 % 32 == 0 && abs(so->x8_exp) <= 16), "wn_input_fwd: 8-bit format needs ldx0 %% 32 == 0");
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  auto a8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+  if (D % 4 == 0 && ldctx % 4 == 0 && ldz % 4 == 0 && ldx0 % 4 == 0 && a16(ctx) && a16(z) && a16(X0) &&
+      a8(Xh) && a8(Xl)) {
+    hipLaunchKernelGGL(wn_input_fwd4_kernel, dim3(grid_for((long long)rows * (ldx0 / 4))), dim3(256), 0, ST(stream), ctx,
+                       ldctx, z, ldz, X0, ldx0, rows, D, h, static_cast<_Float16*>(Xh), static_cast<_Float16*>(Xl), fmt,
+                       ldexpf(1.f, so ? so->x8_exp : 0));
+    return radmmm::check_launch("wn_input_fwd");
+  }
   hipLaunchKernelGGL(wn_input_fwd_kernel, dim3(grid_for((long long)rows * ldx0)), dim3(256), 0,
                      ST(stream), ctx, ldctx, z, ldz, X0, ldx0, rows, D, h, static_cast<_Float16*>(Xh),
                      static_cast<_Float16*>(Xl), fmt, ldexpf(1.f, so ? so->x8_exp : 0));
@@ -502,6 +560,13 @@ extern "C" int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int 
                                    radmmm_stream_t stream) {
   RADMMM_REQUIRE(gX0 && gctx && gz, "wn_input_bwd: null pointer");
   RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_bwd: bad dims");
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (D % 4 == 0 && ldctx % 4 == 0 && ldz % 4 == 0 && ldx0 % 4 == 0 && ldx0 >= (D + h + 3) / 4 * 4 && a16(gX0) && a16(gctx) &&
+      a16(gz)) {
+    hipLaunchKernelGGL(wn_input_bwd4_kernel, dim3(grid_for((long long)rows * ((D + h + 3) / 4))), dim3(256), 0, ST(stream), gX0,
+                       ldx0, gctx, ldctx, ctx_accum, gz, ldz, rows, D, h);
+    return radmmm::check_launch("wn_input_bwd");
+  }
   hipLaunchKernelGGL(wn_input_bwd_kernel, dim3(grid_for((long long)rows * (D + h))), dim3(256), 0,
                      ST(stream), gX0, ldx0, gctx, ldctx, ctx_accum, gz, ldz, rows, D, h);
   return radmmm::check_launch("wn_input_bwd");
