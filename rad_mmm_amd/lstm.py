@@ -26,8 +26,9 @@ class BiLSTMFn(torch.autograd.Function):
 
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, box=None):
         B, T, I = x.shape
+        ctx.box = box
         H = w_hh_f.shape[1]
         x2 = x.reshape(B * T, I).contiguous()
         W_ih = torch.cat((w_ih_f, w_ih_r), 0)                    # [8H, I]
@@ -77,22 +78,60 @@ class BiLSTMFn(torch.autograd.Function):
         check(lib.radmmm_lstm_bwd(ptr(G), ptr(c), ptr(dy2), ptr(W_hh), ptr(lens), ptr(wtpack), ptr(P), ptr(dcbuf), B, T, H,
                                   ptr(gscale), stream()), "lstm_bwd")
         dG = G                                                   # now the pre-activation gradients
-        dx = (dG @ W_ih).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dW_ih = dG.t() @ x2                                      # [8H, I]
-        db = dG.sum(0)
         y3 = y.view(B, T, 2 * H)
         hp = torch.zeros(B, T, 2 * H, device=dy.device, dtype=torch.float32)
         hp[:, 1:, :H] = y3[:, :-1, :H]                           # forward direction: h_{t-1}
         hp[:, :-1, H:] = y3[:, 1:, H:]                           # reverse direction: h_{t+1}
         hp = hp.view(B * T, 2 * H)
-        dW_hh_f = dG[:, :4 * H].t() @ hp[:, :H]
-        dW_hh_r = dG[:, 4 * H:].t() @ hp[:, H:]
-        return (dx, None, dW_ih[:4 * H], dW_hh_f, db[:4 * H], db[:4 * H], dW_ih[4 * H:], dW_hh_r, db[4 * H:], db[4 * H:])
+        if (ctx.box is not None and B * T >= 4096 and (8 * H) % 32 == 0 and I % 4 == 0 and H % 2 == 0 and
+                os.environ.get("RADMMM_LSTM_GRADS", "hip") != "torch"):
+            # frame-rate batches: the four gradient GEMMs (226 + 57 GFLOP at the benchmark size, 2.5 ms on the fp32 library
+            # GEMMs) on the split-f16 kernels: ONE transposing pass over dG feeds both weight gradients (contraction over
+            # frames) and yields the bias gradient as its column sums; the input gradient is a row GEMM on dG's split copy.
+            # Scale of the split gradient tensors: the module's GradScale (previous pass's amax, no host sync).
+            from . import ops
+            box = ctx.box
+            SG = ops.grad_scale(box, dy2)
+            flag = ops.sat_flag_of(box)
+            gy_t, db = ops.transpose_split_act(dG, 8 * H, B, T, None, 0, SG, "lstm_gy", colsum=(0, None, 1, 1))
+            x_t = ops.transpose_split_act(x2, I, B, T, None, 0, 1.0, "lstm_x")
+            hp_t = ops.transpose_split_act(hp, 2 * H, B, T, None, 0, 1.0, "lstm_h")
+            dW_ih = ops.wgrad_h3_slabs(gy_t, x_t, 8 * H, I, I, 1, 1, 1.0 / SG, 3).sum(0)[0]
+            rows = lambda tt, a, b: (tt[0][a:b], tt[1][a:b], None, None, tt[4])
+            dW_hh_f = ops.wgrad_h3_slabs(rows(gy_t, 0, 4 * H), rows(hp_t, 0, H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
+            dW_hh_r = ops.wgrad_h3_slabs(rows(gy_t, 4 * H, 8 * H), rows(hp_t, H, 2 * H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
+            dx = None
+            if ctx.needs_input_grad[0]:
+                gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)
+                Wt = W_ih.t().contiguous()                       # [I, 8H]: the K-contiguous operand of dx = dG W_ih
+                Wth, Wtl = ops.split_f16(Wt, 8 * H, ops.W_SCALE, 8 * H)
+                dx = torch.empty(B * T, I, device=dy.device, dtype=torch.float32)
+                rowgemm_h3(nprod=3, Ah=gh, Al=gl, lda_h=8 * H, Bh=Wth, Bl=Wtl, ldb_h=8 * H, acc_scale=1.0 / (SG * ops.W_SCALE),
+                           C=dx, ldc=I, M=B * T, N=I, K=8 * H, T=T)
+                dx = dx.view(B, T, I)
+            ops.check_saturation(box)
+        else:
+            dx = (dG @ W_ih).view(B, T, I) if ctx.needs_input_grad[0] else None
+            dW_ih = dG.t() @ x2                                  # [8H, I]
+            db = dG.sum(0)
+            dW_hh_f = dG[:, :4 * H].t() @ hp[:, :H]
+            dW_hh_r = dG[:, 4 * H:].t() @ hp[:, H:]
+        return (dx, None, dW_ih[:4 * H], dW_hh_f, db[:4 * H], db[:4 * H], dW_ih[4 * H:], dW_hh_r, db[4 * H:], db[4 * H:],
+                None)
 
 
 def bilstm(lstm: torch.nn.LSTM, x: torch.Tensor, lens32) -> torch.Tensor:
     """Apply `lstm`'s parameters (single layer, bidirectional, batch_first) with the HIP recurrence."""
     assert lstm.num_layers == 1 and lstm.bidirectional and lstm.batch_first and lstm.proj_size == 0
+    box = None
+    if x.is_cuda and torch.is_grad_enabled():
+        # scale state of the split gradient tensors (ops.GradScale): one per LSTM module, carried from pass to pass
+        from . import ops
+        box = lstm.__dict__.get("_radmmm_grad_scale")
+        if box is None:
+            box = ops.GradScale()
+            lstm.__dict__["_radmmm_grad_scale"] = box
+        box.new_forward(x.device)
     return BiLSTMFn.apply(x, lens32, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                           lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
-                          lstm.bias_hh_l0_reverse)
+                          lstm.bias_hh_l0_reverse, box)

@@ -21,7 +21,9 @@ def _ref(lstm, x, lens):
 
 
 @pytest.mark.parametrize("B,T,I,H,lens", [(3, 7, 12, 8, None), (5, 19, 40, 21, [19, 7, 1, 12, 19]),
-                                          (32, 50, 96, 524, None), (34, 23, 30, 70, [23] * 20 + [5] * 14)])
+                                          (32, 50, 96, 524, None), (34, 23, 30, 70, [23] * 20 + [5] * 14),
+                                          # B*T >= 4096: the gradient GEMMs run on the split-f16 kernels (lstm.py)
+                                          (16, 256, 64, 36, None), (18, 230, 52, 40, [230] * 9 + [100, 64, 7] * 3)])
 @pytest.mark.parametrize("persistent", ["0", "1"])
 def test_bilstm_matches_torch(B, T, I, H, lens, persistent, monkeypatch):
     """persistent=1: the opt-in one-launch recurrence (grid barrier, sc1 exchange; csrc/lstm.hip)."""
