@@ -36,8 +36,7 @@ class BiLSTMFn(torch.autograd.Function):
         if (8 * H) % 4 == 0 and B * T >= 4096 and os.environ.get("RADMMM_LSTM_PROJ", "hip") != "torch":
             # frame-rate inputs: the input projection on the split-f16 row GEMM (three f16 products, 2e-6): 114 GFLOP at
             # the benchmark size in ~0.4 ms instead of 0.91 ms on the fp32 library GEMM; W_ih [8H, I] is already the
-            # K-contiguous B operand.  (The projection's GRADIENT GEMMs stay on the library: moving them too was measured
-            # twice and did not pay)
+            # K-contiguous B operand.  (Its gradient GEMMs: BiLSTMFn.backward.)
             from . import ops
             Kp = ops.round_up(I, 32)
             xh, xl = ops.split_f16(x2, I, 1.0, Kp)
