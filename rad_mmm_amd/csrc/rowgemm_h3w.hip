@@ -479,7 +479,12 @@ int pick_h3w_mb(int M, int N, int slots) {
   const int ntn = (N + BN - 1) / BN;
   int best = 4;
   double best_cost = 1e300;
-  for (int mb = 4; mb <= 7; ++mb) {   // MB = 8 compiles with spills; kept for experiments via RADMMM_H3W_MB
+  // MB = 8 (256-row tiles, 20-36 bytes of scratch per lane) costs what this model says it should on the shape it was
+  // measured on (12 800 x 1024: 405 us against 380 us at MB = 7, model 8.77 : 8.22) and is taken where it saves a round
+  // of workgroups: N = 1152 (the start conv's data gradient) and N = 1052 (the LSTM's input gradient) fit 50 x 5 = 250
+  // workgroups into ONE round instead of 290-500 in two.  RADMMM_H3W_MB8=0: candidates 4..7 only (A/B runs).
+  static const int mb_max = (getenv("RADMMM_H3W_MB8") && atoi(getenv("RADMMM_H3W_MB8")) == 0) ? 7 : 8;
+  for (int mb = 4; mb <= mb_max; ++mb) {
     const long long wg = (long long)((M + 32 * mb - 1) / (32 * mb)) * ntn;
     const long long full = wg / slots, tail = wg % slots;
     const double rounds = (double)full + (tail ? 0.65 + 0.35 * (double)tail / slots : 0.0);
