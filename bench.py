@@ -8,8 +8,10 @@ fixed-length batches, B=32 per GPU, 80 mel, T=800 (BASELINE.json configs[1]).
 
 One process per GPU; N > 1 adds the bucketed RCCL gradient all-reduce overlapped with
 backward (rad_mmm_amd/ddp.py).  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     dominant kernel (dilated k=5 1024->1024 conv GEMM, fp32 MFMA) timed live with
-               HIP events on the launch stream: algorithmic FLOP per launch / avg duration
+  roofline     dominant kernel (dilated k=5 1024->1024 conv GEMM on the split-operand path: f16 hi.hi product + FP8
+               cross terms by default) timed live with HIP events on the launch stream: algorithmic FLOP per launch /
+               avg duration against the dense f16 MFMA peak; traffic from profiles/pmc_dominant.json (static)
+  exact_split_mode / throughput_mode   the same step with three f16 products / one f16 product (medians of 5 steps)
   wn_stack     the north_star's derived view: algorithmic fp32 bytes of the WN stack / step time
   cpu_baseline the CPU oracle (a port of the reference's arithmetic) timed on the host cores
                on a bounded sample of the same workload (rank 0, N=1 only)
