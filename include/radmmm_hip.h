@@ -374,6 +374,10 @@ int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, 
  * per process) when data-parallel runs leave CUs to RCCL's channel kernels (Lightning `strategy: ddp`,
  * configs/RADMMM_train_config.yaml:28; rad_mmm_amd/ddp.py reserve_collective_cus). */
 int radmmm_gemm_cu_slots(void);
+/* A HIP stream whose kernels may use only `enabled_cus` of the device's CUs (hipExtStreamCreateWithCUMask); *out receives
+ * the hipStream_t (wrap it, e.g. torch.cuda.ExternalStream).  radmmm_stream_destroy releases it. */
+int radmmm_stream_create_masked(int enabled_cus, void** out);
+int radmmm_stream_destroy(void* stream);
 
 /* Weight gradient on the split-f16 path.  Operands are transposed, time-contiguous, zero-gapped
  * split copies made by radmmm_transpose_split_act from channels-last fp32 [B*T][ld]:

@@ -143,6 +143,8 @@ def _load() -> C.CDLL:
         "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
+        "radmmm_stream_create_masked": [i, C.POINTER(C.c_void_p)],
+        "radmmm_stream_destroy": [p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, so, p],

@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gemms", type=int, default=12, help="in_layer weight-gradient launches (5 taps) per trial")
     ap.add_argument("--priority", type=int, default=0, help="-1: LSTM stream high priority")
+    ap.add_argument("--gemm-cus", type=int, default=0, help="> 0: the GEMM stream may use only this many CUs "
+                                                             "(radmmm_stream_create_masked = hipExtStreamCreateWithCUMask)")
     args = ap.parse_args()
     import rad_mmm_amd  # noqa: F401
     from rad_mmm_amd import ops
@@ -34,6 +36,12 @@ def main():
     xa = torch.randn(B * T, 1024, generator=g).to(dev)
     s_l = torch.cuda.Stream(priority=args.priority)
     s_g = torch.cuda.Stream()
+    if args.gemm_cus > 0:
+        import ctypes
+        from rad_mmm_amd._lib import lib, check
+        raw = ctypes.c_void_p()
+        check(lib.radmmm_stream_create_masked(args.gemm_cus, ctypes.byref(raw)), "stream_create_masked")
+        s_g = torch.cuda.ExternalStream(raw.value)
 
     def run_lstm():
         with torch.cuda.stream(s_l):
@@ -62,7 +70,7 @@ def main():
            "gemms_alone_ms": min(timed(run_gemms) for _ in range(3)),
            "both_gemms_first_ms": min(timed(run_gemms, run_lstm) for _ in range(3)),
            "both_lstm_first_ms": min(timed(run_lstm, run_gemms) for _ in range(3)), "gemms": args.gemms,
-           "lstm_priority": args.priority}
+           "lstm_priority": args.priority, "gemm_cus": args.gemm_cus}
     print(json.dumps(res))
 
 
