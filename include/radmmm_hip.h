@@ -416,6 +416,17 @@ int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void
                     int Nc, int taps, int dil, int splits, float acc_scale, int nprod /* 3 or 1, as radmmm_rowgemm_h3_desc */,
                     radmmm_stream_t stream);
 
+/* The same weight gradient on ROW-MAJOR split operands (csrc/wgrad_rm.hip): GYh/GYl [R][ldg] and Xh/Xl [R][ldx] are the
+ * [frames][channels] fp16 hi/lo pairs the GEMM epilogues write (R = B*T rows, utterance-major), contracted over the frames
+ * with the transposition done in the LDS read; no transposed copies.
+ *   P[split][tap][m][n] = acc_scale * sum_f GY[f][m] * X[f + s][n],  s = (tap - taps/2)*dil, for f + s in f's utterance.
+ * No length mask (operands must be zero where the reference masks them).  ldg, ldx %% 8 == 0, 16-byte aligned operands,
+ * T >= 32 unless taps == 1; ldp >= Nc; slabs `split_stride` floats apart; radmmm_wgrad_rm_tiles as radmmm_wgrad_h3_tiles. */
+int radmmm_wgrad_rm_tiles(int Mc, int Nc, int taps);
+int radmmm_wgrad_rm(const void* GYh, const void* GYl, int ldg, const void* Xh, const void* Xl, int ldx, int R, int T,
+                    float* P, int ldp, int64_t split_stride, int Mc, int Nc, int taps, int dil, int splits,
+                    float acc_scale, radmmm_stream_t stream);
+
 /* Bidirectional single-layer LSTM, recurrent part (reference: the decoder's context LSTM,
  * models/radmmm.py:141-146 = torch.nn.LSTM(bidirectional, batch_first) on a packed batch; gate order
  * i, f, g, o; frames t >= lens[b] produce h = c = 0 as pad_packed_sequence does).

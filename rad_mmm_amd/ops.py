@@ -751,6 +751,21 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     return P
 
 
+def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale):
+    """Weight gradient from ROW-major split pairs (hi, lo fp16 [B*T, ld]) -> P [S, taps, Mc, Nc] fp32 slabs
+    (radmmm_wgrad_rm: contraction over the frames, transposition in the LDS read, no transposed copies)."""
+    gh, gl = gy_pair
+    xh, xl = x_pair
+    R = B * T
+    assert gh.shape[0] >= R and xh.shape[0] >= R and gh.dtype == torch.float16 and xl.dtype == torch.float16
+    tiles = int(lib.radmmm_wgrad_rm_tiles(Mc, Nc, taps))
+    S = pick_splits(tiles, R, slots=int(lib.radmmm_gemm_cu_slots()))              # one workgroup per CU
+    P = torch.empty(S, taps, Mc, Nc, device=gh.device, dtype=torch.float32)
+    check(lib.radmmm_wgrad_rm(ptr(gh), ptr(gl), gh.shape[1], ptr(xh), ptr(xl), xh.shape[1], R, T, ptr(P), Nc, P.stride(0), Mc, Nc,
+                              taps, dil, S, acc_scale, stream()), "wgrad_rm")
+    return P
+
+
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
     a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), a device-side

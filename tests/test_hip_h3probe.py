@@ -120,3 +120,37 @@ def test_extra_k_segment_sums_two_gemms(nprod):
                sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, rowscale=1, **common)
     assert rel_err(got.cpu(), ref.cpu()) < 2e-6
     assert float(got.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,Mc,Nc,taps,dil", [(5, 50, 256, 256, 3, 2), (3, 97, 320, 288, 5, 1), (4, 64, 160, 1152, 1, 1),
+                                                 (2, 400, 1024, 1024, 5, 8)])
+def test_wgrad_rm_matches_the_transposed_path(B, T, Mc, Nc, taps, dil):
+    """radmmm_wgrad_rm (row-major split operands, transposition in the LDS read) against radmmm_wgrad_h3 on transposed
+    zero-gapped copies of the same tensors: same three f16 products of the same hi/lo values, fp32 accumulation in a
+    different order -> agreement to fp32 rounding of the sums; and against a float64 convolution-style reference with
+    utterance boundaries (no cross-utterance products), partial tiles and odd shifts."""
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    gy = (torch.randn(B * T, Mc, generator=g) * 0.3).to(DEV)
+    x = torch.nn.functional.softplus(torch.randn(B * T, Nc, generator=g)).to(DEV)
+    SG = 4.0
+    ldg, ldx = ops.round_up(Mc, 8), ops.round_up(Nc, 8)
+    gh, gl = ops.split_f16(gy, Mc, SG, ldg)
+    xh, xl = ops.split_f16(x, Nc, 1.0, ldx)
+    P = ops.wgrad_rm_slabs((gh, gl), (xh, xl), B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)      # [taps, Mc, Nc]
+    # float64 reference from the split values
+    gv = (gh.double() + gl.double())[:, :Mc].view(B, T, Mc) / SG
+    xv = (xh.double() + xl.double())[:, :Nc].view(B, T, Nc)
+    ref = torch.zeros(taps, Mc, Nc, dtype=torch.float64, device=DEV)
+    for tp in range(taps):
+        s = (tp - taps // 2) * dil
+        lo, hi = max(0, -s), min(T, T - s)
+        if hi > lo:
+            ref[tp] = torch.einsum("btm,btn->mn", gv[:, lo:hi], xv[:, lo + s:hi + s])
+    assert rel_err(P.double().cpu(), ref.cpu()) < 3e-6
+    if (taps // 2) * dil <= ops._TS_FRONT:
+        gy_t = ops.transpose_split_act(gy, Mc, B, T, None, 0, SG, "gy")
+        x_t = ops.transpose_split_act(x, Nc, B, T, None, 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
+        Q = ops.wgrad_h3_slabs(gy_t, x_t, Mc, Nc, Nc, taps, dil, 1.0 / SG).sum(0)
+        assert rel_err(P.cpu(), Q.cpu()) < 2e-6
