@@ -58,7 +58,10 @@ enum { RADMMM_SCALE_TANH = 0, RADMMM_SCALE_EXP = 1, RADMMM_SCALE_SIGMOID = 2, RA
 #define RADMMM_SPLIT_X8B 2
 /* options of a split producer: format, exponent e of the 8-bit parts, optional saturation flag (device int, OR-ed
  * with 1 when |scale * x| > 60000 was clamped) */
-typedef struct { int fmt; int x8_exp; int32_t* sat_flag; } radmmm_split_opts;
+typedef struct { int fmt; int x8_exp; int32_t* sat_flag;
+                 void* lo16; /* optional, 8-bit formats only: the fp16 lo part fp16(s*x - hi) as well, same pitch as the hi
+                                array (radmmm_wn_input_fwd, radmmm_dact_mul_transposed): feeds radmmm_wgrad_rm */
+} radmmm_split_opts;
 
 /* ------------------------------------------------------------------------------------
  * Row GEMM with taps: the Conv1d family in channels-last form, fp32 MFMA
@@ -114,6 +117,8 @@ typedef struct {
   /* split format of Ch/Cl and C2h/C2l (RADMMM_SPLIT_*, see "split formats" below) and the exponents of their 8-bit parts */
   int split_fmt; int ch_x8_exp; int c2h_x8_exp;
   int32_t* sat_flag;     /* optional device int: OR-ed with 1 when a split output exceeded the fp16 range (was clamped) */
+  void* Clo;             /* optional, with Ch and an 8-bit split_fmt: [M][ldch] halves, the fp16 lo part fp16(ch_scale*v - Ch)
+                            as well (the row-major pair Ch / Clo is what radmmm_wgrad_rm contracts) */
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
@@ -420,12 +425,13 @@ int radmmm_wgrad_h3(const void* GYh, const void* GYl, const void* Xh, const void
  * [frames][channels] fp16 hi/lo pairs the GEMM epilogues write (R = B*T rows, utterance-major), contracted over the frames
  * with the transposition done in the LDS read; no transposed copies.
  *   P[split][tap][m][n] = acc_scale * sum_f GY[f][m] * X[f + s][n],  s = (tap - taps/2)*dil, for f + s in f's utterance.
- * No length mask (operands must be zero where the reference masks them).  ldg, ldx %% 8 == 0, 16-byte aligned operands,
- * T >= 32 unless taps == 1; ldp >= Nc; slabs `split_stride` floats apart; radmmm_wgrad_rm_tiles as radmmm_wgrad_h3_tiles. */
+ * x_mask: X rows at frames >= lens[b] count as zeros (partial padding: the conv's input is x * mask).  ldg, ldx %% 8 == 0,
+ * 16-byte aligned operands, T >= 32, at most 1024 utterances; ldp >= Nc; slabs `split_stride` floats apart;
+ * radmmm_wgrad_rm_tiles as radmmm_wgrad_h3_tiles. */
 int radmmm_wgrad_rm_tiles(int Mc, int Nc, int taps);
 int radmmm_wgrad_rm(const void* GYh, const void* GYl, int ldg, const void* Xh, const void* Xl, int ldx, int R, int T,
-                    float* P, int ldp, int64_t split_stride, int Mc, int Nc, int taps, int dil, int splits,
-                    float acc_scale, radmmm_stream_t stream);
+                    const int32_t* lens, int x_mask, float* P, int ldp, int64_t split_stride, int Mc, int Nc, int taps,
+                    int dil, int splits, float acc_scale, radmmm_stream_t stream);
 
 /* Bidirectional single-layer LSTM, recurrent part (reference: the decoder's context LSTM,
  * models/radmmm.py:141-146 = torch.nn.LSTM(bidirectional, batch_first) on a packed batch; gate order

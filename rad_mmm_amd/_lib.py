@@ -48,21 +48,23 @@ class RowGemmDesc(C.Structure):
         ("C2h", C.c_void_p), ("C2l", C.c_void_p), ("ldc2h", C.c_int), ("c2h_scale", C.c_float),
         ("split_fmt", C.c_int), ("ch_x8_exp", C.c_int), ("c2h_x8_exp", C.c_int),
         ("sat_flag", C.c_void_p),
+        ("Clo", C.c_void_p),
     ]
 
 
 class SplitOpts(C.Structure):
     """radmmm_split_opts: format of a split producer's second array (SPLIT_F16 / SPLIT_X8A / SPLIT_X8B), exponent of its
     8-bit parts, optional device saturation flag."""
-    _fields_ = [("fmt", C.c_int), ("x8_exp", C.c_int), ("sat_flag", C.c_void_p)]
+    _fields_ = [("fmt", C.c_int), ("x8_exp", C.c_int), ("sat_flag", C.c_void_p), ("lo16", C.c_void_p)]
 
 
 SPLIT_F16, SPLIT_X8A, SPLIT_X8B = 0, 1, 2
 
 
-def split_opts(fmt: int = 0, x8_exp: int = 0, sat_flag: Optional[torch.Tensor] = None):
+def split_opts(fmt: int = 0, x8_exp: int = 0, sat_flag: Optional[torch.Tensor] = None, lo16: Optional[torch.Tensor] = None):
     """byref(SplitOpts) for a C-ABI call (the struct is read during the call only)."""
-    return C.byref(SplitOpts(fmt, x8_exp, sat_flag.data_ptr() if sat_flag is not None else None))
+    return C.byref(SplitOpts(fmt, x8_exp, sat_flag.data_ptr() if sat_flag is not None else None,
+                             lo16.data_ptr() if lo16 is not None else None))
 
 
 class RowGemmH3Desc(C.Structure):
@@ -130,7 +132,7 @@ def _load() -> C.CDLL:
         "radmmm_transpose_split_act": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p],
         "radmmm_wgrad_h3_tiles": [i, i, i],
         "radmmm_wgrad_rm_tiles": [i, i, i],
-        "radmmm_wgrad_rm": [p, p, i, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, p],
+        "radmmm_wgrad_rm": [p, p, i, p, p, i, i, i, p, i, p, i, i64, i, i, i, i, i, f, p],
         "radmmm_betabinom_prior": [i, i, C.c_double, p, p],
         "radmmm_prior_zoom_batch": [p, i, p, i, i, p],
         "radmmm_energy_average": [p, p, i, i, i, i, p],

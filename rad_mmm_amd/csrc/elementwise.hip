@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
 __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz,
     float* __restrict__ X0, int ldx0, int rows, int D, int h, _Float16* __restrict__ Xh,
-    _Float16* __restrict__ Xl, int fmt, float x8_mul) {
+    _Float16* __restrict__ Xl, int fmt, float x8_mul, void* __restrict__ lo16) {
   const long long total = (long long)rows * ldx0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     if (c < D) v = ctx[(long long)r * ldctx + c];
     else if (c < D + h) v = z[(long long)r * ldz + (c - D)];
     X0[i] = v;
-    if (Xh) radmmm::store_split1_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v);   // split copy (same pitch), scale 1
+    if (Xh) radmmm::store_split1_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v, lo16);   // split copy (same pitch), scale 1
   }
 }
 
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
 // group of the z part goes element by element
 __global__ __launch_bounds__(256) void wn_input_fwd4_kernel(
     const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz, float* __restrict__ X0, int ldx0,
-    int rows, int D, int h, _Float16* __restrict__ Xh, _Float16* __restrict__ Xl, int fmt, float x8_mul) {
+    int rows, int D, int h, _Float16* __restrict__ Xh, _Float16* __restrict__ Xl, int fmt, float x8_mul,
+    void* __restrict__ lo16) {
   const int q = ldx0 >> 2;
   const long long total = (long long)rows * q;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void wn_input_fwd4_kernel(
       if (c + 2 < D + h) v.z = zp[2];
     }
     *reinterpret_cast<float4*>(X0 + (long long)r * ldx0 + c) = v;
-    if (Xh) radmmm::store_split4_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v.x, v.y, v.z, v.w);
+    if (Xh) radmmm::store_split4_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v.x, v.y, v.z, v.w, lo16);
   }
 }
 
@@ -543,15 +544,15 @@ extern "C" int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, 
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   auto a8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
   if (D % 4 == 0 && ldctx % 4 == 0 && ldz % 4 == 0 && ldx0 % 4 == 0 && a16(ctx) && a16(z) && a16(X0) &&
-      a8(Xh) && a8(Xl)) {
+      a8(Xh) && a8(Xl) && a8(so ? so->lo16 : nullptr)) {
     hipLaunchKernelGGL(wn_input_fwd4_kernel, dim3(grid_for((long long)rows * (ldx0 / 4))), dim3(256), 0, ST(stream), ctx,
                        ldctx, z, ldz, X0, ldx0, rows, D, h, static_cast<_Float16*>(Xh), static_cast<_Float16*>(Xl), fmt,
-                       ldexpf(1.f, so ? so->x8_exp : 0));
+                       ldexpf(1.f, so ? so->x8_exp : 0), so ? so->lo16 : nullptr);
     return radmmm::check_launch("wn_input_fwd");
   }
   hipLaunchKernelGGL(wn_input_fwd_kernel, dim3(grid_for((long long)rows * ldx0)), dim3(256), 0,
                      ST(stream), ctx, ldctx, z, ldz, X0, ldx0, rows, D, h, static_cast<_Float16*>(Xh),
-                     static_cast<_Float16*>(Xl), fmt, ldexpf(1.f, so ? so->x8_exp : 0));
+                     static_cast<_Float16*>(Xl), fmt, ldexpf(1.f, so ? so->x8_exp : 0), so ? so->lo16 : nullptr);
   return radmmm::check_launch("wn_input_fwd");
 }
 

@@ -19,15 +19,15 @@ struct EpilogueCtx {
 // split copy of 4 output columns (ld % 4 == 0, col % 4 == 0) in the descriptor's split format; columns >= N are
 // written as zeros in the f16 format and skipped in the 8-bit formats.  Returns max |scale * x| (saturation tracking).
 __device__ __forceinline__ float store_split4(void* hi_, void* lo_, int ld, float s, int fmt, int x8_exp, int row, int col,
-                                              int N, const float (&x)[4]) {
+                                              int N, const float (&x)[4], void* lo16_ = nullptr) {
   const float mul = __builtin_ldexpf(1.f, x8_exp);
   if (col + 3 < N || fmt == 0) {
     return store_split4_fmt(hi_, lo_, (long long)row * ld, col, fmt, mul, s, x[0], col + 1 < N ? x[1] : 0.f,
-                            col + 2 < N ? x[2] : 0.f, col + 3 < N ? x[3] : 0.f);
+                            col + 2 < N ? x[2] : 0.f, col + 3 < N ? x[3] : 0.f, lo16_);
   }
   float amax = 0.f;
   for (int e = 0; e < 4 && col + e < N; ++e)
-    amax = fmaxf(amax, store_split1_fmt(hi_, lo_, (long long)row * ld, col + e, fmt, mul, s, x[e]));
+    amax = fmaxf(amax, store_split1_fmt(hi_, lo_, (long long)row * ld, col + e, fmt, mul, s, x[e], lo16_));
   return amax;
 }
 
@@ -110,7 +110,7 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
   }
   // optional split-fp16 copies (hi/lo of scale*x) feeding the next split-f16 GEMM
   float amax = 0.f;
-  if (p.Ch) amax = store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, p.split_fmt, p.ch_x8_exp, row, col, p.N, v);
+  if (p.Ch) amax = store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, p.split_fmt, p.ch_x8_exp, row, col, p.N, v, p.Clo);
   if (p.C2h) amax = fmaxf(amax, store_split4(p.C2h, p.C2l, p.ldc2h, p.c2h_scale, p.split_fmt, p.c2h_x8_exp, row, col, p.N, c2v));
   if (full) {
     *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);

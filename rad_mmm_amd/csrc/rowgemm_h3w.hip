@@ -71,7 +71,8 @@ __device__ __forceinline__ float epilogue_row_fast(const radmmm_rowgemm_desc& p,
   c2v.x += v0; c2v.y += v1; c2v.z += v2; c2v.w += v3;
   float amax = 0.f;
   if (p.Ch)
-    amax = radmmm::store_split4_fmt(p.Ch, p.Cl, (unsigned)(row * p.ldch), col, p.split_fmt, ec.ch_mul, p.ch_scale, v0, v1, v2, v3);
+    amax = radmmm::store_split4_fmt(p.Ch, p.Cl, (unsigned)(row * p.ldch), col, p.split_fmt, ec.ch_mul, p.ch_scale, v0, v1, v2, v3,
+                                    p.Clo);
   if (p.C2h)
     amax = fmaxf(amax, radmmm::store_split4_fmt(p.C2h, p.C2l, (unsigned)(row * p.ldc2h), col, p.split_fmt, ec.c2h_mul,
                                                 p.c2h_scale, c2v.x, c2v.y, c2v.z, c2v.w));
@@ -530,7 +531,7 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
                     (!p.add || (p.ldadd % 4 == 0 && a16(p.add) && fits(p.ldadd))) &&
                     (!p.dact || (p.lddact % 4 == 0 && a16(p.dact_src) && fits(p.lddact))) &&
                     (!p.C2 || (p.ldc2 % 4 == 0 && a16(p.C2) && fits(p.ldc2))) &&
-                    (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && a8(p.Ch) && a8(p.Cl))) &&
+                    (!p.Ch || (p.ldch % 4 == 0 && fits(p.ldch) && a8(p.Ch) && a8(p.Cl) && a8(p.Clo))) &&
                     (!p.C2h || (p.ldc2h % 4 == 0 && fits(p.ldc2h) && a8(p.C2h) && a8(p.C2l)));
   // (the 8-bit split formats additionally need ld % 32 == 0 and 4-byte aligned cross arrays: checked by the caller
   //  radmmm_rowgemm_h3 for every path)

@@ -29,9 +29,10 @@ __device__ __forceinline__ unsigned x8_lo_off(int col, int fmt) { return ((unsig
 
 // 4 consecutive columns (col % 4 == 0) of row `row`: x0..x3 are the UNSCALED values.  Returns max |scale * x| (for the
 // saturation flag: > 60000 means the fp16 clamp changed a value).  ld in halves, ld % 4 == 0.
+// lo16_ (optional): with an 8-bit format, store the fp16 lo part there as well (pitch of the hi array)
 template <typename OffT>
 __device__ __forceinline__ float store_split4_fmt(void* hi_, void* lo_, OffT elem_off_row, int col, int fmt, float x8_mul,
-                                                  float s, float x0, float x1, float x2, float x3) {
+                                                  float s, float x0, float x1, float x2, float x3, void* lo16_ = nullptr) {
   const float u0 = x0 * s, u1 = x1 * s, u2 = x2 * s, u3 = x3 * s;
   const float amax = fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(u2), fabsf(u3)));
   const float t0 = clamp_f16(u0), t1 = clamp_f16(u1), t2 = clamp_f16(u2), t3 = clamp_f16(u3);
@@ -48,13 +49,18 @@ __device__ __forceinline__ float store_split4_fmt(void* hi_, void* lo_, OffT ele
     const float lm = x8_mul * 2048.f;
     *reinterpret_cast<unsigned*>(row + x8_hi_off(col, fmt)) = pack_e4m3x4(t0 * x8_mul, t1 * x8_mul, t2 * x8_mul, t3 * x8_mul);
     *reinterpret_cast<unsigned*>(row + x8_lo_off(col, fmt)) = pack_e4m3x4(r0 * lm, r1 * lm, r2 * lm, r3 * lm);
+    if (lo16_) {
+      f16x4_t lo;
+      lo[0] = (_Float16)r0; lo[1] = (_Float16)r1; lo[2] = (_Float16)r2; lo[3] = (_Float16)r3;
+      *reinterpret_cast<f16x4_t*>(static_cast<_Float16*>(lo16_) + elem_off_row + col) = lo;
+    }
   }
   return amax;
 }
 
 // one element (generic / tail paths)
 __device__ __forceinline__ float store_split1_fmt(void* hi_, void* lo_, long long elem_off_row, int col, int fmt, float x8_mul,
-                                                  float s, float x) {
+                                                  float s, float x, void* lo16_ = nullptr) {
   const float u = x * s;
   const float t = clamp_f16(u);
   const _Float16 h = (_Float16)t;
@@ -66,6 +72,7 @@ __device__ __forceinline__ float store_split1_fmt(void* hi_, void* lo_, long lon
     unsigned char* row = static_cast<unsigned char*>(lo_) + 2 * elem_off_row;
     row[x8_hi_off(col, fmt)] = (unsigned char)(pack_e4m3x4(t * x8_mul, 0.f, 0.f, 0.f) & 0xffu);
     row[x8_lo_off(col, fmt)] = (unsigned char)(pack_e4m3x4(r * x8_mul * 2048.f, 0.f, 0.f, 0.f) & 0xffu);
+    if (lo16_) static_cast<_Float16*>(lo16_)[elem_off_row + col] = (_Float16)r;
   }
   return fabsf(u);
 }

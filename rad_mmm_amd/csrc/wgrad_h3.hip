@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void transpose_split_act64_kernel(
 __global__ __launch_bounds__(256) void dact_transposed_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds, int C, int T, int Tp, int front, int dact,
     float scale, void* __restrict__ yh, void* __restrict__ yl, int ldyh, int fmt, float x8_mul, int* __restrict__ sat_flag,
-    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part, int vec4) {
+    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part, int vec4,
+    void* __restrict__ ylo16) {
   __shared__ float tile[64][65];
   __shared__ float red[16][65];
   const int b = blockIdx.z;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
         v.z = gv.z * radmmm::dact_from_out(sv.z, dact);
         v.w = gv.w * radmmm::dact_from_out(sv.w, dact);
       }
-      if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w));
+      if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w, ylo16));
       s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
     tile[tl][tx * 4 + 0] = v.x * scale;
@@ -489,7 +490,9 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
   }
   // transposed copy: lanes run along time (64 consecutive frames of one channel = 128 contiguous bytes per array);
   // frames in [T, Tp) are the zero gap after the utterance and are (re)written here as zeros (tile rows hold zeros there)
-  if (vec4) {
+  if (!oh) {
+    // no transposed copy wanted (the weight gradient contracts the row-major pair: radmmm_wgrad_rm)
+  } else if (vec4) {
     const int q = threadIdx.x & 15, cl0 = threadIdx.x >> 4;          // 16 frame quads x 16 channels per pass, 8-byte stores
     const int t = t0 + 4 * q;
     if (t < Tp) {
@@ -625,8 +628,8 @@ extern "C" int radmmm_dact_mul_transposed(const float* g, int ldg, const float* 
                                           int front, int dact, float scale, void* yh, void* yl, int ldyh,
                                           const radmmm_split_opts* so, void* oh, void* ol, int ldk, float* part,
                                           radmmm_stream_t stream) {
-  RADMMM_REQUIRE(g && oh && ol && part && (saved || !dact), "dact_mul_transposed: null pointer");
-  RADMMM_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && T > 0 && Tp >= T && front >= 1 && ldk % 8 == 0 && ldk >= front + B * Tp &&
+  RADMMM_REQUIRE(g && (oh != nullptr) == (ol != nullptr) && part && (saved || !dact), "dact_mul_transposed: null pointer");
+  RADMMM_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && T > 0 && Tp >= T && front >= 1 && (!oh || (ldk % 8 == 0 && ldk >= front + B * Tp)) &&
                      ldg >= C && ldg % 4 == 0 && (!dact || (lds >= C && lds % 4 == 0)),
                  "dact_mul_transposed: bad dims (C, ldg, lds multiples of 4)");
   RADMMM_REQUIRE(radmmm::aligned16(g) && (!dact || radmmm::aligned16(saved)), "dact_mul_transposed: 16-byte aligned inputs");
@@ -638,6 +641,7 @@ extern "C" int radmmm_dact_mul_transposed(const float* g, int ldg, const float* 
                      ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr, static_cast<_Float16*>(oh),
                      static_cast<_Float16*>(ol), ldk, part,
                      (front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0);
+                      (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0,
+                     so ? so->lo16 : nullptr);
   return radmmm::check_launch("dact_mul_transposed");
 }

@@ -3,8 +3,8 @@
 // transposed zero-gapped copies (wgrad_h3.hip's operands) are needed.
 //   P[split][tap][m][n] = acc_scale * sum_f GY[f][m] * X[f + s][n],   s = (tap - taps/2) * dil,
 //   over the frames f of one split whose partner f + s lies in the SAME utterance: rows are utterance-major,
-//   T frames each (f = b*T + t, 0 <= t + s < T).  No length mask: the caller hands over operands that are zero at frames
-//   >= length where the reference masks them (ops.py: the WN hidden states are masked at the source).
+//   T frames each (f = b*T + t, 0 <= t + s < T), and -- x_mask (partial padding: the conv's input is x * mask) -- below
+//   the utterance's length (t + s < lens[b]).
 // Tile machine as wgrad_h3.hip (one workgroup per CU, 256 x 256 output tile, 4 waves x (8 x 2) accumulators, LDS-DMA
 // double buffering, three f16 MFMA products hi.lo + lo.hi + hi.hi, split-K, one tap per workgroup, XCD-aware tile
 // order).  What differs (measured in tools/wgrad_rm_probe.hip: 361 us for the 5-tap 1024 x 1024 gradient against 382 us +
@@ -38,6 +38,8 @@ constexpr int OOB = 0x7fffffff;
 
 struct RmArgs {
   const _Float16 *GYh, *GYl, *Xh, *Xl;   // [R][ld] row-major
+  const int* lens;                       // [R / T] or null; used when x_mask
+  int x_mask;
   int R, T, ldg, ldx, Mc, Nc, taps, dil, splits;
   float* P; int ldp; long long split_stride;
   float acc_scale;
@@ -137,7 +139,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm_kernel(const RmArgs a) {
   const __amdgpu_buffer_rsrc_t rGl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.GYl), 0, a.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rXh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.Xh), 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rXl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.Xl), 0, a.x_bytes, 0x00020000);
-  int p_k[16], p_off[16], p_t[8];
+  // (the Xh and Xl pieces of a row pair share their row: four (frame-in-utterance, utterance, limit) triples per wave)
+  int p_k[16], p_off[16], p_t[4], p_b[4], p_lim[4];
+  int* lim_tab = reinterpret_cast<int*>(sm + SMEM);              // readable frames per utterance: min(len, T) or T
+  const int nb = a.R / a.T;
+  for (int i = tid; i < nb; i += 256) {
+    const int l = (a.x_mask && a.lens) ? a.lens[i] : a.T;
+    lim_tab[i] = l < a.T ? l : a.T;
+  }
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
     const int arr = w >> 2, pr = 4 * (w & 3) + wave;
@@ -149,7 +158,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm_kernel(const RmArgs a) {
     p_k[w] = k;
     const int f0 = step_lo * BK + k;                             // GY frame of this row at the split's first step
     p_off[w] = ch < C ? ((f0 + (isx ? shift : 0)) * ld + ch) * 2 : OOB;
-    if (isx) p_t[w - 8] = f0 % a.T;                              // frame within its utterance
+    if (arr == 2) {
+      const int b = f0 / a.T;
+      const int bc = b < nb ? b : nb - 1;
+      const int l = (a.x_mask && a.lens) ? a.lens[bc] : a.T;
+      p_b[w & 3] = b;
+      p_t[w & 3] = f0 - b * a.T;                                   // frame within its utterance
+      p_lim[w & 3] = l < a.T ? l : a.T;
+    }
   }
   const int g_step = BK * a.ldg * 2, x_step = BK * a.ldx * 2;
   int l_rel = 0;                                                 // steps fetched so far (relative to step_lo)
@@ -159,18 +175,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm_kernel(const RmArgs a) {
     const int f = (step_lo + rel) * BK + p_k[w];
     int ok = -(int)(f < a.R);                                     // the GY frame exists
     if (arr >= 2) {
-      const int ts = p_t[w - 8] + shift;                          // partner frame, counted within the utterance
-      ok &= -(int)((unsigned)ts < (unsigned)a.T);
+      const int ts = p_t[w & 3] + shift;                          // partner frame, counted within the utterance
+      ok &= -(int)((unsigned)ts < (unsigned)p_lim[w & 3]);
     }
     const int vo = ((p_off[w] + rel * (arr >= 2 ? x_step : g_step)) & ok) | (OOB & ~ok);
     dma16(arr == 0 ? rGh : arr == 1 ? rGl : arr == 2 ? rXh : rXl, (lds_u32_ptr)(sm + buf * STAGE + arr * ARR + pr * 1024), vo);
   };
   auto advance_t = [&]() __attribute__((always_inline)) {        // the X pieces' rows move on by one K step
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < 4; ++w) {
       int t = p_t[w] + BK;
-      while (t >= a.T) t -= a.T;                                 // T >= 32 in every use: at most one trip
+      const int wrap = t >= a.T ? 1 : 0;                         // T >= 32: at most one utterance boundary per step
+      t -= wrap ? a.T : 0;
+      const int b = p_b[w] + wrap;
       p_t[w] = t;
+      p_b[w] = b;
+      p_lim[w] = lim_tab[b < nb ? b : nb - 1];
     }
   };
 
@@ -250,21 +270,23 @@ extern "C" int radmmm_wgrad_rm_tiles(int Mc, int Nc, int taps) {
 }
 
 // GYh/GYl [R][ldg], Xh/Xl [R][ldx]: row-major fp16 split pairs (hi, lo) of scale_g * gy and of x; R = B * T rows,
-// utterance-major.  P [splits][taps][Mc][ldp] fp32 partial slabs (split_stride floats apart), to be summed by the caller
-// (radmmm_weightnorm_bwd does).  ldg, ldx multiples of 8, 16-byte aligned operands, T >= 32 or taps == 1.
+// utterance-major.  x_mask: X rows at frames >= lens[b] read as zeros.  P [splits][taps][Mc][ldp] fp32 partial slabs
+// (split_stride floats apart), to be summed by the caller (radmmm_weightnorm_bwd does).  ldg, ldx multiples of 8,
+// 16-byte aligned operands, T >= 32, at most 1024 utterances.
 extern "C" int radmmm_wgrad_rm(const void* GYh, const void* GYl, int ldg, const void* Xh, const void* Xl, int ldx, int R, int T,
-                               float* P, int ldp, int64_t split_stride, int Mc, int Nc, int taps, int dil, int splits,
-                               float acc_scale, radmmm_stream_t stream) {
+                               const int32_t* lens, int x_mask, float* P, int ldp, int64_t split_stride, int Mc, int Nc,
+                               int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream) {
   RADMMM_REQUIRE(GYh && GYl && Xh && Xl && P, "wgrad_rm: null pointer");
   RADMMM_REQUIRE(Mc > 0 && Nc > 0 && taps >= 1 && dil >= 1 && splits >= 1 && R > 0 && T > 0 && R % T == 0 && ldg >= Mc &&
-                     ldx >= Nc && ldg % 8 == 0 && ldx % 8 == 0 && ldp >= Nc && (T >= BK || taps == 1),
-                 "wgrad_rm: bad dims (ldg, ldx %% 8 == 0, R = B * T, T >= 32)");
+                     ldx >= Nc && ldg % 8 == 0 && ldx % 8 == 0 && ldp >= Nc && T >= BK && R / T <= 1024,
+                 "wgrad_rm: bad dims (ldg, ldx %% 8 == 0, R = B * T, T >= 32, B <= 1024)");
   RADMMM_REQUIRE(radmmm::aligned16(GYh) && radmmm::aligned16(GYl) && radmmm::aligned16(Xh) && radmmm::aligned16(Xl),
                  "wgrad_rm: 16-byte aligned operands");
   const long long g_bytes = (long long)R * ldg * 2, x_bytes = (long long)R * ldx * 2;
   RADMMM_REQUIRE(g_bytes < 0x7fffffffLL && x_bytes < 0x7fffffffLL, "wgrad_rm: operand >= 2 GiB");
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SMEM + 4096);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(wgrad_rm): %s", hipGetErrorString(e));
       return -2;
@@ -275,10 +297,11 @@ extern "C" int radmmm_wgrad_rm(const void* GYh, const void* GYl, int ldg, const 
   RmArgs a;
   a.GYh = static_cast<const _Float16*>(GYh); a.GYl = static_cast<const _Float16*>(GYl);
   a.Xh = static_cast<const _Float16*>(Xh); a.Xl = static_cast<const _Float16*>(Xl);
+  a.lens = lens; a.x_mask = x_mask;
   a.R = R; a.T = T; a.ldg = ldg; a.ldx = ldx; a.Mc = Mc; a.Nc = Nc; a.taps = taps; a.dil = dil; a.splits = splits;
   a.P = P; a.ldp = ldp; a.split_stride = split_stride; a.acc_scale = acc_scale;
   a.g_bytes = (int)g_bytes; a.x_bytes = (int)x_bytes;
   const int grid = radmmm_wgrad_rm_tiles(Mc, Nc, taps) * splits;
-  hipLaunchKernelGGL(wgrad_rm_kernel, dim3(grid), dim3(256), SMEM, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(wgrad_rm_kernel, dim3(grid), dim3(256), SMEM + 4096, static_cast<hipStream_t>(stream), a);
   return radmmm::check_launch("wgrad_rm");
 }

@@ -692,18 +692,22 @@ def _ts_buffers(device, C, B, T, role, need_odd):
     return [f[:need].view(C, ldk) for f in ent["flat"]], Tp, Kt, ldk
 
 
-def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp, sat_flag, sum_out=None):
-    """y = g * act'(saved) written as the row-major split pair yh/yl (format fmt), as the transposed zero-gapped
-    split-f16 copy (pool `role`) and as column sums, in one pass and without an fp32 y (radmmm_dact_mul_transposed)
-    -> (transposed-copy tuple, sums [C])."""
-    bufs, Tp, Kt, ldk = _ts_buffers(g.device, C, B, T, role, False)
-    oh, ol = bufs[0], bufs[1]
+def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp, sat_flag, sum_out=None, ylo16=None):
+    """y = g * act'(saved) written as the row-major split pair yh/yl (format fmt; ylo16: the fp16 lo part as well when
+    yl is an 8-bit cross array), as the transposed zero-gapped split-f16 copy (pool `role`; role None: no transposed copy)
+    and as column sums, in one pass and without an fp32 y (radmmm_dact_mul_transposed) -> (transposed-copy tuple, sums [C])."""
+    if role is None:
+        Tp = T + _TS_FRONT
+        Kt, ldk, oh, ol = 0, 0, None, None
+    else:
+        bufs, Tp, Kt, ldk = _ts_buffers(g.device, C, B, T, role, False)
+        oh, ol = bufs[0], bufs[1]
     nparts = B * (-(-Tp // 64))
     part = _empty(nparts, C, like=g)
     sums = sum_out if (sum_out is not None and sum_out.numel() == C) else _empty(C, like=g)
     check(lib.radmmm_dact_mul_transposed(ptr(g), g.shape[1], ptr(saved), saved.shape[1] if saved is not None else 0, C, B, T, Tp,
                                          _TS_FRONT, act, scale, ptr(yh), ptr(yl), yh.shape[1] if yh is not None else 0,
-                                         split_opts(fmt, x8_exp, sat_flag), ptr(oh), ptr(ol), ldk, ptr(part), stream()),
+                                         split_opts(fmt, x8_exp, sat_flag, ylo16), ptr(oh), ptr(ol), ldk, ptr(part), stream()),
           "dact_mul_transposed")
     check(lib.radmmm_colsum_final(ptr(part), ptr(sums), nparts, C, stream()), "colsum_final")
     return (oh, ol, None, None, Kt), sums
@@ -751,9 +755,10 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     return P
 
 
-def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale):
+def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale, lens=None):
     """Weight gradient from ROW-major split pairs (hi, lo fp16 [B*T, ld]) -> P [S, taps, Mc, Nc] fp32 slabs
-    (radmmm_wgrad_rm: contraction over the frames, transposition in the LDS read, no transposed copies)."""
+    (radmmm_wgrad_rm: contraction over the frames, transposition in the LDS read, no transposed copies).
+    lens (int32 [B]): x counts as zero at frames >= length (partial padding)."""
     gh, gl = gy_pair
     xh, xl = x_pair
     R = B * T
@@ -761,8 +766,9 @@ def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale):
     tiles = int(lib.radmmm_wgrad_rm_tiles(Mc, Nc, taps))
     S = pick_splits(tiles, R, slots=int(lib.radmmm_gemm_cu_slots()))              # one workgroup per CU
     P = torch.empty(S, taps, Mc, Nc, device=gh.device, dtype=torch.float32)
-    check(lib.radmmm_wgrad_rm(ptr(gh), ptr(gl), gh.shape[1], ptr(xh), ptr(xl), xh.shape[1], R, T, ptr(P), Nc, P.stride(0), Mc, Nc,
-                              taps, dil, S, acc_scale, stream()), "wgrad_rm")
+    check(lib.radmmm_wgrad_rm(ptr(gh), ptr(gl), gh.shape[1], ptr(xh), ptr(xl), xh.shape[1], R, T, ptr(lens),
+                              1 if lens is not None else 0, ptr(P), Nc, P.stride(0), Mc, Nc, taps, dil, S, acc_scale, stream()),
+          "wgrad_rm")
     return P
 
 
@@ -920,12 +926,19 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         gin = dict(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, acc_scale=inv_ws, T=T, sat_flag=flag)
         gout = dict(split_fmt=fa, ch_x8_exp=X8_ACT_EXP, c2h_x8_exp=X8_ACT_EXP)
 
+        # Weight gradients contract the ROW-major split pairs (hi, fp16 lo) of the activations / gradients directly
+        # (radmmm_wgrad_rm): the pairs of X0 and of every hidden state are kept for backward; under the FP8-cross scheme
+        # the GEMMs' second operand array is the 8-bit cross array, so the producers write the fp16 lo part as well.
+        use_rm = (NPR in (2, 3) and (T >= 32) and any(ctx.needs_input_grad) and
+                  os.environ.get("RADMMM_WGRAD_RM", "1") != "0")
+        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
         z1 = _empty(N, ZLD, like=z_in)
         rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
         X0 = _empty(N, Kp, like=z_in)
         X0h, X0l = _halves(N, Kp, like=z_in)
+        X0lo = torch.empty(N, Kp, device=z_in.device, dtype=torch.float16) if (use_rm and NPR == 2) else None
         check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l),
-                                      split_opts(fa, X8_ACT_EXP), stream()), "wn_input_fwd")
+                                      split_opts(fa, X8_ACT_EXP, None, X0lo), stream()), "wn_input_fwd")
         perm = (h, D, 0)
         Wsh, Wsl, inv_s = split_weight(start_v, start_g, Kp, perm, NPR)
         Wih, Wil, inv_i, Wrh, Wrl, inv_r = [], [], [], [], [], []
@@ -938,8 +951,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
 
         H = [_empty(N, Wc, like=z_in)]
         Hh, Hl = _halves(N, Wc, like=z_in)
+        Hlo = lo16()
         rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
-                   bias=start_b, Ch=Hh, Cl=Hl, ldch=Wc, ch_scale=1.0, **gin, **gout)
+                   bias=start_b, Ch=Hh, Cl=Hl, Clo=Hlo, ldch=Wc, ch_scale=1.0, **gin, **gout)
+        pairs = [(Hh, Hlo if Hlo is not None else Hl)]
         OUT = _empty(N, Wc, like=z_in)
         OUTh, OUTl = _halves(N, Wc, like=z_in)
         R = []
@@ -948,12 +963,14 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             kt = in_p[3 * j].shape[2]
             Hn = _empty(N, Wc, like=z_in)
             Hnh, Hnl = _halves(N, Wc, like=z_in)
+            Hnlo = lo16()
             rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
                        C=Hn, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=1, lens=lens,
                        a_mask_mode=1 if partial else 0, bias=in_p[3 * j + 2], pconv=1 if partial else 0, ratio_taps=kt,
-                       ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, ldch=Wc, ch_scale=1.0, **gin, **gout)
+                       ratio_dil=d, postmask=1, act=act, Ch=Hnh, Cl=Hnl, Clo=Hnlo, ldch=Wc, ch_scale=1.0, **gin, **gout)
             H.append(Hn)
             Hh, Hl = Hnh, Hnl
+            pairs.append((Hnh, Hnlo if Hnlo is not None else Hnl))
             Rj = _empty(N, Wc, like=z_in)
             last = j == nl - 1
             rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc,
@@ -969,9 +986,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                              stream()), "affine_coupling_fwd")
         ctx.meta = meta
         ctx.nl = nl
+        ctx.use_rm = use_rm
+        rm_saved = [X0h, X0lo if X0lo is not None else X0l, *[t for pr in pairs for t in pr]] if use_rm else []
         ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
                               start_b, end_b,
-                              *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *layer_params)
+                              *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *rm_saved, *layer_params)
         return z_out, log_s
 
     @staticmethod
@@ -993,6 +1012,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         Wrh = sv[p: p + nl]; p += nl
         Wrl = sv[p: p + nl]; p += nl
         inv_r = sv[p: p + nl]; p += nl
+        use_rm = ctx.use_rm
+        if use_rm:                                # row-major split pairs (hi, fp16 lo) of X0 and of the hidden states
+            X0pair = (sv[p], sv[p + 1]); p += 2
+            Hpair = [(sv[p + 2 * i], sv[p + 2 * i + 1]) for i in range(nl + 1)]; p += 2 * (nl + 1)
         layer_params = sv[p:]
         in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
         h = C // 2
@@ -1003,6 +1026,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         if g_logs is not None:
             g_logs = g_logs.contiguous()
         box = meta["scale_box"]
+        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
         SG = grad_scale(box, g_zout)
         flag = sat_flag_of(box)
         fa = fmt_a(NPR)
@@ -1024,7 +1048,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         g_res: List[Optional[torch.Tensor]] = [None] * (3 * nl)
         G = None
-        Gh = Gl = None
+        Gh = Gl = Glo = None
         # dL/dH_{j+1} = (k-tap data gradient of in_layer j+1) + (1x1 data gradient of res_skip j): the two GEMMs share their
         # output, so they run as ONE launch -- the 1x1 part is an extra K segment of the k-tap GEMM (radmmm_rowgemm_h3's
         # extra_tap) -- and dL/dH_{j+1} itself never exists in memory.  For that the split copies of g_conv_{j+1} and of
@@ -1044,19 +1068,24 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 gQh, gQl = _halves(N, Wc, like=z_in)
             # through softplus of the res/skip branch: gQ = gOUT * act'(R_j), written as the dgrad GEMM's row-major split
             # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
-            gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, "gy", gQh, gQl, fa, X8_GRAD_EXP, flag,
-                                                         sum_out=grad_out(res_p[3 * j + 2]))
-            # H[j+1]'s transposed copy may still be in the pool from layer j+1's in_layer weight gradient (x_prev, set
-            # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)
-            x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
-            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
+            gQlo = lo16()
+            gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
+                                                         X8_GRAD_EXP, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo)
+            if use_rm:
+                slabs = wgrad_rm_slabs((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], B, T, Wc, Wc, 1, 1, 1.0 / SG)
+            else:
+                # H[j+1]'s transposed copy may still be in the pool from layer j+1's in_layer weight gradient (x_prev, set
+                # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)
+                x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
+                slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
             g_conv = _empty(N, Wc, like=z_in)
             keep_pair = fuse and j > 0               # g_conv_j's split copy becomes the first half of the next pair
             nh, nlo = _halves(2 * N if keep_pair else N, Wc, like=z_in)
             gch, gcl = nh[:N], nlo[:N]
+            gclo = lo16()
             epi = dict(C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens, dact_src=H[j + 1], lddact=Wc, dact=act,
-                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, ldch=Wc, ch_scale=SG)
+                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, Clo=gclo, ldch=Wc, ch_scale=SG)
             if fused:
                 WTh, WTl, ktn, dn = WT_prev
                 transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
@@ -1065,7 +1094,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             else:
                 WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
                 rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout)
-            if (kt // 2) * d <= _TS_FRONT:
+            if use_rm:
+                g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d, out=grad_out(in_p[3 * j + 2]))
+                slabs = wgrad_rm_slabs((gch, gclo if gclo is not None else gcl), Hpair[j], B, T, Wc, Wc, kt, d, 1.0 / SG,
+                                       lens if partial else None)
+            elif (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
                                                             colsum=(2 if partial else 0, lens, kt, d),
                                                             sum_out=grad_out(in_p[3 * j + 2]))
@@ -1094,17 +1127,22 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 G = _empty(N, Wc, like=z_in)
                 if j == 0:
                     Gh, Gl = _halves(N, Wc, like=z_in)
+                    Glo = lo16()
                 rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
                            C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
                            a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
-                           ldch=Wc, ch_scale=SG, **gin, **gout)
+                           Clo=Glo if j == 0 else None, ldch=Wc, ch_scale=SG, **gin, **gout)
                 pair_h = pair_l = None
             check_saturation(box)
         perm = (h, D, 0)
-        gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
-                                              sum_out=grad_out(start_b))
-        x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
-        slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, WPR)
+        if use_rm:
+            g_start_b = colsum(G, Wc, out=grad_out(start_b))
+            slabs = wgrad_rm_slabs((Gh, Glo if Glo is not None else Gl), X0pair, B, T, Wc, Kp, 1, 1, 1.0 / SG)
+        else:
+            gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
+                                                  sum_out=grad_out(start_b))
+            x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
+            slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, WPR)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
         WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)                      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)

@@ -139,6 +139,13 @@ def test_wgrad_rm_matches_the_transposed_path(B, T, Mc, Nc, taps, dil):
     gh, gl = ops.split_f16(gy, Mc, SG, ldg)
     xh, xl = ops.split_f16(x, Nc, 1.0, ldx)
     P = ops.wgrad_rm_slabs((gh, gl), (xh, xl), B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)      # [taps, Mc, Nc]
+    # the length mask on x (partial padding): equal to the unmasked gradient of x zeroed at frames >= length
+    lens = torch.tensor([max(1, T - 7 * b) for b in range(B)], dtype=torch.int32, device=DEV)
+    keep = (torch.arange(T, device=DEV)[None] < lens[:, None]).reshape(B * T, 1)
+    xmh, xml = ops.split_f16(x * keep, Nc, 1.0, ldx)
+    Pm = ops.wgrad_rm_slabs((gh, gl), (xh, xl), B, T, Mc, Nc, taps, dil, 1.0 / SG, lens).sum(0)
+    Pz = ops.wgrad_rm_slabs((gh, gl), (xmh, xml), B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)
+    assert torch.equal(Pm, Pz)
     # float64 reference from the split values
     gv = (gh.double() + gl.double())[:, :Mc].view(B, T, Mc) / SG
     xv = (xh.double() + xl.double())[:, :Nc].view(B, T, Nc)
