@@ -327,9 +327,14 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
 // owns 4 adjacent columns (float4 loads: a block reads 4 KiB contiguous per row).  Stage 2 adds
 // the per-chunk partials.  Deterministic (no atomics).
 constexpr int CS_ROWS_PER_BLOCK = 64;
+// frame-rate inputs (thousands of rows x >= 512 columns: the bias sums of the WN backward) take 16 rows per block: 64
+// serial 16-byte loads per thread in only rows / 64 blocks left the pass at 1.2 TB/s
+__host__ __device__ inline int colsum_rows_per_block(int rows, int cols) {
+  return (rows >= 4096 && cols >= 512) ? 16 : CS_ROWS_PER_BLOCK;
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
     const float* __restrict__ X, int ldx, float* __restrict__ part, int rows, int cols,
-    int row_weight, int T, const int* __restrict__ lens, int taps, int dil, int square) {
+    int row_weight, int T, const int* __restrict__ lens, int taps, int dil, int square, int rpb) {
   // narrow inputs (cols < 1024: the 160-wide flow tensors) would leave most of the block idle with 64
   // serial loads per thread: the spare threads become row lanes (thread = column group + ncg * row lane)
   // whose partial sums are combined through LDS in a fixed order
@@ -338,8 +343,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
   const int ncg = (span + 3) / 4, nrl = 256 / ncg;             // column groups of 4, row lanes
   const int cg = threadIdx.x % ncg, rl = threadIdx.x / ncg;
   const int c = blockIdx.x * 1024 + cg * 4;
-  const int r0 = blockIdx.y * CS_ROWS_PER_BLOCK;
-  int r1 = r0 + CS_ROWS_PER_BLOCK;
+  const int r0 = blockIdx.y * rpb;
+  int r1 = r0 + rpb;
   if (r1 > rows) r1 = rows;
   const bool vec = (ldx % 4 == 0) && radmmm::aligned16(X) && c + 3 < cols;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -614,7 +619,8 @@ extern "C" int radmmm_dact_mul(const float* g, int ldg, const float* saved, int 
 }
 
 extern "C" int64_t radmmm_colsum_scratch_floats(int rows, int cols) {
-  const int64_t nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  const int rpb = colsum_rows_per_block(rows, cols);
+  const int64_t nparts = (rows + rpb - 1) / rpb;
   return nparts * cols;
 }
 
@@ -625,9 +631,10 @@ extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch
   RADMMM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, "colsum: bad dims");
   RADMMM_REQUIRE(row_weight == 0 || (T > 0 && rows % T == 0), "colsum: rows must be a multiple of T");
   RADMMM_REQUIRE(row_weight != 2 || (taps >= 1 && dil >= 1), "colsum: taps/dil");
-  const int nparts = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  const int rpb = colsum_rows_per_block(rows, cols);
+  const int nparts = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 1023) / 1024, nparts), dim3(256), 0, ST(stream),
-                     X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil, square);
+                     X, ldx, scratch, rows, cols, row_weight, T > 0 ? T : 1, lens, taps, dil, square, rpb);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, ST(stream), scratch,
                      out, nparts, cols);
   return radmmm::check_launch("colsum");
