@@ -44,7 +44,9 @@ class BiLSTMFn(torch.autograd.Function):
             G = torch.empty(B * T, 8 * H, device=x.device, dtype=torch.float32)
             rowgemm_h3(nprod=3, Ah=xh, Al=xl, lda_h=Kp, Bh=Wh, Bl=Wl, ldb_h=Kp, acc_scale=1.0 / ops.W_SCALE, C=G, ldc=8 * H,
                        M=B * T, N=8 * H, K=Kp, T=T, bias=bias)
+            ctx.xpair = (xh, xl)                                 # the row-major split pair of x: dW_ih's operand in backward
         else:
+            ctx.xpair = None
             G = torch.addmm(bias, x2, W_ih.t())                  # [B*T, 8H]
         W_hh = torch.stack((w_hh_f, w_hh_r)).contiguous()        # [2, 4H, H]
         y = torch.empty(B * T, 2 * H, device=x.device, dtype=torch.float32)
@@ -92,16 +94,28 @@ class BiLSTMFn(torch.autograd.Function):
             box = ctx.box
             SG = ops.grad_scale(box, dy2)
             flag = ops.sat_flag_of(box)
-            gy_t, db = ops.transpose_split_act(dG, 8 * H, B, T, None, 0, SG, "lstm_gy", colsum=(0, None, 1, 1))
-            x_t = ops.transpose_split_act(x2, I, B, T, None, 0, 1.0, "lstm_x")
-            hp_t = ops.transpose_split_act(hp, 2 * H, B, T, None, 0, 1.0, "lstm_h")
-            dW_ih = ops.wgrad_h3_slabs(gy_t, x_t, 8 * H, I, I, 1, 1, 1.0 / SG, 3).sum(0)[0]
-            rows = lambda tt, a, b: (tt[0][a:b], tt[1][a:b], None, None, tt[4])
-            dW_hh_f = ops.wgrad_h3_slabs(rows(gy_t, 0, 4 * H), rows(hp_t, 0, H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
-            dW_hh_r = ops.wgrad_h3_slabs(rows(gy_t, 4 * H, 8 * H), rows(hp_t, H, 2 * H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
+            gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)       # row-major split pair of dG: operand of all four GEMMs
+            if (ctx.xpair is not None and T >= 32 and (4 * H) % 8 == 0 and os.environ.get("RADMMM_WGRAD_RM", "1") != "0"):
+                # weight gradients straight from the row-major pairs (radmmm_wgrad_rm: transposition in the LDS read); the
+                # pair of x was made for the forward projection, the pairs of h_prev (one per direction, each with its own
+                # 16-byte aligned row pitch) cost what the transposed copy did
+                db = ops.colsum(dG, 8 * H)
+                Hq = ops.round_up(H, 8)
+                hpf = ops.split_f16(hp[:, :H].contiguous(), H, 1.0, Hq)
+                hpr = ops.split_f16(hp[:, H:].contiguous(), H, 1.0, Hq)
+                dW_ih = ops.wgrad_rm_slabs((gh, gl), ctx.xpair, B, T, 8 * H, I, 1, 1, 1.0 / SG).sum(0)[0]
+                dW_hh_f = ops.wgrad_rm_slabs((gh[:, :4 * H], gl[:, :4 * H]), hpf, B, T, 4 * H, H, 1, 1, 1.0 / SG).sum(0)[0]
+                dW_hh_r = ops.wgrad_rm_slabs((gh[:, 4 * H:], gl[:, 4 * H:]), hpr, B, T, 4 * H, H, 1, 1, 1.0 / SG).sum(0)[0]
+            else:
+                gy_t, db = ops.transpose_split_act(dG, 8 * H, B, T, None, 0, SG, "lstm_gy", colsum=(0, None, 1, 1))
+                x_t = ops.transpose_split_act(x2, I, B, T, None, 0, 1.0, "lstm_x")
+                hp_t = ops.transpose_split_act(hp, 2 * H, B, T, None, 0, 1.0, "lstm_h")
+                dW_ih = ops.wgrad_h3_slabs(gy_t, x_t, 8 * H, I, I, 1, 1, 1.0 / SG, 3).sum(0)[0]
+                rows = lambda tt, a, b: (tt[0][a:b], tt[1][a:b], None, None, tt[4])
+                dW_hh_f = ops.wgrad_h3_slabs(rows(gy_t, 0, 4 * H), rows(hp_t, 0, H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
+                dW_hh_r = ops.wgrad_h3_slabs(rows(gy_t, 4 * H, 8 * H), rows(hp_t, H, 2 * H), 4 * H, H, H, 1, 1, 1.0 / SG, 3).sum(0)[0]
             dx = None
             if ctx.needs_input_grad[0]:
-                gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)
                 Wt = W_ih.t().contiguous()                       # [I, 8H]: the K-contiguous operand of dx = dG W_ih
                 Wth, Wtl = ops.split_f16(Wt, 8 * H, ops.W_SCALE, 8 * H)
                 dx = torch.empty(B * T, I, device=dy.device, dtype=torch.float32)

@@ -766,7 +766,8 @@ def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale, lens=Non
     tiles = int(lib.radmmm_wgrad_rm_tiles(Mc, Nc, taps))
     S = pick_splits(tiles, R, slots=int(lib.radmmm_gemm_cu_slots()))              # one workgroup per CU
     P = torch.empty(S, taps, Mc, Nc, device=gh.device, dtype=torch.float32)
-    check(lib.radmmm_wgrad_rm(ptr(gh), ptr(gl), gh.shape[1], ptr(xh), ptr(xl), xh.shape[1], R, T, ptr(lens),
+    assert gh.stride(1) == 1 and xh.stride(1) == 1 and gl.stride(0) == gh.stride(0) and xl.stride(0) == xh.stride(0)
+    check(lib.radmmm_wgrad_rm(ptr(gh), ptr(gl), gh.stride(0), ptr(xh), ptr(xl), xh.stride(0), R, T, ptr(lens),
                               1 if lens is not None else 0, ptr(P), Nc, P.stride(0), Mc, Nc, taps, dil, S, acc_scale, stream()),
           "wgrad_rm")
     return P
