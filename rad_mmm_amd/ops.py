@@ -1184,6 +1184,8 @@ class ConvNormH3Fn(torch.autograd.Function):
                    postmask=1 if mask_out else 0, act=act)
         ctx.meta = meta
         ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
+        # the row-major split pair of x is the weight gradient's operand (radmmm_wgrad_rm) when it is an fp16 pair
+        ctx.xpair = (xh, xl) if (NPR == 3 and T >= 32 and Cin % 8 == 0 and os.environ.get("RADMMM_WGRAD_RM", "1") != "0") else None
         ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
                               inv if inv is not None else v, y)
         return y
@@ -1212,10 +1214,14 @@ class ConvNormH3Fn(torch.autograd.Function):
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
                                   taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), X8_GRAD_EXP, flag), stream()),
               "dact_mul")
-        gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
-                                           colsum=(2 if partial else 0, lens, taps, dil))
-        x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
-        slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, WPR)
+        if ctx.xpair is not None:
+            g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
+            slabs = wgrad_rm_slabs((gph, gpl), ctx.xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)
+        else:
+            gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
+                                               colsum=(2 if partial else 0, lens, taps, dil))
+            x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
+            slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, WPR)
         if ctx.has_g:
             g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin)
         else:
