@@ -475,10 +475,12 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
       if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w, ylo16));
       s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
-    tile[tl][tx * 4 + 0] = v.x * scale;
-    tile[tl][tx * 4 + 1] = v.y * scale;
-    tile[tl][tx * 4 + 2] = v.z * scale;
-    tile[tl][tx * 4 + 3] = v.w * scale;
+    if (oh) {                                                     // (no transposed copy wanted: nothing to stage)
+      tile[tl][tx * 4 + 0] = v.x * scale;
+      tile[tl][tx * 4 + 1] = v.y * scale;
+      tile[tl][tx * 4 + 2] = v.z * scale;
+      tile[tl][tx * 4 + 3] = v.w * scale;
+    }
   }
   red[ty][tx * 4 + 0] = s0; red[ty][tx * 4 + 1] = s1; red[ty][tx * 4 + 2] = s2; red[ty][tx * 4 + 3] = s3;
   __syncthreads();
