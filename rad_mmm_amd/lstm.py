@@ -95,7 +95,8 @@ class BiLSTMFn(torch.autograd.Function):
             SG = ops.grad_scale(box, dy2)
             flag = ops.sat_flag_of(box)
             gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)       # row-major split pair of dG: operand of all four GEMMs
-            if (ctx.xpair is not None and T >= 32 and (4 * H) % 8 == 0 and os.environ.get("RADMMM_WGRAD_RM", "1") != "0"):
+            if (ctx.xpair is not None and T >= 32 and B <= 1024 and (4 * H) % 8 == 0 and
+                    os.environ.get("RADMMM_WGRAD_RM", "1") != "0"):
                 # weight gradients straight from the row-major pairs (radmmm_wgrad_rm: transposition in the LDS read); the
                 # pair of x was made for the forward projection, the pairs of h_prev (one per direction, each with its own
                 # 16-byte aligned row pitch) cost what the transposed copy did

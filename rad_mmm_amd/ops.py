@@ -930,7 +930,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # Weight gradients contract the ROW-major split pairs (hi, fp16 lo) of the activations / gradients directly
         # (radmmm_wgrad_rm): the pairs of X0 and of every hidden state are kept for backward; under the FP8-cross scheme
         # the GEMMs' second operand array is the 8-bit cross array, so the producers write the fp16 lo part as well.
-        use_rm = (NPR in (2, 3) and (T >= 32) and any(ctx.needs_input_grad) and
+        use_rm = (NPR in (2, 3) and T >= 32 and B <= 1024 and any(ctx.needs_input_grad) and
                   os.environ.get("RADMMM_WGRAD_RM", "1") != "0")
         lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
         z1 = _empty(N, ZLD, like=z_in)
@@ -1185,7 +1185,8 @@ class ConvNormH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
         # the row-major split pair of x is the weight gradient's operand (radmmm_wgrad_rm) when it is an fp16 pair
-        ctx.xpair = (xh, xl) if (NPR == 3 and T >= 32 and Cin % 8 == 0 and os.environ.get("RADMMM_WGRAD_RM", "1") != "0") else None
+        ctx.xpair = (xh, xl) if (NPR == 3 and T >= 32 and B <= 1024 and Cin % 8 == 0 and
+                                 os.environ.get("RADMMM_WGRAD_RM", "1") != "0") else None
         ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
                               inv if inv is not None else v, y)
         return y
