@@ -307,7 +307,10 @@ __device__ __forceinline__ void direct_epilogue(const f32x16 (&acc)[MB][2], cons
 // ds_read in flight and every MFMA group waits for LDS (measured: 39 % MFMA busy inside a workgroup)
 constexpr int SGB_VMEM = 0x020, SGB_MFMA = 0x008, SGB_DSR = 0x100;
 constexpr int LOOKAHEAD = 2;    // fragment look-ahead in pipeline items
-constexpr int DPI = 2;          // DMA pieces issued per pipeline item
+#ifndef RADMMM_DPI
+#define RADMMM_DPI 2
+#endif
+constexpr int DPI = RADMMM_DPI;   // DMA pieces issued per pipeline item
 
 // ---------------------------------------------------------------------------------------------------
 // LDS-DMA staging: the operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), no

@@ -75,7 +75,7 @@ def main():
         ("res dgrad (add + dact + rowscale, C + Ch/Cl)",
          conv(1, add=add, ldadd=1024, dact_src=x, lddact=1024, dact=1, rowscale=2, ratio_taps=5, ratio_dil=2, **split)),
     ]
-    nwg = 232
+    nwg = ((N + 223) // 224) * 4                                      # MB = 7 tiles x 4 column tiles
     buf = (C.c_ulonglong * (4 * nwg))()
     print(json.dumps({"lib": LIB_PATH}))
     for name, fn in cases:
