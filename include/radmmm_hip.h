@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RADMMM_ABI_VERSION 1
+#define RADMMM_ABI_VERSION 2
 
 typedef void* radmmm_stream_t; /* hipStream_t */
 
@@ -178,7 +178,7 @@ int radmmm_wgrad_f32(const radmmm_wgrad_desc* d, radmmm_stream_t stream);
  *             inv_norm[co] = 1/||v[co]||
  *             col(ci) = ci < perm_split ? ci + off_lo : ci - perm_split + off_hi
  *             (columns not hit by col() are left untouched: zero them once)
- *   backward: from `splits` slabs of dL/dW (layout of W) -> dL/dv [co][ci][tap], dL/dg [co]
+ *   backward: from `splits` slabs of dL/dW (layout of W) -> dL/dv [co][ci][tap], dL/dg [co] (+ *poison)
  * v is in the reference's checkpoint layout [Cout][Cin][taps].
  * ------------------------------------------------------------------------------------ */
 int radmmm_weightnorm_fwd(const float* v, const float* g, float* W, float* inv_norm,
@@ -188,7 +188,12 @@ int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
                           const float* dW, int splits, int64_t split_stride,
                           float* dv, float* dg,
                           int Cout, int Cin, int taps, int ldw,
-                          int perm_split, int off_lo, int off_hi, radmmm_stream_t stream);
+                          int perm_split, int off_lo, int off_hi,
+                          const float* poison /* optional device scalar added to every dg element: 0, or NaN when the
+                                                 pass's incoming gradient was not finite (the split operands clamp NaN / Inf
+                                                 to finite values; this puts the non-finite result back where an AMP
+                                                 GradScaler or a gradient-norm clip looks for it) */,
+                          radmmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * WN input assembly (cat((z0, context), 1), common.py:819) in channels-last, K-padded:

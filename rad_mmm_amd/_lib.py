@@ -16,6 +16,17 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RADMMM_LIB_PATH") or os.path.join(_HERE, "libradmmm_hip.so")   # override: A/B builds of the same ABI
 
+
+
+def debug_env(name: str, default: Optional[str] = None) -> Optional[str]:
+    """Value of an experiment / test switch (forced kernel choices, A/B paths): honoured only under RADMMM_DEBUG=1, like
+    the library's own (csrc/error.cpp debug_env).  Supported switches are read with os.environ directly: RADMMM_PRECISION,
+    RADMMM_GEMM_CUS, RADMMM_CHECK_SATURATION, RADMMM_LIB_PATH, RADMMM_LSTM."""
+    if os.environ.get("RADMMM_DEBUG", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
+
+
 ACT_NONE, ACT_SOFTPLUS, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 SCALE = {"tanh": 0, "exp": 1, "sigmoid": 2, "translate": 3}
 ACT = {"none": 0, "softplus": 1, "relu": 2, "leaky_relu": 3}
@@ -102,7 +113,7 @@ def _load() -> C.CDLL:
     lib.radmmm_abi_version.restype = C.c_int
     lib.radmmm_gemm_cu_slots.restype = C.c_int
     lib.radmmm_gemm_cu_slots.argtypes = []
-    if lib.radmmm_abi_version() != 1:
+    if lib.radmmm_abi_version() != 2:
         raise ImportError("libradmmm_hip.so ABI version mismatch")
     i, i64, p = C.c_int, C.c_int64, C.c_void_p
     f = C.c_float
@@ -112,7 +123,7 @@ def _load() -> C.CDLL:
         "radmmm_wgrad_f32": [C.POINTER(WgradDesc), p],
         "radmmm_rowgemm_h3": [C.POINTER(RowGemmH3Desc), p],
         "radmmm_weightnorm_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
-        "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p],
+        "radmmm_weightnorm_bwd": [p, p, p, p, i, i64, p, p, i, i, i, i, i, i, i, p, p],
         "radmmm_wn_input_fwd": [p, i, p, i, p, i, i, i, i, p, p, so, p],
         "radmmm_wn_input_bwd": [p, i, p, i, i, p, i, i, i, i, p],
         "radmmm_squeeze_rows": [p, p, i, i, i, i, i, i, p],

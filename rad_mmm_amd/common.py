@@ -18,7 +18,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import ACT, SCALE
+from ._lib import ACT, SCALE, debug_env
 
 
 def get_mask_from_lengths(lengths: torch.Tensor) -> torch.Tensor:
@@ -232,7 +232,7 @@ class AffineTransformationLayer(nn.Module):
         wn = self.affine_param_predictor
         head, layers = wn.flat_params()
         nprod = ops.NPROD.get(precision, 3)
-        if nprod == 2 and B * T < int(os.environ.get("RADMMM_F8X_MIN_ROWS", "4096")):
+        if nprod == 2 and B * T < int(debug_env("RADMMM_F8X_MIN_ROWS", "4096")):
             # below half a round of the one-workgroup-per-CU kernel's smallest tile the split GEMMs run on the 128 x 128
             # two-workgroups-per-CU kernel, which has the three-f16-product scheme only (B = 8, T = 800: 38.7 vs 40.9 ms)
             nprod = 3

@@ -9,6 +9,8 @@
 namespace radmmm {
 
 void set_error(const char* fmt, ...);
+// value of an experiment / test switch, or nullptr unless RADMMM_DEBUG=1 (error.cpp)
+const char* debug_env(const char* name);
 
 // rowgemm16_f32.hip: 16-row-granular tiling of radmmm_rowgemm_f32 (descriptor already validated)
 int launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(
     const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
     const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
     float* __restrict__ dg, int Cout, int Cin, int taps, int ldw, int perm_split, int off_lo,
-    int off_hi) {
+    int off_hi, const float* __restrict__ poison) {
   __shared__ float sh[17];
   const int co = blockIdx.x;
   const int n = Cin * taps;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(
   for (int i = threadIdx.x; i < n; i += blockDim.x) dot = fmaf(gw_at(i), vr[i], dot);
   dot = block_sum(dot, sh);
   const float inv = inv_norm[co], gg = g[co];
-  if (threadIdx.x == 0) dg[co] = dot * inv;
+  if (threadIdx.x == 0) dg[co] = dot * inv + (poison ? poison[0] : 0.f);   // poison: 0, or NaN after a non-finite upstream gradient
   const float a = gg * inv, b = gg * dot * inv * inv * inv;
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     dv[(long long)co * n + i] = a * gw_at(i) - b * vr[i];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
     const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
     const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
     float* __restrict__ dg, int Cout, int Cin, int taps, int ldw, int perm_split, int off_lo,
-    int off_hi) {
+    int off_hi, const float* __restrict__ poison) {
   extern __shared__ __attribute__((aligned(16))) float gw[];          // [Cin * taps]
   __shared__ float sh[17];
   const int co = blockIdx.x;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
   for (int i = threadIdx.x; i < n; i += blockDim.x) dot = fmaf(gw[i], vr[i], dot);
   dot = block_sum(dot, sh);
   const float inv = inv_norm[co], gg = g[co];
-  if (threadIdx.x == 0) dg[co] = dot * inv;
+  if (threadIdx.x == 0) dg[co] = dot * inv + (poison ? poison[0] : 0.f);   // poison: 0, or NaN after a non-finite upstream gradient
   const float a = gg * inv, b = gg * dot * inv * inv * inv;
   if (VEC && n % 4 == 0) {
     for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(
       }
     }
   }
-  radmmm::raise_sat_flag(sat_flag, sat);
+  radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
 }
 
 // ------------------------------------------------------------------ column sums
@@ -516,7 +516,7 @@ extern "C" int radmmm_weightnorm_fwd(const float* v, const float* g, float* W, f
 extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
                                      const float* dW, int splits, int64_t split_stride, float* dv,
                                      float* dg, int Cout, int Cin, int taps, int ldw,
-                                     int perm_split, int off_lo, int off_hi,
+                                     int perm_split, int off_lo, int off_hi, const float* poison,
                                      radmmm_stream_t stream) {
   RADMMM_REQUIRE(v && g && inv_norm && dW && dv && dg, "weightnorm_bwd: null pointer");
   RADMMM_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && ldw >= Cin && splits >= 1, "weightnorm_bwd: bad dims");
@@ -527,14 +527,14 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
                      split_stride % 4 == 0 && a16(dW) && a16(v) && a16(dv);
     if (vec)
       hipLaunchKernelGGL(weightnorm_bwd_lds_kernel<true>, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
-                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi, poison);
     else
       hipLaunchKernelGGL(weightnorm_bwd_lds_kernel<false>, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
-                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi);
+                         splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi, poison);
   } else {
     hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW,
                        splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split,
-                       off_lo, off_hi);
+                       off_lo, off_hi, poison);
   }
   return radmmm::check_launch("weightnorm_bwd");
 }

@@ -368,7 +368,7 @@ extern "C" int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t 
   RADMMM_REQUIRE(!(d->pconv || d->rowscale == 2) || (d->ratio_taps >= 1 && d->ratio_dil >= 1), "rowgemm: ratio_taps/ratio_dil required with pconv/rowscale=2");
   RADMMM_REQUIRE(!d->dact || d->dact_src, "rowgemm: dact needs dact_src");
   static const bool use32 = [] {
-    const char* e = getenv("RADMMM_ROWGEMM_TILE");
+    const char* e = radmmm::debug_env("RADMMM_ROWGEMM_TILE");
     return e && atoi(e) == 32;
   }();
   if (!use32 && d->K % 16 == 0) {
@@ -399,7 +399,7 @@ extern "C" int radmmm_wgrad_f32(const radmmm_wgrad_desc* d, radmmm_stream_t stre
   RADMMM_REQUIRE(d->ldx % 4 == 0 && d->ldx >= ((d->Nc + 3) & ~3) && radmmm::aligned16(d->X), "wgrad: X alignment (ldx=%d Nc=%d)", d->ldx, d->Nc);
   RADMMM_REQUIRE(d->ldp >= d->Nc, "wgrad: ldp < Nc");
   static const bool generic_only = [] {
-    const char* e = getenv("RADMMM_ROWGEMM_TILE");
+    const char* e = radmmm::debug_env("RADMMM_ROWGEMM_TILE");
     return e && atoi(e) == 32;
   }();
   if (!generic_only) {

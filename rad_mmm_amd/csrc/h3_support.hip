@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? x[(long long)r * ld + c + e] : 0.f;
     sat = fmaxf(sat, radmmm::store_split4_fmt(hi, lo, (long long)r * ldh, c, fmt, x8_mul, scale, v[0], v[1], v[2], v[3]));
   }
-  radmmm::raise_sat_flag(sat_flag, sat);
+  radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
 }
 
 // dst[b][c][r] = src[b][r][c] for both members of a split pair; 32x32 tiles through LDS

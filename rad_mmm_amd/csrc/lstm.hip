@@ -400,7 +400,7 @@ constexpr int BAR_BYTES = 256;   // one 32-bit counter per (direction, batch blo
 // boundary), so the simpler launch-per-step path stays the default; the persistent path needs every
 // workgroup resident at once and is only taken when the grid has at most one workgroup per CU.
 bool use_persistent(const dim3& grid) {
-  const char* e = getenv("RADMMM_LSTM_PERSISTENT");
+  const char* e = radmmm::debug_env("RADMMM_LSTM_PERSISTENT");
   if (!e || atoi(e) == 0 || grid.z * 2 * 4 > BAR_BYTES) return false;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||

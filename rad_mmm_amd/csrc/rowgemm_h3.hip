@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_h3_kernel(const radmmm_rowgemm
     const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * BN + c4);
     sat = fmaxf(sat, radmmm::epilogue_store4(p, ec, m0 + rl, n0 + c4, a4));
   }
-  radmmm::raise_sat_flag(p.sat_flag, sat);
+  radmmm::raise_sat_flag(p.sat_flag, sat, (p.Ch && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, p.ch_x8_exp) : 0.f);
 }
 
 }  // namespace
@@ -208,16 +208,16 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   // tiles (M = 3200: 100 workgroups of its smallest 128 x 256 tile on 256 CUs): below half a round this file's
   // 128 x 128 kernel, two workgroups per CU, is faster (B = 8, T = 800: 40.0 vs 43.9 ms per step).
   // RADMMM_H3_TILE=128 / 256 forces one or the other (A/B runs).
-  const char* forced_env = getenv("RADMMM_H3_TILE");          // read per launch: tests switch it
+  const char* forced_env = radmmm::debug_env("RADMMM_H3_TILE");   // (RADMMM_DEBUG=1 only; read per launch then: tests switch it)
   const int forced = forced_env ? atoi(forced_env) : 0;
   static const bool narrow_1x1 = [] {                 // experiment: short-K launches on the 2-workgroup-per-CU kernel
-    const char* e = getenv("RADMMM_H3_1X1");
+    const char* e = radmmm::debug_env("RADMMM_H3_1X1");
     return e && atoi(e) == 128;
   }();
   const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
   // (the FP8 cross-term scheme exists on the wide kernel only)
   const bool narrow = d->nprod != 2 && !d->extra_tap && (forced == 128 || (forced != 256 && wide_wgs < 128));
-  if (!narrow && !(narrow_1x1 && p.taps == 1))
+  if (!narrow && !(narrow_1x1 && p.taps == 1 && d->nprod != 2 && !d->extra_tap))
     return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3_kernel),

@@ -30,7 +30,7 @@ int pick_h3w_mb(int M, int N, int slots) {
   // measured on (12 800 x 1024: 405 us against 380 us at MB = 7, model 8.77 : 8.22) and is taken where it saves a round
   // of workgroups: N = 1152 (the start conv's data gradient) and N = 1052 (the LSTM's input gradient) fit 50 x 5 = 250
   // workgroups into ONE round instead of 290-500 in two.  RADMMM_H3W_MB8=0: candidates 4..7 only (A/B runs).
-  static const int mb_max = (getenv("RADMMM_H3W_MB8") && atoi(getenv("RADMMM_H3W_MB8")) == 0) ? 7 : 8;
+  static const int mb_max = (debug_env("RADMMM_H3W_MB8") && atoi(debug_env("RADMMM_H3W_MB8")) == 0) ? 7 : 8;
   for (int mb = 4; mb <= mb_max; ++mb) {
     const long long wg = (long long)((M + 32 * mb - 1) / (32 * mb)) * ntn;
     const long long full = wg / slots, tail = wg % slots;
@@ -64,7 +64,7 @@ int gemm_cu_slots() {
 
 int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   int mb = pick_h3w_mb(d.base.M, d.base.N, gemm_cu_slots());
-  if (const char* e = getenv("RADMMM_H3W_MB")) {
+  if (const char* e = debug_env("RADMMM_H3W_MB")) {
     const int v = atoi(e);
     if (v >= 4 && v <= 8) mb = v;
   }
@@ -77,7 +77,7 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
   auto a4 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
   auto fits = [&](long long ld, int esz) { return ((long long)p.M + 64) * ld * esz < 0x7fffffffLL; };
   static const bool force_generic = [] {
-    const char* e = getenv("RADMMM_DEBUG_EPILOGUE");
+    const char* e = debug_env("RADMMM_DEBUG_EPILOGUE");
     return e && e[0] == 'g';
   }();
   int ek = EK_GENERIC;

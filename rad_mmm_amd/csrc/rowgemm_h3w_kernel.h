@@ -615,7 +615,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
     }
     epilogue_blocks<MB, 0>(acc, smf, rowf, p, ec, q.acc_scale, m0, n0, tid, lane, wave, biasv, sat);
   }
-  radmmm::raise_sat_flag(p.sat_flag, sat);
+  {
+    // (8-bit outputs: Ch with ch_x8_exp, C2h with c2h_x8_exp; one bound for both = the larger multiplier)
+    const int xe = p.Ch ? (p.C2h && p.c2h_x8_exp > p.ch_x8_exp ? p.c2h_x8_exp : p.ch_x8_exp) : p.c2h_x8_exp;
+    radmmm::raise_sat_flag(p.sat_flag, sat, ((p.Ch || p.C2h) && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, xe) : 0.f);
+  }
   RADMMM_PHASE(3);
 }
 

@@ -77,9 +77,14 @@ __device__ __forceinline__ float store_split1_fmt(void* hi_, void* lo_, long lon
   return fabsf(u);
 }
 
-// wave-level: raise the saturation flag if any lane saw |scale * x| > 60000
-__device__ __forceinline__ void raise_sat_flag(int* flag, float amax) {
-  if (flag && amax > 60000.f) atomicOr(flag, 1);
+// Raise the saturation flag word from this lane's max |scale * x|: bit 0 when the fp16 clamp changed a value
+// (> 60000); bit 1 when the tensor was written in an 8-bit cross format (x8_mul = 2^e > 0) and an element's 8-bit parts
+// left e4m3's range (|scale * x| * 2^e > 448: both its hi8 and, bounded by the same product, its lo8 part clamp) -- that
+// element then carries no cross-term correction, i.e. single-fp16-product accuracy.
+__device__ __forceinline__ void raise_sat_flag(int* flag, float amax, float x8_mul = 0.f) {
+  if (!flag) return;
+  if (amax > 60000.f) atomicOr(flag, 1);
+  if (x8_mul > 0.f && amax * x8_mul > 448.f) atomicOr(flag, 2);
 }
 
 }  // namespace radmmm

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
       }
     }
   }
-  radmmm::raise_sat_flag(sat_flag, sat);
+  radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
 }
 
 }  // namespace
@@ -545,7 +545,7 @@ static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp,
   const int ty = (Tp + 63) / 64;
   const bool vec_out = front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
                        (reinterpret_cast<uintptr_t>(ol) & 7) == 0;
-  static const bool narrow = getenv("RADMMM_TRANSPOSE32") != nullptr;       // A/B switch: the 32-channel kernel
+  static const bool narrow = radmmm::debug_env("RADMMM_TRANSPOSE32") != nullptr;       // A/B switch: the 32-channel kernel
   if (vec_out && !narrow && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     hipLaunchKernelGGL(transpose_split_act64_kernel, dim3((C + 63) / 64, ty, B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ld, C, T, Tp, front, lens, mask_mode, scale,

@@ -17,7 +17,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import fp32_region
+from ._lib import fp32_region, debug_env
 from .common import (AffineTransformationLayer, DataInitializedInvertible1x1Conv,
                      Invertible1x1ConvLUS, SequenceLength)
 
@@ -147,7 +147,7 @@ class RADMMMFlow(nn.Module):
         # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen)
         self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if use_context_lstm else "miopen"
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
-                                 os.environ.get("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
+                                 debug_env("RADMMM_LSTM_TWO_STREAMS", "0") == "1")   # opt-in, see _bilstm_two_streams
         self._side_stream = None
         # ---- decoders.py:105-143
         self.matrix_decomposition = "LUS"

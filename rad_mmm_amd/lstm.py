@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd, rowgemm_h3
+from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd, rowgemm_h3, debug_env
 
 
 def _scratch(B, H, which, like):
@@ -33,7 +33,7 @@ class BiLSTMFn(torch.autograd.Function):
         x2 = x.reshape(B * T, I).contiguous()
         W_ih = torch.cat((w_ih_f, w_ih_r), 0)                    # [8H, I]
         bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r))     # [8H]
-        if (8 * H) % 4 == 0 and B * T >= 4096 and os.environ.get("RADMMM_LSTM_PROJ", "hip") != "torch":
+        if (8 * H) % 4 == 0 and B * T >= 4096 and debug_env("RADMMM_LSTM_PROJ", "hip") != "torch":
             # frame-rate inputs: the input projection on the split-f16 row GEMM (three f16 products, 2e-6): 114 GFLOP at
             # the benchmark size in ~0.4 ms instead of 0.91 ms on the fp32 library GEMM; W_ih [8H, I] is already the
             # K-contiguous B operand.  (Its gradient GEMMs: BiLSTMFn.backward.)
@@ -44,9 +44,9 @@ class BiLSTMFn(torch.autograd.Function):
             G = torch.empty(B * T, 8 * H, device=x.device, dtype=torch.float32)
             rowgemm_h3(nprod=3, Ah=xh, Al=xl, lda_h=Kp, Bh=Wh, Bl=Wl, ldb_h=Kp, acc_scale=1.0 / ops.W_SCALE, C=G, ldc=8 * H,
                        M=B * T, N=8 * H, K=Kp, T=T, bias=bias)
-            ctx.xpair = (xh, xl)                                 # the row-major split pair of x: dW_ih's operand in backward
+            xpair = (xh, xl)                                     # the row-major split pair of x: dW_ih's operand in backward
         else:
-            ctx.xpair = None
+            xpair = ()
             G = torch.addmm(bias, x2, W_ih.t())                  # [B*T, 8H]
         W_hh = torch.stack((w_hh_f, w_hh_r)).contiguous()        # [2, 4H, H]
         y = torch.empty(B * T, 2 * H, device=x.device, dtype=torch.float32)
@@ -56,8 +56,9 @@ class BiLSTMFn(torch.autograd.Function):
         check(lib.radmmm_lstm_fwd(ptr(G), ptr(W_hh), ptr(y), ptr(c), ptr(lens), ptr(wsplit), ptr(hsplit), B, T, H,
                                   stream()), "lstm_fwd")
         ctx.dims = (B, T, I, H)
-        ctx.save_for_backward(x2, G, c, y, W_ih, W_hh, lens if lens is not None else torch.empty(0, device=x.device))
+        ctx.save_for_backward(x2, G, c, y, W_ih, W_hh, lens if lens is not None else torch.empty(0, device=x.device), *xpair)
         ctx.has_lens = lens is not None
+        ctx.has_xpair = len(xpair) == 2
         return y.view(B, T, 2 * H)
 
     @staticmethod
@@ -68,7 +69,8 @@ class BiLSTMFn(torch.autograd.Function):
             raise RuntimeError("BiLSTMFn.backward ran twice on the same graph: it turns the saved gate activations into "
                                "gradients in place (no retain_graph / double backward)")
         ctx._consumed = True
-        x2, G, c, y, W_ih, W_hh, lens = ctx.saved_tensors
+        x2, G, c, y, W_ih, W_hh, lens = ctx.saved_tensors[:7]
+        xpair = tuple(ctx.saved_tensors[7:9]) if ctx.has_xpair else None
         lens = lens if ctx.has_lens else None
         dy2 = dy.contiguous().view(B * T, 2 * H)
         amax = dy2.abs().amax().clamp_min(1e-30)
@@ -85,7 +87,7 @@ class BiLSTMFn(torch.autograd.Function):
         hp[:, :-1, H:] = y3[:, 1:, H:]                           # reverse direction: h_{t+1}
         hp = hp.view(B * T, 2 * H)
         if (ctx.box is not None and B * T >= 4096 and (8 * H) % 32 == 0 and I % 4 == 0 and H % 2 == 0 and
-                os.environ.get("RADMMM_LSTM_GRADS", "hip") != "torch"):
+                debug_env("RADMMM_LSTM_GRADS", "hip") != "torch"):
             # frame-rate batches: the four gradient GEMMs (226 + 57 GFLOP at the benchmark size, 2.5 ms on the fp32 library
             # GEMMs) on the split-f16 kernels: ONE transposing pass over dG feeds both weight gradients (contraction over
             # frames) and yields the bias gradient as its column sums; the input gradient is a row GEMM on dG's split copy.
@@ -95,8 +97,8 @@ class BiLSTMFn(torch.autograd.Function):
             SG = ops.grad_scale(box, dy2)
             flag = ops.sat_flag_of(box)
             gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)       # row-major split pair of dG: operand of all four GEMMs
-            if (ctx.xpair is not None and T >= 32 and B <= 1024 and (4 * H) % 8 == 0 and
-                    os.environ.get("RADMMM_WGRAD_RM", "1") != "0"):
+            if (xpair is not None and T >= 32 and B <= 1024 and (4 * H) % 8 == 0 and
+                    debug_env("RADMMM_WGRAD_RM", "1") != "0"):
                 # weight gradients straight from the row-major pairs (radmmm_wgrad_rm: transposition in the LDS read); the
                 # pair of x was made for the forward projection, the pairs of h_prev (one per direction, each with its own
                 # 16-byte aligned row pitch) cost what the transposed copy did
@@ -104,7 +106,7 @@ class BiLSTMFn(torch.autograd.Function):
                 Hq = ops.round_up(H, 8)
                 hpf = ops.split_f16(hp[:, :H].contiguous(), H, 1.0, Hq)
                 hpr = ops.split_f16(hp[:, H:].contiguous(), H, 1.0, Hq)
-                dW_ih = ops.wgrad_rm_slabs((gh, gl), ctx.xpair, B, T, 8 * H, I, 1, 1, 1.0 / SG).sum(0)[0]
+                dW_ih = ops.wgrad_rm_slabs((gh, gl), xpair, B, T, 8 * H, I, 1, 1, 1.0 / SG).sum(0)[0]
                 dW_hh_f = ops.wgrad_rm_slabs((gh[:, :4 * H], gl[:, :4 * H]), hpf, B, T, 4 * H, H, 1, 1, 1.0 / SG).sum(0)[0]
                 dW_hh_r = ops.wgrad_rm_slabs((gh[:, 4 * H:], gl[:, 4 * H:]), hpr, B, T, 4 * H, H, 1, 1, 1.0 / SG).sum(0)[0]
             else:

@@ -108,15 +108,16 @@ def weightnorm_fwd(v: torch.Tensor, g: torch.Tensor, ldw: Optional[int] = None,
     return W, inv
 
 
-def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0)):
-    """dW_slabs [S, taps, Cout, ldw] -> (dv like v, dg like g)."""
+def weightnorm_bwd(v, g, inv, dW_slabs: torch.Tensor, ldw: int, perm=(0, 0, 0), poison: Optional[torch.Tensor] = None):
+    """dW_slabs [S, taps, Cout, ldw] -> (dv like v, dg like g).  poison (device fp32[1], GradScale.poison): 0, or NaN when
+    the pass's incoming gradient was not finite -- added to dg so that the non-finite pass stays visible to the caller."""
     Cout, Cin, taps = v.shape
     S = dW_slabs.shape[0]
     dv = grad_out(v)
     dg = grad_out(g)
     check(lib.radmmm_weightnorm_bwd(ptr(v), ptr(g), ptr(inv), ptr(dW_slabs), S,
                                     dW_slabs.stride(0), ptr(dv), ptr(dg), Cout, Cin, taps, ldw,
-                                    perm[0], perm[1], perm[2], stream()), "weightnorm_bwd")
+                                    perm[0], perm[1], perm[2], ptr(poison), stream()), "weightnorm_bwd")
     return dv, dg
 
 
@@ -302,6 +303,27 @@ class AffineFlowStepFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------
 # squeeze (nn.Unfold group g) folded into the assembly of the channels-last operands
 # ---------------------------------------------------------------------------------------
+def _squeeze_rows_into(x, out2d, B, C, T, g, ld, col0):
+    """nn.Unfold's squeeze of x [B, C, T] into columns [col0, col0 + C*g) of the channels-last rows out2d [B*(T//g), ld].
+    The kernel's tile covers group sizes dividing 64 (every shipped config: 2); other reference-legal group sizes
+    (n_group_size 3, 5, 6 ...) take the same index permutation through stock device ops."""
+    if 64 % g == 0:
+        check(lib.radmmm_squeeze_rows(ptr(x), ptr(out2d), B, C, T, g, ld, col0, stream()), "squeeze_rows")
+        return
+    Tg = T // g
+    out2d.view(B, Tg, ld)[:, :, col0: col0 + C * g] = x[:, :, : Tg * g].reshape(B, C, Tg, g).permute(0, 2, 1, 3).reshape(B, Tg, C * g)
+
+
+def _unsqueeze_rows_from(gout2d, gin, B, C, T, g, ld, col0):
+    """gradient scatter of _squeeze_rows_into: gin [B, C, T] (frames beyond g * (T // g) get zero)"""
+    if 64 % g == 0:
+        check(lib.radmmm_unsqueeze_rows(ptr(gout2d), ptr(gin), B, C, T, g, ld, col0, stream()), "unsqueeze_rows")
+        return
+    Tg = T // g
+    gin.zero_()
+    gin[:, :, : Tg * g] = gout2d.view(B, Tg, ld)[:, :, col0: col0 + C * g].reshape(B, Tg, C, g).permute(0, 2, 1, 3).reshape(B, C, Tg * g)
+
+
 class SqueezeRowsFn(torch.autograd.Function):
     """x [B, C, T] (reference layout) -> channels-last rows [B*T', ld], T' = T // g, the C*g squeezed channels (order
     c*g + k, nn.Unfold's) at columns [col0, col0 + C*g), zeros elsewhere (decoders.py:118-122,178)."""
@@ -313,7 +335,7 @@ class SqueezeRowsFn(torch.autograd.Function):
         x = f32c(x)
         Tg = T // g
         out = (torch.zeros if ld != C * g else torch.empty)(B * Tg, ld, device=x.device, dtype=torch.float32)
-        check(lib.radmmm_squeeze_rows(ptr(x), ptr(out), B, C, T, g, ld, col0, stream()), "squeeze_rows")
+        _squeeze_rows_into(x, out, B, C, T, g, ld, col0)
         ctx.dims = (B, C, T, g, ld, col0)
         return out
 
@@ -322,7 +344,7 @@ class SqueezeRowsFn(torch.autograd.Function):
     def backward(ctx, gout):
         B, C, T, g, ld, col0 = ctx.dims
         gin = torch.empty(B, C, T, device=gout.device, dtype=torch.float32)
-        check(lib.radmmm_unsqueeze_rows(ptr(f32c(gout)), ptr(gin), B, C, T, g, ld, col0, stream()), "unsqueeze_rows")
+        _unsqueeze_rows_from(f32c(gout), gin, B, C, T, g, ld, col0)
         return gin, None, None, None
 
 
@@ -345,7 +367,7 @@ class LstmInputFn(torch.autograd.Function):
                   g if energy is not None else 0]
         I = sum(widths)
         x = torch.empty(B, Tg, I, device=context.device, dtype=torch.float32)
-        check(lib.radmmm_squeeze_rows(ptr(f32c(context)), ptr(x), B, Ct, T, g, I, 0, stream()), "squeeze_rows")
+        _squeeze_rows_into(f32c(context), x.view(B * Tg, I), B, Ct, T, g, I, 0)
         o = widths[0]
         x[:, :, o: o + widths[1]] = spk[:, None, :]
         o += widths[1]
@@ -372,7 +394,7 @@ class LstmInputFn(torch.autograd.Function):
         gctx = None
         if need[1]:
             gctx = torch.empty(B, Ct, T, device=gx.device, dtype=torch.float32)
-            check(lib.radmmm_unsqueeze_rows(ptr(gx), ptr(gctx), B, Ct, T, g, I, 0, stream()), "unsqueeze_rows")
+            _unsqueeze_rows_from(gx.view(B * Tg, I), gctx, B, Ct, T, g, I, 0)
         o = widths[0]
         gspk = gx[:, :, o: o + widths[1]].sum(1) if need[2] else None
         o += widths[1]
@@ -528,7 +550,7 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     Cout, Cin, taps = v.shape
     # split-f16 path for the frame-rate convs (FiLM stacks: N = B*T' rows); text-rate convs (encoder,
     # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
-    min_rows = int(os.environ.get("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
+    min_rows = int(debug_env("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
     prec = os.environ.get("RADMMM_PRECISION", "f8x")
     # "f8x" (FP8 cross terms) is for the WN stack of the affine flows; the FiLM convs of the spline flows keep the three
     # f16 products: the piecewise-quadratic transform's log-Jacobian amplifies errors of its 65 parameters per element
@@ -604,7 +626,7 @@ def stft_mel(audio: torch.Tensor, basis: torch.Tensor, mel_basis: torch.Tensor, 
 # ---------------------------------------------------------------------------------------
 # affine flow step on the split-f16 GEMM path (fp32-class accuracy on the f16 matrix cores)
 # ---------------------------------------------------------------------------------------
-from ._lib import rowgemm_h3  # noqa: E402
+from ._lib import rowgemm_h3, debug_env  # noqa: E402
 
 W_SCALE = 256.0          # power-of-two scale of the split weights (|w| <= |g| ~ 1 after weight norm)
 # RADMMM_PRECISION / gemm_precision -> product scheme of radmmm_rowgemm_h3 ("fp32" uses the fp32-MFMA kernels instead)
@@ -745,8 +767,8 @@ def wgrad_h3_slabs(gy_t, x_t, Mc, Nc, ldp, taps, dil, acc_scale, nprod=3):
     assert Kt == Kt2
     tiles = int(lib.radmmm_wgrad_h3_tiles(Mc, Nc, taps))
     S = pick_splits(tiles, Kt, slots=int(lib.radmmm_gemm_cu_slots()))            # one workgroup per CU
-    if os.environ.get("RADMMM_WGRAD_SPLITS"):         # experiments
-        S = int(os.environ["RADMMM_WGRAD_SPLITS"])
+    if debug_env("RADMMM_WGRAD_SPLITS"):              # experiments
+        S = int(debug_env("RADMMM_WGRAD_SPLITS"))
     P = torch.empty(S, taps, Mc, ldp, device=gh.device, dtype=torch.float32)
     if ldp != Nc:
         P.zero_()
@@ -776,26 +798,45 @@ def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale, lens=Non
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
     a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), a device-side
-    saturation flag OR-ed by every split producer that had to clamp, and the bookkeeping that keeps both off the host's
-    critical path.
+    flag word OR-ed by every split producer (bit 0: an element exceeded the fp16 range and was clamped; bit 1: an element's
+    8-bit cross-term parts exceeded e4m3's 448 -- that element keeps single-fp16-product accuracy, ~5e-4, instead of the
+    scheme's 4e-5), and the bookkeeping that keeps both off the host's critical path.
 
     Steady state has NO host synchronisation: the first backward node of pass k queues `amax(|g|)` of its incoming
     gradient; the next forward queues an asynchronous copy of (amax, flag) to pinned memory behind an event and clears the
-    flag; the first backward node of a later pass polls that event (query, never wait), adopts the new S and raises
-    FloatingPointError if the flag was set -- the gradients of THAT earlier pass were clamped (dict-like access keeps
-    the "S" key of the former plain-dict box working).  Only the very first pass of a module synchronises once.
-    `check()` is the synchronous form (end of a step, tests); RADMMM_CHECK_SATURATION=1 calls it after every flow step."""
+    flag; the first backward node of a later pass polls that event (query, never wait) and adopts the new S.  Only the very
+    first pass of a module synchronises once.
 
-    def __init__(self):
+    What happens to a pass that clamped (`reports`, counters `saturated_passes` / `x8_saturated_passes` /
+    `nonfinite_passes`):
+      * default: one RuntimeWarning per process and kind, the scale is refreshed, training goes on (a raise one step
+        later would kill an AMP loop that is about to skip the step anyway, and under DDP only the affected rank would
+        raise and the others hang in the next collective);
+      * RADMMM_CHECK_SATURATION=1 (or strict=True): FloatingPointError -- synchronously after every flow step
+        (`check()`), and for the deferred report after the flag has been MAX-all-reduced when a process group is active,
+        so every rank raises together.
+    Non-finite incoming gradients (an fp16-AMP GradScaler overflow step): the split producers clamp NaN / Inf to finite
+    values, so the pass's amax is tracked with NaN propagation and `poison` (device fp32[1] = amax * 0: 0, or NaN) is
+    added to every weight-norm gain gradient of the pass (radmmm_weightnorm_bwd): GradScaler / clip_grad_norm_ see the
+    non-finite step and skip it as they would with the reference; S keeps its previous value."""
+
+    def __init__(self, strict: Optional[bool] = None):
         self.S = None
         self.flag = None          # device int32[1]
         self.amax = None          # device fp32[1]
+        self.poison = None        # device fp32[1]: 0, or NaN when this pass's incoming gradient is not finite
         self._host = None         # pinned fp32[2]: amax, flag
         self._event = None
         self._pending = False
         self._fwd_id = 0
         self._bwd_id = -1
         self._stats_fwd = -1      # forward id whose backward produced the device stats
+        self.strict = strict
+        self.saturated_passes = 0
+        self.x8_saturated_passes = 0
+        self.nonfinite_passes = 0
+
+    _warned = set()
 
     # the state is per process and per device (a CUDA event, pinned memory): copies / pickles of the owning module start
     # fresh (copy.deepcopy(model) for an EMA copy, torch.save(model))
@@ -806,7 +847,7 @@ class GradScale:
         self.__init__()
 
     def __deepcopy__(self, memo):
-        return GradScale()
+        return GradScale(self.strict)
 
     # dict-like compatibility ("S")
     def get(self, k, d=None):
@@ -820,9 +861,13 @@ class GradScale:
         if self.flag is None or self.flag.device != dev:
             self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
             self.amax = torch.zeros(1, device=dev, dtype=torch.float32)
+            self.poison = torch.zeros(1, device=dev, dtype=torch.float32)
             self._host = torch.zeros(2, dtype=torch.float32).pin_memory()
             self._event = torch.cuda.Event()
             self._pending = False
+
+    def _is_strict(self) -> bool:
+        return self.strict if self.strict is not None else os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1"
 
     @staticmethod
     def _pow2(amax: float) -> float:
@@ -830,15 +875,37 @@ class GradScale:
             return 1.0
         return float(2.0 ** max(-40, min(40, math.floor(math.log2(16.0 / amax)))))
 
+    def _report(self, kind: str, msg: str):
+        if self._is_strict() and kind == "f16":             # (the e4m3 saturation is a soft loss of accuracy: never an error)
+            raise FloatingPointError(msg)
+        if kind not in GradScale._warned:
+            GradScale._warned.add(kind)
+            import warnings
+            warnings.warn(msg + "  (reported once per process; RADMMM_CHECK_SATURATION=1 turns it into an error)", RuntimeWarning)
+
     def _consume(self):
-        """host copy is complete: adopt the scale, report a saturated pass"""
+        """host copy is complete: adopt the scale, report what the producers flagged in that earlier pass"""
         self._pending = False
-        amax, flag = float(self._host[0]), float(self._host[1])
-        self.S = self._pow2(amax) if amax > 0 else self.S
-        if flag != 0.0:
-            raise FloatingPointError(
-                "split-f16 gradient saturated in an earlier backward pass: a gradient element exceeded 2^12 x the first "
-                "gradient's maximum and was clamped (that pass's gradients are not exact; the scale has been refreshed)")
+        amax, flag = float(self._host[0]), int(self._host[1])
+        if not math.isfinite(amax):
+            # non-finite upstream gradient (AMP overflow step): that pass was poisoned (see the class docstring); keep S,
+            # and do not report the clamping the NaN / Inf values caused
+            self.nonfinite_passes += 1
+            self._report("nonfinite", "non-finite gradient entered the split-operand backward: the pass's weight-norm gain "
+                                      "gradients were set to NaN, the gradient scale keeps its value")
+            return
+        if amax > 0:
+            self.S = self._pow2(amax)
+        if flag & 2:
+            self.x8_saturated_passes += 1
+            self._report("x8", "FP8 cross terms saturated in an earlier pass: split-operand elements beyond e4m3's range (activations "
+                               "above ~112, gradient elements above ~2-3x the first gradient's maximum) lost their cross-term correction (single-fp16-product accuracy, ~5e-4, for "
+                               "those elements); RADMMM_PRECISION=h3 has no such limit")
+        if flag & 1:
+            self.saturated_passes += 1
+            self._report("f16", "split-f16 gradient saturated in an earlier backward pass: a gradient element exceeded 2^12 x the "
+                                "first gradient's maximum and was clamped (that pass's gradients are not exact; the scale has been "
+                                "refreshed)")
 
     def new_forward(self, dev):
         """called by the owning module at the start of a training forward"""
@@ -847,8 +914,11 @@ class GradScale:
             self._consume()
         if self._stats_fwd == self._fwd_id and not self._pending:
             # publish the stats of the backward that followed the previous forward, then re-arm the flag
+            flagf = self.flag.float()
+            if self._is_strict() and torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.all_reduce(flagf, op=torch.distributed.ReduceOp.MAX)      # every rank raises together
             self._host[0:1].copy_(self.amax, non_blocking=True)
-            self._host[1:2].copy_(self.flag.float(), non_blocking=True)
+            self._host[1:2].copy_(flagf, non_blocking=True)
             self._event.record()
             self.flag.zero_()
             self._pending = True
@@ -863,19 +933,26 @@ class GradScale:
                 self._consume()
             if self.S is None:                              # first pass of this module: one synchronisation
                 self.S = self._pow2(float(g.abs().max()))
-            torch.amax(g.detach().abs().reshape(-1), dim=0, keepdim=True, out=self.amax)
+            torch.amax(g.detach().abs().reshape(-1), dim=0, keepdim=True, out=self.amax)     # (propagates NaN)
+            torch.mul(self.amax, 0.0, out=self.poison)                                     # 0, or NaN for Inf / NaN
             self._stats_fwd = self._fwd_id
         return self.S
 
     def check(self) -> None:
-        """synchronous: raise FloatingPointError if a split producer has clamped since the flag was last cleared"""
+        """synchronous: raise FloatingPointError if a split producer has clamped since the flag was last cleared (fp16
+        range; the softer e4m3 saturation of the cross terms is counted and warned about, see `reports`)"""
         if self._pending:
             self._event.synchronize()
             self._consume()
-        if self.flag is not None and int(self.flag.item()) != 0:
-            self.flag.zero_()
-            raise FloatingPointError("split-f16 gradient saturated: a gradient element exceeds 2^12 x the first gradient's "
-                                     "maximum of this backward pass and was clamped")
+        if self.flag is not None:
+            f = int(self.flag.item())
+            if f:
+                self.flag.zero_()
+            if f & 2:
+                self.x8_saturated_passes += 1
+            if f & 1:
+                raise FloatingPointError("split-f16 gradient saturated: a gradient element exceeds 2^12 x the first gradient's "
+                                         "maximum of this backward pass and was clamped")
 
 
 def grad_scale(box, g: torch.Tensor) -> float:
@@ -890,6 +967,10 @@ def grad_scale(box, g: torch.Tensor) -> float:
 
 def sat_flag_of(box) -> Optional[torch.Tensor]:
     return box.flag if isinstance(box, GradScale) else None
+
+
+def poison_of(box) -> Optional[torch.Tensor]:
+    return box.poison if isinstance(box, GradScale) else None
 
 
 def check_saturation(box) -> None:
@@ -931,7 +1012,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # (radmmm_wgrad_rm): the pairs of X0 and of every hidden state are kept for backward; under the FP8-cross scheme
         # the GEMMs' second operand array is the 8-bit cross array, so the producers write the fp16 lo part as well.
         use_rm = (NPR in (2, 3) and T >= 32 and B <= 1024 and any(ctx.needs_input_grad) and
-                  os.environ.get("RADMMM_WGRAD_RM", "1") != "0")
+                  debug_env("RADMMM_WGRAD_RM", "1") != "0")
         lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
         z1 = _empty(N, ZLD, like=z_in)
         rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
@@ -1030,6 +1111,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
         SG = grad_scale(box, g_zout)
         flag = sat_flag_of(box)
+        poison = poison_of(box)
         fa = fmt_a(NPR)
         inv_acc = 1.0 / (SG * W_SCALE)
         gin = dict(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, acc_scale=inv_acc, T=T, sat_flag=flag)
@@ -1055,7 +1137,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # extra_tap) -- and dL/dH_{j+1} itself never exists in memory.  For that the split copies of g_conv_{j+1} and of
         # gQ_j live in one [2N, Wc] pair (rows [0, N) / [N, 2N)) and the transposed weights of in_layer j+1 and res_skip j
         # in one [taps + 1] tap stack.  RADMMM_FUSED_DGRAD=0 keeps the two-launch arrangement (A/B runs).
-        fuse = os.environ.get("RADMMM_FUSED_DGRAD", "1") != "0"
+        fuse = debug_env("RADMMM_FUSED_DGRAD", "1") != "0"
         pair_h = pair_l = None           # [2N, Wc]: g_conv_{j+1} split in the first half, gQ_j goes into the second
         WT_prev = None                   # (WiT stack [kt+1][Wc][Wc] of layer j+1 with its last slot free, kt, dil)
         x_prev = None
@@ -1079,7 +1161,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)
                 x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
-            g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc)
+            g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc, poison=poison)
             g_conv = _empty(N, Wc, like=z_in)
             keep_pair = fuse and j > 0               # g_conv_j's split copy becomes the first half of the next pair
             nh, nlo = _halves(2 * N if keep_pair else N, Wc, like=z_in)
@@ -1114,7 +1196,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 x_prev = None
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d)
                 slabs = wgrad_slabs(g_conv, Wc, H[j], Wc, Wc, T, lens, taps=kt, dil=d, x_mask_mode=1 if partial else 0)
-            g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc)
+            g_in[3 * j], g_in[3 * j + 1] = weightnorm_bwd(in_p[3 * j], in_p[3 * j + 1], inv_i[j], slabs, Wc, poison=poison)
             if keep_pair:
                 # in_layer j's data gradient is deferred into layer j-1's fused launch: transposed weights into a tap
                 # stack with one free slot for res_skip j-1's
@@ -1144,7 +1226,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                                   sum_out=grad_out(start_b))
             x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, WPR)
-        g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm)
+        g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm, poison=poison)
         WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)                      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)
         rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc, **gin)
@@ -1185,10 +1267,9 @@ class ConvNormH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
         # the row-major split pair of x is the weight gradient's operand (radmmm_wgrad_rm) when it is an fp16 pair
-        ctx.xpair = (xh, xl) if (NPR == 3 and T >= 32 and B <= 1024 and Cin % 8 == 0 and
-                                 os.environ.get("RADMMM_WGRAD_RM", "1") != "0") else None
+        ctx.has_xpair = bool(NPR == 3 and T >= 32 and B <= 1024 and Cin % 8 == 0 and debug_env("RADMMM_WGRAD_RM", "1") != "0")
         ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
-                              inv if inv is not None else v, y)
+                              inv if inv is not None else v, y, *((xh, xl) if ctx.has_xpair else ()))
         return y
 
     @staticmethod
@@ -1197,7 +1278,8 @@ class ConvNormH3Fn(torch.autograd.Function):
         meta = ctx.meta
         B, T, dil = meta["B"], meta["T"], meta["dil"]
         partial, mask_out, act = meta["partial"], meta["mask_out"], meta["act"]
-        x, v, g, lens, Wh, Wl, inv, y = ctx.saved_tensors
+        x, v, g, lens, Wh, Wl, inv, y = ctx.saved_tensors[:8]
+        xpair = tuple(ctx.saved_tensors[8:10]) if ctx.has_xpair else None
         lens = lens if ctx.has_lens else None
         NPR = meta.get("nprod", 3)
         WPR = 3 if NPR == 2 else NPR
@@ -1215,16 +1297,16 @@ class ConvNormH3Fn(torch.autograd.Function):
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
                                   taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), X8_GRAD_EXP, flag), stream()),
               "dact_mul")
-        if ctx.xpair is not None:
+        if xpair is not None:
             g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
-            slabs = wgrad_rm_slabs((gph, gpl), ctx.xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)
+            slabs = wgrad_rm_slabs((gph, gpl), xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)
         else:
             gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
                                                colsum=(2 if partial else 0, lens, taps, dil))
             x_t = transpose_split_act(x, Cin, B, T, lens, 1 if partial else 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
             slabs = wgrad_h3_slabs(gy_t, x_t, Cout, Cin, Cin, taps, dil, 1.0 / SG, WPR)
         if ctx.has_g:
-            g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin)
+            g_v, g_g = weightnorm_bwd(v, g, inv, slabs, Cin, poison=poison_of(box))
         else:
             g_v, g_g = slabs.sum(0).permute(1, 2, 0).contiguous(), None
         gx = None

@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tests force kernel choices (tile sizes, product schemes on tiny batches, the persistent LSTM): those switches are
+    # honoured only under RADMMM_DEBUG=1 (rad_mmm_amd/_lib.py debug_env, csrc/error.cpp), set before the library loads
+    os.environ.setdefault("RADMMM_DEBUG", "1")
     # the HIP library is a build artefact (git-ignored): cross-compile it if this is a fresh tree
     if not os.path.exists(os.path.join(ROOT, "rad_mmm_amd", "libradmmm_hip.so")):
         import subprocess

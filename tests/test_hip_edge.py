@@ -289,13 +289,74 @@ def test_saturation_is_detected_by_default(monkeypatch):
         dec.check_saturation()                               # ... (a) reported synchronously
     step()                                                   # saturates again; flag published by the next forward
     monkeypatch.setattr(ops, "grad_scale", real)
+    before = dec._grad_scale.saturated_passes
+    ops.GradScale._warned.discard("f16")
+    with pytest.warns(RuntimeWarning, match="saturated"):
+        for _ in range(4):                                   # (b) a later pass picks the flag up by polling: a warning
+            torch.cuda.synchronize()                         #     (once per process) and a counter, no exception by default
+            time.sleep(0.01)
+            step()
+    assert dec._grad_scale.saturated_passes > before
+    step()
+    dec.check_saturation()                                   # recovered
+    # strict mode: the deferred report raises
+    monkeypatch.setattr(ops, "grad_scale", lambda box, g: real(box, g) * 2.0 ** 30)
+    step()
+    monkeypatch.setattr(ops, "grad_scale", real)
+    dec._grad_scale.strict = True
     with pytest.raises(FloatingPointError, match="saturated"):
-        for _ in range(4):                                   # (b) a later pass picks the flag up by polling
+        for _ in range(4):
             torch.cuda.synchronize()
             time.sleep(0.01)
             step()
+    dec._grad_scale.strict = None
+
+
+def test_nonfinite_upstream_gradient_poisons_the_pass_and_keeps_the_scale(monkeypatch):
+    """An fp16-AMP overflow step hands the decoder an Inf / NaN gradient.  The split producers clamp those to finite
+    values, so the pass is marked instead: every weight-norm gain gradient becomes NaN (what GradScaler / clip_grad_norm_
+    look at), nothing raises -- not one step later either -- and the gradient scale keeps its value for the next pass."""
+    import time
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.delenv("RADMMM_CHECK_SATURATION", raising=False)
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(T(S.procedural_decoder_state(S.decoder_state_shapes(cfg))))
+    dec = dec.to(DEV).train()
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in S.synthetic_batch(2, 64, cfg, seed=3, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+
+    def step(mult=1.0):
+        dec.zero_grad(set_to_none=True)
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        (crit(out, None, sl, 0)["loss_mel"][0] * mult).backward()
+
     step()
-    dec.check_saturation()                                   # recovered
+    step()
+    torch.cuda.synchronize()
+    S0 = dec._grad_scale.S
+    gains = [p for n, p in dec.named_parameters() if n.endswith("weight_g") and "affine_param_predictor" in n]
+    assert gains and all(torch.isfinite(p.grad).all() for p in gains)
+    step(float("inf"))                                       # the scaled loss overflowed
+    torch.cuda.synchronize()
+    assert all(torch.isnan(p.grad).all() for p in gains)     # visible to GradScaler.unscale_ / clip_grad_norm_
+    total = torch.nn.utils.clip_grad_norm_(dec.parameters(), 1.0)
+    assert not torch.isfinite(total)
+    ops_mod = __import__("rad_mmm_amd.ops", fromlist=["GradScale"])
+    ops_mod.GradScale._warned.discard("nonfinite")
+    with pytest.warns(RuntimeWarning, match="non-finite"):
+        for _ in range(3):                                   # later passes: the report is a warning, the scale is kept
+            time.sleep(0.01)
+            step()
+            torch.cuda.synchronize()
+    assert dec._grad_scale.nonfinite_passes == 1 and dec._grad_scale.S == S0
+    assert all(torch.isfinite(p.grad).all() for p in gains)
 
 
 def test_batch_shape_changes_between_steps():
