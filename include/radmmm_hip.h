@@ -438,6 +438,15 @@ int radmmm_wgrad_rm(const void* GYh, const void* GYl, int ldg, const void* Xh, c
                     const int32_t* lens, int x_mask, float* P, int ldp, int64_t split_stride, int Mc, int Nc, int taps,
                     int dil, int splits, float acc_scale, radmmm_stream_t stream);
 
+/* The same weight gradient under the FP8-cross scheme (csrc/wgrad_rm8.hip; common.py:816-835 backward,
+ * partialconv1d.py:82): GYh.Xh on the f16 matrix pipe + both cross terms GYh.Xl + GYl.Xh in one block-scaled FP8 MFMA per
+ * 32-frame K step -- two thirds of radmmm_wgrad_rm's MFMA work.  GYx / Xx are the tensors' 8-bit cross arrays
+ * (RADMMM_SPLIT_X8A, written with exponents g8_exp / x8_exp); only their lo8 halves are read, the hi8 parts are derived
+ * from the fp16 hi planes in registers.  No fp16 lo array is involved.  ldg, ldx multiples of 32. */
+int radmmm_wgrad_rm8(const void* GYh, const void* GYx, int ldg, int g8_exp, const void* Xh, const void* Xx, int ldx, int x8_exp,
+                     int R, int T, const int32_t* lens, int x_mask, float* P, int ldp, int64_t split_stride, int Mc, int Nc,
+                     int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream);
+
 /* Bidirectional single-layer LSTM, recurrent part (reference: the decoder's context LSTM,
  * models/radmmm.py:141-146 = torch.nn.LSTM(bidirectional, batch_first) on a packed batch; gate order
  * i, f, g, o; frames t >= lens[b] produce h = c = 0 as pad_packed_sequence does).

@@ -144,6 +144,7 @@ def _load() -> C.CDLL:
         "radmmm_wgrad_h3_tiles": [i, i, i],
         "radmmm_wgrad_rm_tiles": [i, i, i],
         "radmmm_wgrad_rm": [p, p, i, p, p, i, i, i, p, i, p, i, i64, i, i, i, i, i, f, p],
+        "radmmm_wgrad_rm8": [p, p, i, i, p, p, i, i, i, i, p, i, p, i, i64, i, i, i, i, i, f, p],
         "radmmm_betabinom_prior": [i, i, C.c_double, p, p],
         "radmmm_prior_zoom_batch": [p, i, p, i, i, p],
         "radmmm_energy_average": [p, p, i, i, i, i, p],

@@ -1,0 +1,373 @@
+// Weight gradient of a (dilated, k-tap) conv on ROW-MAJOR split operands under the FP8-cross scheme (round 3):
+//   P[split][tap][m][n] = acc_scale * sum_f GY[f][m] * X[f + s][n],   s = (tap - taps/2) * dil
+// as wgrad_rm.hip (same tile machine, masking rules, split-K slabs, XCD-aware tile order), but the split product is
+//   GYh.Xh                on the f16 pipe (two v_mfma_f32_32x32x16_f16 per 32-frame K step and 32x32 tile), and
+//   GYh.Xl + GYl.Xh       as ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (twice the f16 rate),
+// i.e. two thirds of wgrad_rm's MFMA time -- that kernel is MFMA-bound (63 % busy, profiles/r02_pmc_wgrad_rm.txt).
+// Operands per tensor: the fp16 hi plane [frames][ld] and an 8-bit lo plane (e4m3 of lo * 2^(11 + e)): the lo8 half of the
+// tensor's 8-bit cross array (RADMMM_SPLIT_X8A: per 32 channels 64 bytes [hi8 x 32 | lo8 x 32], the array the GEMM
+// epilogues write anyway) -- described by (row pitch, block stride, block offset) so that a plain lo8 plane fits too.
+// No fp16 lo array is needed any more.  The hi8 halves of the FP8 operands are NOT read: they are a function of the fp16 hi
+// fragments already in registers (v_cvt_scalef32_pk_fp8_f16 under MODE.FP16_OVFL = saturating, round to nearest even;
+// measured semantics: tools/cvt_tr_probe.hip, profiles/r03_cvt_tr_probe.txt), 8 conversions per fragment pair under
+// the MFMAs.
+// LDS stage (48 KiB): GYh, Xh 32 frames x 512 B each (layout and ds_read_b64_tr_b16 fragments of wgrad_rm.hip), GYl8, Xl8
+// 32 frames x 256 B; an 8-bit fragment (8 consecutive frames of one channel) is one ds_read_b64_tr_b8 -- a 16-lane group
+// reads an [8 frames][16 channels] byte block and lane p receives column p (measured) -- with the 32-byte channel units of
+// frame row r stored XOR-ed by (r & 7): the eight rows of a read fall into eight different bank groups.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned int* lds_u32_ptr;
+
+constexpr int BK = 32, TM = 256, TN = 256;          // frames per K step, output tile
+constexpr int HARR = BK * TM * 2;                    // bytes of one fp16 hi array in a stage: 32 rows x 512 B
+constexpr int LARR = BK * TM;                        // bytes of one lo8 array in a stage: 32 rows x 256 B
+constexpr int STAGE = 2 * HARR + 2 * LARR;           // GYh, Xh, GYl8, Xl8 = 48 KiB
+constexpr int SMEM = 2 * STAGE;                      // 96 KiB; the epilogue reuses it
+constexpr int OOB = 0x7fffffff;
+
+struct Rm8Args {
+  const _Float16 *GYh, *Xh;               // [R][ld] row-major fp16 hi planes
+  const unsigned char *GYl, *Xl;         // 8-bit arrays holding the lo8 parts
+  int gl_pitch, gl_bstride, gl_boff;     // lo8 of GY channel c of frame f: GYl[f * pitch + (c >> 5) * bstride + boff + (c & 31)]
+  int xl_pitch, xl_bstride, xl_boff;
+  int g8_exp, x8_exp;                    // the lo8 parts hold lo * 2^(11 + e)
+  const int* lens;                       // [R / T] or null; used when x_mask
+  int x_mask;
+  int R, T, ldg, ldx, Mc, Nc, taps, dil, splits;
+  float* P; int ldp; long long split_stride;
+  float acc_scale;
+  int g_bytes, x_bytes, gl_bytes, xl_bytes;
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
+struct Frag { i32x2 lo, hi; };
+// fp16 hi planes: LDS address of this lane's 8 bytes of (32-channel unit u, k block kb) -- rows k and k + 4 of the lane's
+// half k block (wgrad_rm.hip)
+__device__ __forceinline__ unsigned frag_addr(const unsigned char* arr, int u, int kb, int lane) {
+  const int p = lane & 15, gq = lane >> 4;
+  const int k = 16 * kb + 8 * (gq >> 1) + (p >> 2);
+  const int off = k * 512 + ((u ^ (p >> 2)) << 6) + (gq & 1) * 32 + (p & 3) * 8;
+  return (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(arr + off));
+}
+__device__ __forceinline__ void frag_issue(Frag& f, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ f16x8 frag_val(const Frag& f) {
+  return __builtin_bit_cast(f16x8, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3));
+}
+// lo8 planes: this lane's (channel (gq & 1) * 16 + p of unit u, frames 8 h .. 8 h + 7 of k block 0) -- row r = 8 h + (p >> 1)
+// supplies the 8-byte segment (p & 1); k block 1 lies 16 rows = 4096 bytes further (same r & 7)
+__device__ __forceinline__ unsigned frag8_addr(const unsigned char* arr, int u, int lane) {
+  const int p = lane & 15, gq = lane >> 4;
+  const int r = 8 * (gq >> 1) + (p >> 1);
+  const int off = r * 256 + ((u ^ (r & 7)) << 5) + (gq & 1) * 16 + (p & 1) * 8;
+  return (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(arr + off));
+}
+__device__ __forceinline__ void frag8_issue(Frag& f, unsigned addr) {      // .lo: k block 0, .hi: k block 1
+  asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:4096" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+}
+// wait until at most N LDS operations issued AFTER these fragments are outstanding (LDS returns in order)
+template <int N>
+__device__ __forceinline__ void frag_wait3(Frag& a, Frag& b, Frag& c) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi) : "n"(N) : "memory");
+}
+// e4m3(hi * 2^e) of the 16 fp16 values of a fragment pair (k block 0, k block 1) -> 16 bytes in fragment order.
+// inv = 2^-e: the instruction divides by its scale operand; saturating under MODE.FP16_OVFL.
+__device__ __forceinline__ i32x4 hi8_of(const Frag& f0, const Frag& f1, float inv) {
+  i32x4 r;
+  const int src[4] = {f0.lo[0], f0.lo[1], f0.hi[0], f0.hi[1]};
+  const int src1[4] = {f1.lo[0], f1.lo[1], f1.hi[0], f1.hi[1]};
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    i16x2 o = {0, 0};
+    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_bit_cast(f16x2, src[2 * d]), inv, false);
+    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_bit_cast(f16x2, src[2 * d + 1]), inv, true);
+    r[d] = __builtin_bit_cast(int, o);
+    i16x2 q = {0, 0};
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(f16x2, src1[2 * d]), inv, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(f16x2, src1[2 * d + 1]), inv, true);
+    r[2 + d] = __builtin_bit_cast(int, q);
+  }
+  return r;
+}
+
+// accumulators of row block I -> LDS -> coalesced float4 rows of P (as wgrad_rm.hip's store_blocks)
+template <int I>
+__device__ __forceinline__ void store_blocks(const f32x16 (&acc)[8][2], float* smf, float* P, int ldp, int Mc, int Nc, float sc,
+                                             int m0, int n0, int tid, int lane, int wave, bool vec_ok) {
+  if constexpr (I < 8) {
+    if (I > 0) radmmm::lds_barrier();
+    float* wbase = smf + (4 * (lane >> 5)) * TN + wave * 64 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * TN + j * 32] = acc[I][j][e] * sc;
+    radmmm::lds_barrier();
+    const int c4 = (tid & 63) * 4, col = n0 + c4;
+#pragma unroll 4
+    for (int k = 0; k < 8; ++k) {
+      const int rl = k * 4 + (tid >> 6);
+      const int row = m0 + I * 32 + rl;
+      if (row < Mc && col < Nc) {
+        const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * TN + c4);
+        if (vec_ok && col + 3 < Nc) {
+          *reinterpret_cast<float4*>(P + (long long)row * ldp + col) = a4;
+        } else {
+          const float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < Nc) P[(long long)row * ldp + col + e] = v[e];
+        }
+      }
+    }
+    store_blocks<I + 1>(acc, smf, P, ldp, Mc, Nc, sc, m0, n0, tid, lane, wave, vec_ok);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");      // MODE.FP16_OVFL: the fp8 conversions saturate
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntm = (a.Mc + TM - 1) / TM, ntn = (a.Nc + TN - 1) / TN;
+  const int nt = ntm * ntn * a.taps * a.splits, wg = blockIdx.x;
+  const int xcd = wg & 7, loc = wg >> 3, qq = nt >> 3, r8 = nt & 7;
+  int id = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
+  const int tn = id % ntn; id /= ntn;
+  const int tm = id % ntm; id /= ntm;
+  const int tap = id % a.taps;
+  const int split = id / a.taps;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int shift = (tap - a.taps / 2) * a.dil;
+  const int steps_total = (a.R + BK - 1) / BK;
+  const int steps_per = (steps_total + a.splits - 1) / a.splits;
+  const int step_lo = split * steps_per;
+  int step_hi = step_lo + steps_per;
+  if (step_hi > steps_total) step_hi = steps_total;
+  const int nsteps = step_hi - step_lo;
+
+  // DMA pieces of one wave per stage.
+  //   hi planes: 16 pieces per array (two 512-byte frame rows each) -> piece w = 0..7: array w >> 2 (GYh, Xh), row pair
+  //              4 (w & 3) + wave; lane: row of the pair lane >> 5, LDS unit (lane & 31) >> 2, 16-byte part lane & 3
+  //   lo8 planes: 8 pieces per array (four 256-byte frame rows each) -> piece w = 8..11: array (w - 8) >> 1 (GYl8, Xl8), row
+  //              quad 4 ((w - 8) & 1) + wave; lane: row of the quad lane >> 4, LDS unit (lane >> 1) & 7, 16-byte half lane & 1
+  // Per piece: this lane's frame offset within a K step, its byte offset at step 0 of the split, and (X arrays) the
+  // frame-in-utterance counter of its row at the step being fetched.
+  const __amdgpu_buffer_rsrc_t rGh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.GYh), 0, a.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rXh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.Xh), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rGl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.GYl), 0, a.gl_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rXl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.Xl), 0, a.xl_bytes, 0x00020000);
+  int p_k[12], p_off[12];
+  int p_t[6], p_b[6], p_lim[6];                                  // X pieces: 4 hi row pairs, 2 lo8 row quads
+  int* lim_tab = reinterpret_cast<int*>(sm + SMEM);              // readable frames per utterance: min(len, T) or T
+  const int nb = a.R / a.T;
+  for (int i = tid; i < nb; i += 256) {
+    const int l = (a.x_mask && a.lens) ? a.lens[i] : a.T;
+    lim_tab[i] = l < a.T ? l : a.T;
+  }
+  auto init_x = [&](int slot, int f0) __attribute__((always_inline)) {
+    const int b = f0 / a.T;
+    const int bc = b < nb ? b : nb - 1;
+    const int l = (a.x_mask && a.lens) ? a.lens[bc] : a.T;
+    p_b[slot] = b;
+    p_t[slot] = f0 - b * a.T;                                    // frame within its utterance
+    p_lim[slot] = l < a.T ? l : a.T;
+  };
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int isx = w >> 2, pr = 4 * (w & 3) + wave;
+    const int k = 2 * pr + (lane >> 5);
+    const int u = ((lane & 31) >> 2) ^ (k & 3);                  // source 64-byte unit that lands at this lane's LDS unit
+    const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
+    const int ch = c0 + u * 32 + (lane & 3) * 8;
+    p_k[w] = k;
+    const int f0 = step_lo * BK + k;                             // GY frame of this row at the split's first step
+    p_off[w] = ch < ld ? ((f0 + (isx ? shift : 0)) * ld + ch) * 2 : OOB;
+    if (isx) init_x(w & 3, f0);
+  }
+#pragma unroll
+  for (int w = 8; w < 12; ++w) {
+    const int isx = (w - 8) >> 1, q = 4 * ((w - 8) & 1) + wave;
+    const int k = 4 * q + (lane >> 4);
+    const int u = ((lane >> 1) & 7) ^ (k & 7);                   // source 32-channel unit that lands at this lane's LDS unit
+    const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
+    const int ch = c0 + u * 32 + (lane & 1) * 16;
+    p_k[w] = k;
+    const int f0 = step_lo * BK + k;
+    const int pitch = isx ? a.xl_pitch : a.gl_pitch, bs = isx ? a.xl_bstride : a.gl_bstride, bo = isx ? a.xl_boff : a.gl_boff;
+    p_off[w] = ch < ld ? (f0 + (isx ? shift : 0)) * pitch + (ch >> 5) * bs + bo + (ch & 31) : OOB;
+    if (isx) init_x(4 + ((w - 8) & 1), f0);
+  }
+  const int g_step = BK * a.ldg * 2, x_step = BK * a.ldx * 2, gl_step = BK * a.gl_pitch, xl_step = BK * a.xl_pitch;
+  int l_rel = 0;                                                 // steps fetched so far (relative to step_lo)
+  // piece w of relative step `rel` into stage `buf`; call with consecutive rel (the counters advance)
+  auto dma_piece = [&](int buf, int w, int rel) __attribute__((always_inline)) {
+    const bool lo8 = w >= 8;
+    const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
+    const int f = (step_lo + rel) * BK + p_k[w];
+    int ok = -(int)(f < a.R);                                     // the GY frame exists
+    if (isx) {
+      const int slot = lo8 ? 4 + ((w - 8) & 1) : (w & 3);
+      const int ts = p_t[slot] + shift;                           // partner frame, counted within the utterance
+      ok &= -(int)((unsigned)ts < (unsigned)p_lim[slot]);
+    }
+    const int stepb = lo8 ? (isx ? xl_step : gl_step) : (isx ? x_step : g_step);
+    const int vo = ((p_off[w] + rel * stepb) & ok) | (OOB & ~ok);
+    const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
+    dma16(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo);
+  };
+  auto advance_t = [&]() __attribute__((always_inline)) {        // the X pieces' rows move on by one K step
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+      int t = p_t[w] + BK;
+      const int wrap = t >= a.T ? 1 : 0;                         // T >= 32: at most one utterance boundary per step
+      t -= wrap ? a.T : 0;
+      const int b = p_b[w] + wrap;
+      p_t[w] = t;
+      p_b[w] = b;
+      p_lim[w] = lim_tab[b < nb ? b : nb - 1];
+    }
+  };
+
+  f32x16 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // E8M0 block scales of the cross MFMA (rowgemm_h3w_kernel.h): A = [GYhi8 | GYlo8 * 2^11], B = [Xlo8 * 2^11 | Xhi8], each
+  // further multiplied by 2^g8_exp / 2^x8_exp; the scale byte of lane (row, half 0) applies to the first 16 bytes
+  const int x_sa = (lane >> 5) ? 127 - 11 - a.g8_exp : 127 - a.g8_exp;
+  const int x_sb = (lane >> 5) ? 127 - a.x8_exp : 127 - 11 - a.x8_exp;
+  const float g_inv = __builtin_ldexpf(1.f, -a.g8_exp), x_inv = __builtin_ldexpf(1.f, -a.x8_exp);
+
+  if (nsteps > 0) {
+#pragma unroll
+    for (int w = 0; w < 12; ++w) dma_piece(0, w, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      const bool more = s + 1 < nsteps;
+      if (more) {                                                  // (uniform) the counters follow the stage being fetched
+        advance_t();
+        l_rel = s + 1;
+      }
+      const unsigned char* st = sm + buf * STAGE;
+      // B side (X, this wave's two 32-channel units): fp16 hi fragments of both k blocks + the FP8 operand [lo8 | hi8]
+      Frag xb0[2], xb1[2], xb8[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        frag_issue(xb0[j], frag_addr(st + HARR, 2 * wave + j, 0, lane));
+        frag_issue(xb1[j], frag_addr(st + HARR, 2 * wave + j, 1, lane));
+        frag8_issue(xb8[j], frag8_addr(st + 2 * HARR + LARR, 2 * wave + j, lane));
+      }
+      Frag ga0[2], ga1[2], ga8[2];                                  // A side (GY), two slots
+      frag_issue(ga0[0], frag_addr(st, 0, 0, lane));
+      frag_issue(ga1[0], frag_addr(st, 0, 1, lane));
+      frag8_issue(ga8[0], frag8_addr(st + 2 * HARR, 0, lane));
+      frag_wait3<12>(xb0[0], xb1[0], xb8[0]);                       // (6 B + 6 A read instructions are younger than B's first unit)
+      frag_wait3<6>(xb0[1], xb1[1], xb8[1]);
+      f16x8 bh0[2], bh1[2];
+      i32x8 b8[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh0[j] = frag_val(xb0[j]);
+        bh1[j] = frag_val(xb1[j]);
+        const i32x4 h8 = hi8_of(xb0[j], xb1[j], x_inv);
+        const i32x4 l8 = __builtin_shufflevector(xb8[j].lo, xb8[j].hi, 0, 1, 2, 3);
+        b8[j] = __builtin_shufflevector(l8, h8, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sl = i & 1;
+        if (i + 1 < 8) {                                            // next row block's fragments ahead of this one's MFMAs
+          frag_issue(ga0[sl ^ 1], frag_addr(st, i + 1, 0, lane));
+          frag_issue(ga1[sl ^ 1], frag_addr(st, i + 1, 1, lane));
+          frag8_issue(ga8[sl ^ 1], frag8_addr(st + 2 * HARR, i + 1, lane));
+          frag_wait3<6>(ga0[sl], ga1[sl], ga8[sl]);
+        } else {
+          frag_wait3<0>(ga0[sl], ga1[sl], ga8[sl]);
+        }
+        const f16x8 ah0 = frag_val(ga0[sl]), ah1 = frag_val(ga1[sl]);
+        const i32x4 h8 = hi8_of(ga0[sl], ga1[sl], g_inv);
+        const i32x4 l8 = __builtin_shufflevector(ga8[sl].lo, ga8[sl].hi, 0, 1, 2, 3);
+        const i32x8 a8 = __builtin_shufflevector(h8, l8, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
+        }
+        if (more && i < 6) {                                        // two DMA pieces of the next stage per row block
+          dma_piece(buf ^ 1, 2 * i, l_rel);
+          dma_piece(buf ^ 1, 2 * i + 1, l_rel);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* P = a.P + (long long)split * a.split_stride + (long long)tap * a.Mc * a.ldp;
+  const bool vec_ok = (a.ldp % 4 == 0) && radmmm::aligned16(a.P) && (a.split_stride % 4 == 0);
+  store_blocks<0>(acc, reinterpret_cast<float*>(sm), P, a.ldp, a.Mc, a.Nc, a.acc_scale, m0, n0, tid, lane, wave, vec_ok);
+}
+
+}  // namespace
+
+// GYh / Xh [R][ldg / ldx] row-major fp16 hi planes of scale_g * gy and of x; GYx / Xx the tensors' 8-bit cross arrays
+// (RADMMM_SPLIT_X8A, row pitch 2 * ld bytes) written with exponents g8_exp / x8_exp: only their lo8 halves are read.
+// Everything else as radmmm_wgrad_rm.  ldg, ldx multiples of 32, 16-byte aligned operands, T >= 32, at most 1024 utterances.
+extern "C" int radmmm_wgrad_rm8(const void* GYh, const void* GYx, int ldg, int g8_exp, const void* Xh, const void* Xx, int ldx,
+                                int x8_exp, int R, int T, const int32_t* lens, int x_mask, float* P, int ldp, int64_t split_stride,
+                                int Mc, int Nc, int taps, int dil, int splits, float acc_scale, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(GYh && GYx && Xh && Xx && P, "wgrad_rm8: null pointer");
+  RADMMM_REQUIRE(Mc > 0 && Nc > 0 && taps >= 1 && dil >= 1 && splits >= 1 && R > 0 && T > 0 && R % T == 0 && ldg >= Mc &&
+                     ldx >= Nc && ldg % 32 == 0 && ldx % 32 == 0 && ldp >= Nc && T >= BK && R / T <= 1024 &&
+                     abs(g8_exp) <= 16 && abs(x8_exp) <= 16,
+                 "wgrad_rm8: bad dims (ldg, ldx %% 32 == 0, R = B * T, T >= 32, B <= 1024, |x8_exp| <= 16)");
+  RADMMM_REQUIRE(radmmm::aligned16(GYh) && radmmm::aligned16(GYx) && radmmm::aligned16(Xh) && radmmm::aligned16(Xx),
+                 "wgrad_rm8: 16-byte aligned operands");
+  const long long g_bytes = (long long)R * ldg * 2, x_bytes = (long long)R * ldx * 2;
+  RADMMM_REQUIRE(g_bytes < 0x7fffffffLL && x_bytes < 0x7fffffffLL, "wgrad_rm8: operand >= 2 GiB");
+  static int once = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rm8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SMEM + 4096);
+    if (e != hipSuccess) {
+      radmmm::set_error("hipFuncSetAttribute(wgrad_rm8): %s", hipGetErrorString(e));
+      return -2;
+    }
+    return 0;
+  }();
+  if (once) return once;
+  Rm8Args a;
+  a.GYh = static_cast<const _Float16*>(GYh); a.Xh = static_cast<const _Float16*>(Xh);
+  a.GYl = static_cast<const unsigned char*>(GYx); a.Xl = static_cast<const unsigned char*>(Xx);
+  a.gl_pitch = 2 * ldg; a.gl_bstride = 64; a.gl_boff = 32;       // lo8 half of the A-role cross array
+  a.xl_pitch = 2 * ldx; a.xl_bstride = 64; a.xl_boff = 32;
+  a.g8_exp = g8_exp; a.x8_exp = x8_exp;
+  a.lens = lens; a.x_mask = x_mask;
+  a.R = R; a.T = T; a.ldg = ldg; a.ldx = ldx; a.Mc = Mc; a.Nc = Nc; a.taps = taps; a.dil = dil; a.splits = splits;
+  a.P = P; a.ldp = ldp; a.split_stride = split_stride; a.acc_scale = acc_scale;
+  a.g_bytes = (int)g_bytes; a.x_bytes = (int)x_bytes; a.gl_bytes = (int)g_bytes; a.xl_bytes = (int)x_bytes;
+  const int tiles = ((Mc + TM - 1) / TM) * ((Nc + TN - 1) / TN) * taps;
+  hipLaunchKernelGGL(wgrad_rm8_kernel, dim3(tiles * splits), dim3(256), SMEM + 4096, static_cast<hipStream_t>(stream), a);
+  return radmmm::check_launch("wgrad_rm8");
+}

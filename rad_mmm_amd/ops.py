@@ -795,6 +795,23 @@ def wgrad_rm_slabs(gy_pair, x_pair, B, T, Mc, Nc, taps, dil, acc_scale, lens=Non
     return P
 
 
+def wgrad_rm8_slabs(gy_pair, g8_exp, x_pair, x8_exp, B, T, Mc, Nc, taps, dil, acc_scale, lens=None):
+    """Weight gradient under the FP8-cross scheme from ROW-major (hi fp16, 8-bit cross array) pairs [B*T, ld]
+    (radmmm_wgrad_rm8: GYh.Xh on the f16 pipe, both cross terms in one block-scaled FP8 MFMA) -> P [S, taps, Mc, Nc]."""
+    gh, gx = gy_pair
+    xh, xx = x_pair
+    R = B * T
+    assert gh.shape[0] >= R and xh.shape[0] >= R and gh.dtype == torch.float16 and xh.dtype == torch.float16
+    tiles = int(lib.radmmm_wgrad_rm_tiles(Mc, Nc, taps))
+    S = pick_splits(tiles, R, slots=int(lib.radmmm_gemm_cu_slots()))              # one workgroup per CU
+    P = torch.empty(S, taps, Mc, Nc, device=gh.device, dtype=torch.float32)
+    assert gh.stride(1) == 1 and xh.stride(1) == 1 and gx.stride(0) == gh.stride(0) and xx.stride(0) == xh.stride(0)
+    check(lib.radmmm_wgrad_rm8(ptr(gh), ptr(gx), gh.stride(0), g8_exp, ptr(xh), ptr(xx), xh.stride(0), x8_exp, R, T, ptr(lens),
+                               1 if lens is not None else 0, ptr(P), Nc, P.stride(0), Mc, Nc, taps, dil, S, acc_scale, stream()),
+          "wgrad_rm8")
+    return P
+
+
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
     a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), a device-side
@@ -1013,12 +1030,15 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # the GEMMs' second operand array is the 8-bit cross array, so the producers write the fp16 lo part as well.
         use_rm = (NPR in (2, 3) and T >= 32 and B <= 1024 and any(ctx.needs_input_grad) and
                   debug_env("RADMMM_WGRAD_RM", "1") != "0")
-        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
+        # (NPR 2: radmmm_wgrad_rm8 contracts (hi, cross array) pairs -- no fp16 lo copies; RADMMM_DEBUG + RADMMM_WGRAD_RM8=0
+        #  keeps the three-product gradient on (hi, fp16 lo) pairs for A/B runs)
+        rm8 = use_rm and NPR == 2 and Wc % 32 == 0 and debug_env("RADMMM_WGRAD_RM8", "1") != "0"
+        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2 and not rm8) else (lambda: None)
         z1 = _empty(N, ZLD, like=z_in)
         rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
         X0 = _empty(N, Kp, like=z_in)
         X0h, X0l = _halves(N, Kp, like=z_in)
-        X0lo = torch.empty(N, Kp, device=z_in.device, dtype=torch.float16) if (use_rm and NPR == 2) else None
+        X0lo = torch.empty(N, Kp, device=z_in.device, dtype=torch.float16) if (use_rm and NPR == 2 and not rm8) else None
         check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l),
                                       split_opts(fa, X8_ACT_EXP, None, X0lo), stream()), "wn_input_fwd")
         perm = (h, D, 0)
@@ -1069,6 +1089,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.nl = nl
         ctx.use_rm = use_rm
+        ctx.rm8 = rm8
         rm_saved = [X0h, X0lo if X0lo is not None else X0l, *[t for pr in pairs for t in pr]] if use_rm else []
         ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
                               start_b, end_b,
@@ -1108,7 +1129,13 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         if g_logs is not None:
             g_logs = g_logs.contiguous()
         box = meta["scale_box"]
-        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2) else (lambda: None)
+        rm8 = ctx.rm8
+        lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2 and not rm8) else (lambda: None)
+
+        def wg_rm(gpair, xpair_, Mc_, Nc_, taps_, dil_, lens_=None):
+            if rm8:
+                return wgrad_rm8_slabs(gpair, X8_GRAD_EXP, xpair_, X8_ACT_EXP, B, T, Mc_, Nc_, taps_, dil_, 1.0 / SG, lens_)
+            return wgrad_rm_slabs(gpair, xpair_, B, T, Mc_, Nc_, taps_, dil_, 1.0 / SG, lens_)
         SG = grad_scale(box, g_zout)
         flag = sat_flag_of(box)
         poison = poison_of(box)
@@ -1155,7 +1182,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
                                                          X8_GRAD_EXP, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo)
             if use_rm:
-                slabs = wgrad_rm_slabs((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], B, T, Wc, Wc, 1, 1, 1.0 / SG)
+                slabs = wg_rm((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], Wc, Wc, 1, 1)
             else:
                 # H[j+1]'s transposed copy may still be in the pool from layer j+1's in_layer weight gradient (x_prev, set
                 # below only when that length-masked copy is IDENTICAL to the unmasked one this gradient needs)
@@ -1179,8 +1206,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout)
             if use_rm:
                 g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d, out=grad_out(in_p[3 * j + 2]))
-                slabs = wgrad_rm_slabs((gch, gclo if gclo is not None else gcl), Hpair[j], B, T, Wc, Wc, kt, d, 1.0 / SG,
-                                       lens if partial else None)
+                slabs = wg_rm((gch, gclo if gclo is not None else gcl), Hpair[j], Wc, Wc, kt, d, lens if partial else None)
             elif (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
                                                             colsum=(2 if partial else 0, lens, kt, d),
@@ -1220,7 +1246,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         perm = (h, D, 0)
         if use_rm:
             g_start_b = colsum(G, Wc, out=grad_out(start_b))
-            slabs = wgrad_rm_slabs((Gh, Glo if Glo is not None else Gl), X0pair, B, T, Wc, Kp, 1, 1, 1.0 / SG)
+            slabs = wg_rm((Gh, Glo if Glo is not None else Gl), X0pair, Wc, Kp, 1, 1)
         else:
             gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
                                                   sum_out=grad_out(start_b))

@@ -161,3 +161,44 @@ def test_wgrad_rm_matches_the_transposed_path(B, T, Mc, Nc, taps, dil):
         x_t = ops.transpose_split_act(x, Nc, B, T, None, 0, 1.0, "x", need_odd=(dil % 2 == 1 and taps > 1))
         Q = ops.wgrad_h3_slabs(gy_t, x_t, Mc, Nc, Nc, taps, dil, 1.0 / SG).sum(0)
         assert rel_err(P.cpu(), Q.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,Mc,Nc,taps,dil", [(4, 64, 256, 256, 1, 1), (3, 96, 320, 288, 5, 2), (2, 160, 1024, 1152, 1, 1),
+                                                (5, 40, 96, 160, 3, 1), (2, 352, 512, 256, 5, 8)])
+def test_wgrad_rm8_fp8_cross_terms(B, T, Mc, Nc, taps, dil):
+    """radmmm_wgrad_rm8 (hi.hi on the f16 pipe, both cross terms in one block-scaled FP8 MFMA whose hi8 halves are derived
+    from the fp16 fragments in registers, lo8 halves read from the cross arrays through ds_read_b64_tr_b8) against a float64
+    reference built from the exact fp32 tensors: utterance boundaries, partial tiles, odd shifts, the length mask; and its
+    error against the three-product kernel on the same tensors (the scheme's cross terms are e4m3-rounded: ~2^-4 * 2^-11
+    per product, averaged over the frames)."""
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    gy = (torch.randn(B * T, Mc, generator=g) * 0.3).to(DEV)
+    x = torch.nn.functional.softplus(torch.randn(B * T, Nc, generator=g)).to(DEV)
+    SG = 32.0                                                # amax * SG in [8, 16) .. the producers' calibration
+    ldg, ldx = ops.round_up(Mc, 32), ops.round_up(Nc, 32)
+    gh, gx = ops.split_f16(gy, Mc, SG, ldg, 2, ops.X8_GRAD_EXP)
+    xh, xx = ops.split_f16(x, Nc, 1.0, ldx, 2, ops.X8_ACT_EXP)
+    P = ops.wgrad_rm8_slabs((gh, gx), ops.X8_GRAD_EXP, (xh, xx), ops.X8_ACT_EXP, B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)
+    lens = torch.tensor([max(1, T - 7 * b) for b in range(B)], dtype=torch.int32, device=DEV)
+    keep = (torch.arange(T, device=DEV)[None] < lens[:, None]).reshape(B * T, 1)
+    xmh, xmx = ops.split_f16(x * keep, Nc, 1.0, ldx, 2, ops.X8_ACT_EXP)
+    Pm = ops.wgrad_rm8_slabs((gh, gx), ops.X8_GRAD_EXP, (xh, xx), ops.X8_ACT_EXP, B, T, Mc, Nc, taps, dil, 1.0 / SG, lens).sum(0)
+    Pz = ops.wgrad_rm8_slabs((gh, gx), ops.X8_GRAD_EXP, (xmh, xmx), ops.X8_ACT_EXP, B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)
+    assert torch.equal(Pm, Pz)
+    gv = gy.double().view(B, T, Mc)
+    xv = x.double().view(B, T, Nc)
+    ref = torch.zeros(taps, Mc, Nc, dtype=torch.float64, device=DEV)
+    for tp in range(taps):
+        s = (tp - taps // 2) * dil
+        lo, hi = max(0, -s), min(T, T - s)
+        if hi > lo:
+            ref[tp] = torch.einsum("btm,btn->mn", gv[:, lo:hi], xv[:, lo + s:hi + s])
+    err8 = rel_err(P.double().cpu(), ref.cpu())
+    g3h, g3l = ops.split_f16(gy, Mc, SG, ldg)
+    x3h, x3l = ops.split_f16(x, Nc, 1.0, ldx)
+    P3 = ops.wgrad_rm_slabs((g3h, g3l), (x3h, x3l), B, T, Mc, Nc, taps, dil, 1.0 / SG).sum(0)
+    err3 = rel_err(P3.double().cpu(), ref.cpu())
+    print(f"wgrad_rm8 B={B} T={T} {Mc}x{Nc} taps={taps}: max rel err fp8-cross {err8:.2e}, three products {err3:.2e}")
+    assert err8 < 6e-5 and err3 < 3e-6            # (a few hundred frames here: the e4m3 rounding of the cross terms averages down with the frame count)
