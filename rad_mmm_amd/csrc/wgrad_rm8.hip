@@ -15,6 +15,11 @@
 // 32 frames x 256 B; an 8-bit fragment (8 consecutive frames of one channel) is one ds_read_b64_tr_b8 -- a 16-lane group
 // reads an [8 frames][16 channels] byte block and lane p receives column p (measured) -- with the 32-byte channel units of
 // frame row r stored XOR-ed by (r & 7): the eight rows of a read fall into eight different bank groups.
+// THREE stages: the 12 DMA pieces a wave issues during step s belong to step s + 2, and the barrier at the end of step s
+// waits with vmcnt(12) -- for the pieces of step s + 1, issued a whole step earlier (vmcnt retires in order) -- so no
+// barrier ever waits for a transfer that has just been started (with two stages the 32-frame step took 2.4 us against
+// 1.08 us of MFMA work).  Every LDS read of the loop is inline asm: the compiler would otherwise order its own reads
+// behind all outstanding LDS-DMA with vmcnt(0).
 #include <cstdlib>
 
 #include "common.h"
@@ -34,7 +39,8 @@ constexpr int BK = 32, TM = 256, TN = 256;          // frames per K step, output
 constexpr int HARR = BK * TM * 2;                    // bytes of one fp16 hi array in a stage: 32 rows x 512 B
 constexpr int LARR = BK * TM;                        // bytes of one lo8 array in a stage: 32 rows x 256 B
 constexpr int STAGE = 2 * HARR + 2 * LARR;           // GYh, Xh, GYl8, Xl8 = 48 KiB
-constexpr int SMEM = 2 * STAGE;                      // 96 KiB; the epilogue reuses it
+constexpr int NSTAGE = 3;                            // LDS ring: the tile of step s + 2 is fetched during step s
+constexpr int SMEM = NSTAGE * STAGE;                 // 144 KiB; the epilogue reuses it
 constexpr int OOB = 0x7fffffff;
 
 struct Rm8Args {
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int l = (a.x_mask && a.lens) ? a.lens[i] : a.T;
     lim_tab[i] = l < a.T ? l : a.T;
   }
+  __syncthreads();                                               // (advance_t reads the table before the first K-step barrier)
   auto init_x = [&](int slot, int f0) __attribute__((always_inline)) {
     const int b = f0 / a.T;
     const int bc = b < nb ? b : nb - 1;
@@ -216,13 +223,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     if (isx) init_x(4 + ((w - 8) & 1), f0);
   }
   const int g_step = BK * a.ldg * 2, x_step = BK * a.ldx * 2, gl_step = BK * a.gl_pitch, xl_step = BK * a.xl_pitch;
-  int l_rel = 0;                                                 // steps fetched so far (relative to step_lo)
   // piece w of relative step `rel` into stage `buf`; call with consecutive rel (the counters advance)
   auto dma_piece = [&](int buf, int w, int rel) __attribute__((always_inline)) {
     const bool lo8 = w >= 8;
     const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
     const int f = (step_lo + rel) * BK + p_k[w];
-    int ok = -(int)(f < a.R);                                     // the GY frame exists
+    int ok = -(int)((f < a.R) & (rel < nsteps));                  // the GY frame exists and belongs to this split
     if (isx) {
       const int slot = lo8 ? 4 + ((w - 8) & 1) : (w & 3);
       const int ts = p_t[slot] + shift;                           // partner frame, counted within the utterance
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     dma16(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo);
   };
   auto advance_t = [&]() __attribute__((always_inline)) {        // the X pieces' rows move on by one K step
+    unsigned p_lim_new[6];
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
       int t = p_t[w] + BK;
@@ -242,8 +249,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
       const int b = p_b[w] + wrap;
       p_t[w] = t;
       p_b[w] = b;
-      p_lim[w] = lim_tab[b < nb ? b : nb - 1];
+      unsigned lv;                                               // (asm: a compiler-visible LDS read would wait for the DMA in flight)
+      const unsigned la = (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(lim_tab + (b < nb ? b : nb - 1)));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(lv) : "v"(la) : "memory");
+      p_lim_new[w] = lv;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p_lim_new[0]), "+v"(p_lim_new[1]), "+v"(p_lim_new[2]), "+v"(p_lim_new[3]), "+v"(p_lim_new[4]),
+                 "+v"(p_lim_new[5]) : : "memory");
+#pragma unroll
+    for (int w = 0; w < 6; ++w) p_lim[w] = (int)p_lim_new[w];
   };
 
   f32x16 acc[8][2];
@@ -261,16 +275,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
   const float g_inv = __builtin_ldexpf(1.f, -a.g8_exp), x_inv = __builtin_ldexpf(1.f, -a.x8_exp);
 
   if (nsteps > 0) {
+    // prologue: tiles 0 and 1 (the pieces of a step beyond the split's end are issued all the same, with out-of-range
+    // offsets -- zeros into a stage nobody reads -- so that every step issues exactly 12 pieces per wave)
 #pragma unroll
     for (int w = 0; w < 12; ++w) dma_piece(0, w, 0);
-    __syncthreads();
+    advance_t();
+#pragma unroll
+    for (int w = 0; w < 12; ++w) dma_piece(1, w, 1);
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
-      const int buf = s & 1;
-      const bool more = s + 1 < nsteps;
-      if (more) {                                                  // (uniform) the counters follow the stage being fetched
-        advance_t();
-        l_rel = s + 1;
-      }
+      advance_t();                                                 // the counters follow the tile being fetched: s + 2
+      const int l_rel = s + 2;
+      const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
       const unsigned char* st = sm + buf * STAGE;
       // B side (X, this wave's two 32-channel units): fp16 hi fragments of both k blocks + the FP8 operand [lo8 | hi8]
       Frag xb0[2], xb1[2], xb8[2];
@@ -317,13 +334,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
         }
-        if (more && i < 6) {                                        // two DMA pieces of the next stage per row block
-          dma_piece(buf ^ 1, 2 * i, l_rel);
-          dma_piece(buf ^ 1, 2 * i + 1, l_rel);
+        if (i < 6) {                                                // two DMA pieces of tile s + 2 per row block
+          dma_piece(nbuf, 2 * i, l_rel);
+          dma_piece(nbuf, 2 * i + 1, l_rel);
         }
       }
-      __syncthreads();
+      // all reads of stage `buf` are complete (waited above); tile s + 1 has landed once at most this step's 12 pieces
+      // are outstanding
+      asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      buf = buf + 1 < NSTAGE ? buf + 1 : 0;
     }
+    __syncthreads();                                               // the trailing (out-of-range) pieces, before LDS is reused
   }
   float* P = a.P + (long long)split * a.split_stride + (long long)tap * a.Mc * a.ldp;
   const bool vec_ok = (a.ldp % 4 == 0) && radmmm::aligned16(a.P) && (a.split_stride % 4 == 0);
