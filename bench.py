@@ -240,6 +240,69 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
                       f"(probe B=1,T=100: {probe:.2f} s)"}
 
 
+def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=5, t_txt=150):
+    """The WHOLE training step the reference's Lightning loop runs per batch (tts_lightning_modules.py:643-750 + clip +
+    RAdam, configs/RADMMM_train_config.yaml:7-8): embeddings, text encoder, alignment attention with the beta-binomial
+    prior, on-device MAS (binarisation on), context = txt_enc . attn^T, flow decoder, flow NLL + CTC + binarisation losses,
+    backward, global-norm clip 1.0, RAdam -- on synthetic text (150 tokens per utterance) and the decoder leg's mel.
+    Reported: ms per step, the share outside the decoder's fwd+bwd, and the host synchronisations one step makes."""
+    import warnings
+    from rad_mmm_amd.data import BetaBinomialInterpolator
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.optim import FlatRAdam
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    torch.manual_seed(1234)
+    model = TTSTrainingStep(Encoder(3, CFG["n_text_dim"], 5), dec, RADMMMLoss(sigma=1.0, kl_loss_start_iter=0),
+                            n_speakers=8, n_accents=4, n_text_tokens=185, n_text_dim=CFG["n_text_dim"],
+                            n_speaker_dim=CFG["n_speaker_dim"], n_accent_dim=CFG["n_accent_dim"], use_accent=True,
+                            use_accent_emb_for_decoder=CFG["use_accent_emb_for_decoder"], binarization_start_iter=0).to(dev).train()
+    g = torch.Generator().manual_seed(99)
+    in_lens = [t_txt] * B
+    batch = {"mel": gb["mel"] * 2 - 5,                      # the step applies (mel + 5) / 2 itself
+             "speaker_ids": torch.randint(0, 8, (B,), generator=g).to(dev), "accent_ids": torch.randint(0, 4, (B,), generator=g).to(dev),
+             "text": torch.randint(0, 185, (B, t_txt), generator=g).to(dev),
+             "input_lengths": torch.tensor(in_lens, device=dev), "output_lengths": gb["lengths"],
+             "attn_prior": BetaBinomialInterpolator(device=dev).batch(in_lens, [T] * B),
+             "f0": gb["f0"], "energy_avg": gb["energy"]}
+    opt = FlatRAdam(model.named_parameters(), lr=1e-6, weight_decay=1e-6)       # tiny lr: the loss stays put
+
+    def step():
+        opt.zero_grad()
+        loss, losses, _ = model.training_step(batch, global_step=10)
+        loss.backward()
+        opt.clip_grad_norm(1.0)
+        opt.step()
+        return loss
+    for _ in range(3):
+        lv = step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        lv = step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]))
+    # host synchronisations of one step: torch's sync debug mode warns on every blocking device->host read
+    n_sync = None
+    try:
+        torch.cuda.set_sync_debug_mode("warn")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            step()
+        n_sync = sum(1 for x in w if "synchroniz" in str(x.message).lower())
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    return {"what": "TTSTrainingStep.training_step (text encoder + attention + on-device MAS + decoder + NLL/CTC/binarisation "
+                    "losses) + backward + clip 1.0 + FlatRAdam; tts_lightning_modules.py:643-750",
+            "batch": B, "frames": T, "text_tokens": t_txt, "steps": steps, "statistic": "median", "ms_per_step": ms,
+            "value": B * T / (ms * 1e-3), "unit": "mel-frames/s", "loss": float(lv.detach()),
+            "decoder_fwd_bwd_ms": decoder_only_ms, "ms_outside_decoder_fwd_bwd": ms - decoder_only_ms,
+            "share_outside_decoder": (ms - decoder_only_ms) / ms, "host_syncs_per_step": n_sync}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +319,13 @@ def main():
     ap.add_argument("--optimizer", action="store_true",
                     help="also run the fused global-norm clip + RAdam update inside the timed step (NOT the BASELINE metric, "
                          "which is fwd+bwd only; reported with config.includes_optimizer = true)")
+    ap.add_argument("--full-step", action="store_true",
+                    help="extra leg (N = 1): the whole training step of the reference's TTSModel.training_step "
+                         "(tts_lightning_modules.py:643-750: text encoder, alignment attention, on-device MAS, decoder, losses) "
+                         "+ global-norm clip + RAdam on synthetic text/mel, reported under `full_step`")
+    ap.add_argument("--rccl-channels", type=int, default=None,
+                    help="N > 1: pin RCCL to this many channels (NCCL_MIN/MAX_NCHANNELS) and size the GEMM grids for the "
+                         "remaining CUs; default 8 (rad_mmm_amd.ddp.reserve_collective_cus)")
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     ap.add_argument("--dominant-only", action="store_true",
                     help="launch only the roofline leg's kernel (the PMC passes of tools/pmc_dominant.sh wrap this)")
@@ -311,8 +381,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("RADMMM_FORCE_DIST") == "1"   # the latter: RCCL smoke test on 1 GPU
     if world > 1:
-        from rad_mmm_amd.ddp import reserve_collective_cus    # before the library's first launch and before RCCL starts
-        reserve_collective_cus()
+        from rad_mmm_amd.ddp import reserve_collective_cus, RCCL_CUS   # before the library's first launch and before RCCL starts
+        reserve_collective_cus(args.rccl_channels or RCCL_CUS)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -338,6 +408,7 @@ def main():
     gb = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
     sl = SequenceLength(gb["lengths"])
     reducer = BucketedGradReducer(dec)
+    reducer.profile = bool(use_dist)          # HIP events around the waits of finish(): exposed communication per step
     opt = None
     if args.optimizer:
         from rad_mmm_amd.optim import FlatRAdam
@@ -365,9 +436,11 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    comm_ev = []
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
+        comm_ev.append(reducer._prof_events)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -382,6 +455,32 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * B * T * args.steps / dt
     loss_val = float(loss.detach())
+    # self-diagnosis of the data-parallel run: the world RCCL really spans (an all-reduce of ones), the time the compute
+    # stream waited for all-reduces after backward (exposed communication; per bucket in issue order = last flow first),
+    # the slowest rank's figure, and the knobs in force
+    dist_info = {"backend": dist.get_backend() if use_dist else None, "process_group": bool(use_dist),
+                 "gradient_buckets": len(reducer.buckets), "gradient_bytes_per_step": reducer.total_bytes,
+                 "gemm_cu_budget": os.environ.get("RADMMM_GEMM_CUS"),
+                 "nccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}}
+    if use_dist:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        per_step = []
+        per_bucket = None
+        for ev in comm_ev:
+            if ev:
+                d = [ev[i].elapsed_time(ev[i + 1]) for i in range(len(ev) - 1)]
+                per_step.append(sum(d))
+                per_bucket = d if per_bucket is None else [a + b for a, b in zip(per_bucket, d)]
+        exp_ms = float(np.median(per_step)) if per_step else None
+        worst = torch.tensor([exp_ms or 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dist_info.update(rccl_world_size=dist.get_world_size(), rccl_allreduce_of_ones=float(ones),
+                         reduce_op="avg" if reducer._avg else "sum + scale",
+                         exposed_comm_ms_median_rank0=exp_ms, exposed_comm_ms_median_slowest_rank=float(worst),
+                         exposed_comm_ms_per_bucket_mean_rank0=([x / len(per_step) for x in per_bucket] if per_bucket else None),
+                         bucket_order=[reducer.buckets[i]["key"] for i in reducer._order],
+                         bucket_mbytes=[round(reducer.buckets[i]["flat"].numel() * 4 / 1e6, 1) for i in reducer._order])
 
     if rank == 0:
         N = B * (T // cfg.n_group_size)
@@ -422,7 +521,10 @@ def main():
             "metric": "mel-frames/sec training step (fwd+bwd)", "value": frames_per_s, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # inputs, outputs, accumulation and the parity bar are fp32; the label names the multiplier arrays the products run on
+            "dtype": ("f32 (f16 hi.hi product + fp8 e4m3 cross terms, fp32 accumulate)" if f8x else
+                      "f32 (3 f16 products per fp32 product, fp32 accumulate)" if h3 else "f32 (fp32 MFMA)"),
             "data": "synthetic (procedural random-init weights, N(2.5,0.5) mel, fixed length)",
             "config": {"workload": ("RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
                                     "D=1048) fwd+NLL+bwd") if args.config == "radtts" else
@@ -434,16 +536,17 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec,
                        "includes_optimizer": bool(args.optimizer)},
             "loss_mel": loss_val,
-            "distributed": {"backend": dist.get_backend() if use_dist else None, "process_group": bool(use_dist),
-                            "gradient_buckets": len(reducer.buckets), "gradient_bytes_per_step": reducer.total_bytes,
-                            "gemm_cu_budget": os.environ.get("RADMMM_GEMM_CUS")},
+            "distributed": dist_info,
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "frac_algorithmic": achieved / peak, "frac_executed": nprod * achieved / peak,
                          "avg_launch_ms": kdur * 1e3, "flop_per_launch": kflop, "executed_mfma_flop_per_launch": nprod * kflop,
                          "executed_mfma_tflops": nprod * achieved,
-                         # split A operand (4 B/element) + split weights (4 B) + fp32 output (4 B) + its split copy (4 B), each once
-                         "algorithmic_bytes_per_launch": (N * 1024 * 12 + 5 * 1024 * 1024 * 4) if h3 else None,
+                         # fp32 operands and result once = A 52 MB + W 21 MB + C 52 MB at M = 12 800
+                         "algorithmic_bytes_per_launch": N * 1024 * 4 * 2 + 5 * 1024 * 1024 * 4,
+                         # what this kernel's formats move at best: split A (hi + 8-bit cross array, 4 B/element), split
+                         # weights (4 B), fp32 output (4 B) and its split copy (4 B), each once
+                         "own_format_bytes_per_launch": (N * 1024 * 12 + 5 * 1024 * 1024 * 4) if h3 else None,
                          "traffic": traffic, "traffic_static": traffic is not None, "traffic_source": traffic_src,
                          # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
                          # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
@@ -492,6 +595,8 @@ def main():
                                       "ms_per_step": dt16 * 1e3, "statistic": "median", "value": B * T / dt16, "unit": "mel-frames/s",
                                       "loss_mel": l16, "loss_rel_diff_vs_parity_mode": abs(l16 - loss_val) / abs(loss_val),
                                       "within_parity_bar": False}
+        if world == 1 and args.full_step:
+            res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd)
     if use_dist:

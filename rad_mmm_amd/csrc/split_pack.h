@@ -83,8 +83,13 @@ __device__ __forceinline__ float store_split1_fmt(void* hi_, void* lo_, long lon
 // element then carries no cross-term correction, i.e. single-fp16-product accuracy.
 __device__ __forceinline__ void raise_sat_flag(int* flag, float amax, float x8_mul = 0.f) {
   if (!flag) return;
-  if (amax > 60000.f) atomicOr(flag, 1);
-  if (x8_mul > 0.f && amax * x8_mul > 448.f) atomicOr(flag, 2);
+  // one atomic per wave at most, and none when the bits are already set (when a tensor saturates, most lanes see it: a
+  // per-lane atomicOr on one address serialises -- measured 13 -> 66 us for a 50 MB split pass)
+  const bool b0 = amax > 60000.f, b1 = x8_mul > 0.f && amax * x8_mul > 448.f;
+  const unsigned long long m0 = __ballot(b0), m1 = __ballot(b1);
+  const int bits = (m0 ? 1 : 0) | (m1 ? 2 : 0);
+  if (bits && (threadIdx.x & 63) == (unsigned)__ffsll((long long)(m0 | m1)) - 1 && (__atomic_load_n(flag, __ATOMIC_RELAXED) & bits) != bits)
+    atomicOr(flag, bits);
 }
 
 }  // namespace radmmm

@@ -3,7 +3,7 @@ gradient buckets all-reduced over RCCL/xGMI while backward is still running.
 
 The reference trains with Lightning `strategy: ddp` (configs/RADMMM_train_config.yaml:28),
 i.e. torch DDP's 25 MB buckets in registration order.  Here the bucket is the flow step:
-each FlowStep's 26.5 M parameters (106 MB fp32) are one flat buffer whose slices ARE the
+each FlowStep's 26.5 M parameters (106 MB fp32) are two flat buffers (upper / lower WN layers) whose slices ARE the
 parameters' .grad tensors (no flatten/unflatten copies); backward visits flows 7..0, every
 step's gradients become final when its autograd node returns, and its bucket is reduced on
 RCCL's stream while the earlier flows are still computing.  With 8 GPUs fully connected by
@@ -40,13 +40,23 @@ def reserve_collective_cus(n: int = RCCL_CUS, total_cus: int = 256) -> None:
 
 
 def default_bucket_key(name: str) -> str:
-    """flows.3.coupling_tfn... -> 'flows.3', also below a parent module (decoder.flows.3... -> 'decoder.flows.3':
-    the reducer wrapped around the whole training step); everything else (LSTM, embeddings, text encoder,
-    attention, attribute predictors: ~10 M parameters against the flows' 27 M each) -> 'misc'."""
+    """flows.3.coupling_tfn... -> 'flows.3.lo' / 'flows.3.hi', also below a parent module (decoder.flows.3... ->
+    'decoder.flows.3.lo': the reducer wrapped around the whole training step); everything else (LSTM, embeddings, text
+    encoder, attention, attribute predictors: ~10 M parameters against the flows' 27 M each) -> 'misc'.
+    A flow step is TWO buckets (round 3): backward walks its WN layers 3, 2, 1, 0, start, so the gradients of the upper
+    layers (in_layers / res_skip_layers 2.. and the end conv: '.hi', ~53 MB) are final half a flow step before the rest
+    ('.lo': 1x1 conv, start conv, layers 0-1) -- their all-reduce starts that much earlier, and at the end of the pass only
+    flow 0's lower half + the LSTM bucket (~80 MB instead of ~132 MB) can still be in flight when backward returns."""
     parts = name.split(".")
     for i in range(len(parts) - 2):
         if parts[i] == "flows" and parts[i + 1].isdigit():
-            return ".".join(parts[: i + 2])
+            hi = False
+            for j in range(i + 2, len(parts) - 1):
+                if parts[j] in ("in_layers", "res_skip_layers") and parts[j + 1].isdigit():
+                    hi = int(parts[j + 1]) >= 2
+                if parts[j] == "end":
+                    hi = True
+            return ".".join(parts[: i + 2]) + (".hi" if hi else ".lo")
     return "misc"
 
 
@@ -67,6 +77,11 @@ class BucketedGradReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized()      # reduce even at world size 1 (RCCL smoke test)
+        # the mean comes out of the collective itself where the backend has it (RCCL: ReduceOp.AVG); gloo (CPU tests) sums
+        # and the buckets are scaled after the wait
+        self._avg = self.active and dist.get_backend(process_group) == "nccl"
+        self.profile = False                     # bench.py: record HIP events around the waits of finish()
+        self._prof_events = None
         if direct is None:
             direct = lambda name: ".affine_param_predictor." in name or ".invtbl_conv." in name
         groups: "OrderedDict[str, List]" = OrderedDict()
@@ -104,6 +119,8 @@ class BucketedGradReducer:
         self._order = list(reversed(range(len(self.buckets))))
         self._next = 0
         self._sink_keys: List[int] = []
+        self._by_ptr: Dict[int, torch.nn.Parameter] = {}
+        self._early: set = set()          # parameters whose gradient was declared final before their node returned
 
     def _make_hook(self, bucket):
         def hook(param):
@@ -111,6 +128,9 @@ class BucketedGradReducer:
             if param.grad is not view and param.grad.data_ptr() != view.data_ptr():
                 view.copy_(param.grad)               # the node did not use the sink (or autograd cloned): one copy
                 param.grad = view
+            if id(param) in self._early:         # counted when its node declared it final (ops.notify_grads_final)
+                self._early.discard(id(param))
+                return
             bucket["pending"] -= 1
             if bucket["pending"] < 0 and self.active:
                 raise RuntimeError("BucketedGradReducer: a second backward between prepare() and finish() would add to "
@@ -121,6 +141,21 @@ class BucketedGradReducer:
                 self._launch_ready()
         return hook
 
+    def _grads_final(self, ptrs) -> None:
+        """ops.notify_grads_final: these parameters' sinks hold their final gradient although the node has not returned"""
+        if not self.active:
+            return
+        for ptr in ptrs:
+            p = self._by_ptr.get(ptr)
+            if p is None or not self._direct[id(p)] or id(p) in self._early or ptr in self._sink_keys_live:
+                continue                      # (a sink still registered = the node did not write through it: wait for the hook)
+            self._early.add(id(p))
+            b = self._by_param[id(p)]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                b["ready"] = True
+        self._launch_ready()
+
     def _launch_ready(self, force: bool = False) -> None:
         """issue the all-reduces of the leading ready buckets of the fixed order (all remaining ones with force)"""
         while self._next < len(self._order):
@@ -129,7 +164,8 @@ class BucketedGradReducer:
                 return
             # RCCL's stream waits for the kernels already queued on the compute stream, then runs concurrently with the
             # rest of backward
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg,
+                                          async_op=True)
             self._next += 1
 
     def prepare(self) -> None:
@@ -138,6 +174,10 @@ class BucketedGradReducer:
         from . import ops
         self._drop_sinks()
         self._next = 0
+        self._early.clear()
+        self._by_ptr = {p.data_ptr(): p for b in self.buckets for p in b["params"]}
+        if self._grads_final not in ops.GRAD_FINAL_HOOKS:
+            ops.GRAD_FINAL_HOOKS.append(self._grads_final)
         for b in self.buckets:
             if b["n_direct"] < b["flat"].numel():
                 b["flat"][b["n_direct"]:].zero_()
@@ -153,12 +193,19 @@ class BucketedGradReducer:
                 elif p.grad is None or p.grad.data_ptr() != view.data_ptr():
                     p.grad = view
 
+    @property
+    def _sink_keys_live(self):
+        from . import ops
+        return ops.GRAD_SINKS.keys()
+
     def _drop_sinks(self) -> None:
         """remove THIS reducer's sinks only (another reducer in the process keeps its direct writes)"""
         from . import ops
         for k in self._sink_keys:
             ops.GRAD_SINKS.pop(k, None)
         self._sink_keys = []
+        if self._grads_final in ops.GRAD_FINAL_HOOKS:
+            ops.GRAD_FINAL_HOOKS.remove(self._grads_final)
 
     def finish(self) -> None:
         """Wait for the outstanding reductions and turn sums into means (call after backward)."""
@@ -173,10 +220,28 @@ class BucketedGradReducer:
             return
         self._launch_ready(force=True)        # buckets with a parameter without gradient this step, in sequence
         inv = 1.0 / self.world
-        for b in self.buckets:
-            b["handle"].wait()
-            if self.world > 1:
+        ev = None
+        if self.profile and self.buckets[0]["flat"].is_cuda:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.buckets) + 1)]
+            ev[0].record()                    # the compute stream has reached the end of backward
+        for n, i in enumerate(self._order):   # in the order the collectives were issued
+            b = self.buckets[i]
+            b["handle"].wait()                # the compute stream waits for RCCL's stream here: exposed communication
+            if ev is not None:
+                ev[n + 1].record()
+            if self.world > 1 and not self._avg:
                 b["flat"].mul_(inv)
+        self._prof_events = ev
+
+    def exposed_comm_ms(self):
+        """(total, [per bucket, in issue order]) milliseconds the compute stream spent waiting for all-reduces in the last
+        finish() -- the part of the gradient exchange that backward did not hide.  Needs profile = True; synchronises."""
+        ev = self._prof_events
+        if not ev:
+            return None, []
+        ev[-1].synchronize()
+        per = [ev[i].elapsed_time(ev[i + 1]) for i in range(len(ev) - 1)]
+        return sum(per), per
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=None) -> None:

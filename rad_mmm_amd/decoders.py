@@ -144,6 +144,16 @@ class RADMMMFlow(nn.Module):
         # 2e-6, 1.07x the step time), "fp32" (fp32 MFMA), "f16" (single product: throughput mode, outside the 1e-4 bar)
         self.gemm_precision = os.environ.get("RADMMM_PRECISION", "f8x")
         self._grad_scale = None
+        # Runtime guard of the FP8-cross scheme (its 8-bit cross terms have a fixed range per tensor class, so its accuracy
+        # depends on the data; the parity tests cover several weight / input distributions, this covers the live ones): on
+        # the first training forward and every `precision_guard_every` after it, the LAST flow step (deepest hidden
+        # states) is run a second time, without gradients, in the exact split scheme ("h3") on the same input, and the
+        # relative difference of its outputs is published to pinned memory behind an event.  A later forward that finds
+        # it above `precision_guard_tol` switches the decoder to "h3" (1.07x the step time, 2e-6) with a RuntimeWarning
+        # -- or raises FloatingPointError under RADMMM_CHECK_SATURATION=1.  No host synchronisation; 0 disables.
+        self.precision_guard_every = int(os.environ.get("RADMMM_PRECISION_GUARD_EVERY", "1000"))
+        self.precision_guard_tol = 5e-5
+        self._guard = {"n": 0, "host": None, "event": None, "pending": False, "last": None, "trips": 0}
         # context LSTM recurrence: "hip" = csrc/lstm.hip (default), "miopen" = torch.nn.LSTM (MIOpen)
         self.lstm_impl = os.environ.get("RADMMM_LSTM", "hip") if use_context_lstm else "miopen"
         self.lstm_two_streams = (use_context_lstm and context_lstm_norm is None and
@@ -375,18 +385,67 @@ class RADMMMFlow(nn.Module):
         scale_box = self._grad_scale   # gradient scale + saturation flag of the split-operand path (no host sync in steady state)
         if torch.is_grad_enabled():
             scale_box.new_forward(mel.device)
+        guard_now = self._guard_poll(mel.device)
         for i, flow in enumerate(self.flows):
             off = 0
             if i in self.exit_steps:
                 z_out.append(z[:, : self.n_early_size])
                 off = self.n_early_size
+            z_in = z
             z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off, self.gemm_precision, scale_box)
+            if guard_now and i == len(self.flows) - 1:
+                self._guard_measure(flow, z_in, z, cond2, unfolded, lens32, B, Tg, off)
             log_s_list.append(log_s.view(B, Tg, -1).transpose(1, 2))
             log_det_W_list.append(log_det_W)
         z_out.append(z[:, : self.flows[-1].n_mel_channels])
         z_mel = torch.cat([t.reshape(B, Tg, -1) for t in z_out], 2).transpose(1, 2).contiguous()
         return {"z_mel": z_mel, "log_det_W_list": log_det_W_list, "log_s_list": log_s_list,
                 "context_w_spkvec": cond.transpose(1, 2)}
+
+
+    # ------------------------------------------------------------------ FP8-cross runtime guard (see __init__)
+    def _guard_poll(self, dev) -> bool:
+        """adopt a finished measurement; -> whether this forward takes one"""
+        g = self._guard
+        if g["pending"] and g["event"].query():
+            g["pending"] = False
+            g["last"] = float(g["host"][0])
+            if not (g["last"] <= self.precision_guard_tol):          # (NaN trips it too)
+                g["trips"] += 1
+                import os
+                import warnings
+                msg = (f"FP8-cross scheme off its accuracy budget on live data: the last flow step's output differs from the "
+                       f"exact split scheme by {g['last']:.2e} (> {self.precision_guard_tol:.0e} relative); switching this "
+                       f"decoder to RADMMM_PRECISION=h3")
+                if os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1":
+                    raise FloatingPointError(msg)
+                warnings.warn(msg, RuntimeWarning)
+                self.gemm_precision = "h3"
+        if not (self.training and torch.is_grad_enabled() and self.gemm_precision == "f8x" and self.precision_guard_every > 0):
+            return False
+        n = g["n"]
+        g["n"] = n + 1
+        return n % self.precision_guard_every == 0 and not g["pending"]
+
+    def _guard_measure(self, flow, z_in, z_f8x, cond2, unfolded, lens32, B, Tg, off):
+        g = self._guard
+        with torch.no_grad():
+            z_ref, _, _ = flow.forward_cl(z_in.detach(), cond2.detach(), unfolded, lens32, B, Tg, off, "h3", {})
+            rel = (z_f8x.detach() - z_ref).abs().max() / z_ref.abs().max().clamp_min(1e-30)
+            if g["host"] is None:
+                g["host"] = torch.zeros(1, dtype=torch.float32).pin_memory()
+                g["event"] = torch.cuda.Event()
+            g["host"].copy_(rel.reshape(1), non_blocking=True)
+            g["event"].record()
+            g["pending"] = True
+
+    def precision_guard_status(self):
+        """(last measured relative difference or None, number of times the guard switched the scheme) -- synchronous"""
+        g = self._guard
+        if g["pending"]:
+            g["event"].synchronize()
+            self._guard_poll(None)
+        return g["last"], g["trips"]
 
 
 class _UnfoldedLens:

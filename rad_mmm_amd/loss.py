@@ -35,25 +35,27 @@ def compute_flow_loss(z, log_det_W_list, log_s_list, n_elements, n_dims, lens32,
 
 
 class AttentionCTCLoss(nn.Module):
-    """loss.py:112-141 (per-item log_softmax + torch CTC; stock torch ops)."""
+    """loss.py:112-141: blank column (log-prob -1) in front, per-utterance log_softmax over ITS text positions, torch's
+    CTC with targets 1 .. len, zero_infinity, mean over the batch of (loss / target length).  The reference loops over
+    the utterances with two host reads each (`int(in_lens[bid])`): 64 synchronisations per step at B = 32.  Here the batch
+    goes through ONE F.ctc_loss call: text positions beyond an utterance's length are taken out of its softmax with a
+    -1e4 logit (exp underflows to exactly 0 in fp32, so every remaining value is the per-utterance softmax's; a literal
+    -inf would turn torch's CTC gradient, exp(lp) - exp(alpha*beta - lp), into NaN at those positions), frames beyond its
+    mel length are ignored through input_lengths.  Same values as the loop (tests/golden/tts_step.npz), no host sync."""
 
     def __init__(self, blank_logprob=-1):
         super().__init__()
         self.blank_logprob = blank_logprob
-        self.CTCLoss = nn.CTCLoss(zero_infinity=True)
 
     def forward(self, attn_logprob, in_lens, out_lens):
-        padded = F.pad(attn_logprob, (1, 0), value=self.blank_logprob)
-        total = 0.0
-        B = attn_logprob.shape[0]
-        for bid in range(B):
-            kl, ql = int(in_lens[bid]), int(out_lens[bid])
-            target = torch.arange(1, kl + 1, device=attn_logprob.device).unsqueeze(0)
-            lp = padded[bid].permute(1, 0, 2)[:ql, :, : kl + 1]
-            lp = torch.log_softmax(lp, -1)
-            total = total + self.CTCLoss(lp, target, input_lengths=out_lens[bid: bid + 1],
-                                         target_lengths=in_lens[bid: bid + 1])
-        return total / B
+        padded = F.pad(attn_logprob, (1, 0), value=self.blank_logprob)[:, 0]          # [B, T_mel, 1 + T_txt]
+        B, _, C = padded.shape
+        cls = torch.arange(C, device=padded.device)
+        lp = padded.masked_fill(cls[None, None, :] > in_lens[:, None, None], -1e4)
+        lp = torch.log_softmax(lp, -1).transpose(0, 1)                               # [T_mel, B, C]
+        targets = cls[1:][None].expand(B, -1)                                        # 1 .. T_txt; the first len count
+        loss = F.ctc_loss(lp, targets, out_lens, in_lens, blank=0, reduction="none", zero_infinity=True)
+        return (loss / in_lens.clamp_min(1).to(loss.dtype)).sum() / B
 
 
 class AttentionBinarizationLoss(nn.Module):

@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
     broadcast_module_state(model, 0)
     red = BucketedGradReducer(model)
     keys = [b["key"] for b in red.buckets]
-    assert keys == ["flows.0", "flows.1", "flows.2", "misc"], keys
+    assert keys == ["flows.0.lo", "flows.1.lo", "flows.2.lo", "misc"], keys
     g = torch.Generator().manual_seed(7)
     data = torch.randn(world, 4, 5, 6, generator=g)
     ok = True
@@ -107,8 +107,11 @@ def test_bucketed_reducer_world2_gloo():
 
 def test_bucket_key():
     from rad_mmm_amd.ddp import default_bucket_key
-    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.start.weight_v") == "flows.3"
-    assert default_bucket_key("decoder.flows.11.invtbl_conv.lower") == "decoder.flows.11"      # reducer around the whole step
+    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.start.weight_v") == "flows.3.lo"
+    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_g") == "flows.3.lo"
+    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.res_skip_layers.2.bias") == "flows.3.hi"
+    assert default_bucket_key("flows.3.coupling_tfn.affine_param_predictor.end.weight") == "flows.3.hi"
+    assert default_bucket_key("decoder.flows.11.invtbl_conv.lower") == "decoder.flows.11.lo"   # reducer around the whole step
     assert default_bucket_key("f0_predictor.feat_pred.lstm.weight_hh_l0") == "misc"
     assert default_bucket_key("context_lstm.weight_ih_l0") == "misc"
 

@@ -1,0 +1,235 @@
+"""Round-3 GPU parity tests (all through the C ABI):
+  * the FP8-cross scheme (default product scheme) on MORE THAN ONE weight / input distribution, at benchmark-like row
+    counts, forward + NLL + whole backward against the CPU oracle;
+  * the runtime precision guard of the decoder (3b): it measures, and a forced failure switches the scheme;
+  * BASELINE configs[4] at its defining size -- the 16 kHz-dims decoder with 2 piecewise-quadratic spline flows (+ masked
+    batch-norm FiLM predictors), B = 32, T = 2000 ragged -- against the oracle on its two shortest utterances (item 4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+KW2 = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+           n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+           scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True,
+           n_conv_layers_per_step=4, n_flows=8)
+
+
+def T(d):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()}
+
+
+def _variant_state(O, cfg, variant):
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    for k in sd:
+        if "affine_param_predictor" not in k:
+            continue
+        if variant == "gain_div4" and (k.endswith("weight_g") or k.endswith("end.weight")):
+            sd[k] = sd[k] * 0.25                         # every WN conv's gain and the end conv: hidden states shrink 4x per layer
+        if variant == "gain_x4":
+            # hidden states 4x larger through the whole stack (the start conv's gain), the coupling kept in its working range
+            # by the end conv (x4 on EVERY gain drives tanh(.) + 1 to its 1e-6 floor in both implementations: log s = -13.8,
+            # a degenerate flow that says nothing about the arithmetic)
+            if k.endswith("start.weight_g"):
+                sd[k] = sd[k] * 4.0
+            if k.endswith("end.weight"):
+                sd[k] = sd[k] * 0.25
+    return sd
+
+
+@pytest.mark.parametrize("variant", ["gain_x4", "gain_div4", "mel_var_x3", "after_20_radam_steps"])
+def test_f8x_full_backward_on_other_distributions(variant, monkeypatch):
+    """The RADTTS decoder (8 flows, WN 1024 x 4) in the DEFAULT product scheme, B = 12, T = 800 ragged (4 800 grouped
+    frames: the wide-tile FP8-cross kernels, as at the benchmark size), forward + NLL + whole backward against the CPU
+    oracle, on distributions the round-2 tests did not cover: weight-norm gains x4 and /4 (hidden states far larger /
+    smaller than the e4m3 exponents were chosen for), mel with 3x the variance, and the state 20 RAdam steps away from the
+    procedural weights.  Bars: z / NLL 1e-4 (north_star), gradient norms 5e-4, gradient elements 5e-4 of the tensor max."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", "f8x")
+    cfg = O.DecoderConfig(**KW2)
+    sd = _variant_state(O, cfg, variant)
+    dec = RADMMMFlow(use_accent=True, **KW2)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    assert dec.gemm_precision == "f8x"
+    dec.precision_guard_every = 0
+    B, Tn = 12, 800
+    b = T(O.synthetic_batch(B, Tn, cfg, 777, ragged=True))
+    if variant == "mel_var_x3":
+        b["mel"] = (b["mel"] - 2.5) * (3.0 ** 0.5) + 2.5
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    crit = RADMMMLoss(n_group_size=2)
+    if variant == "after_20_radam_steps":
+        from rad_mmm_amd.optim import FlatRAdam
+        opt = FlatRAdam(dec.named_parameters(), lr=1e-3, weight_decay=1e-6)      # the reference's optimizer settings
+        for _ in range(20):
+            opt.zero_grad()
+            o = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+            crit(o, None, sl, 0)["loss_mel"][0].backward()
+            opt.clip_grad_norm(1.0)
+            opt.step()
+        opt.zero_grad()
+        sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    mel = gb["mel"].clone().requires_grad_(True)
+    ctx = gb["context"].clone().requires_grad_(True)
+    for q in dec.parameters():
+        q.grad = None
+    out = dec(mel, gb["spk"], ctx, sl, gb["f0"], gb["energy"], gb["accent"])
+    lm = crit(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    torch.cuda.synchronize()
+    p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
+             and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
+    omel = b["mel"].clone().requires_grad_(True)
+    octx = b["context"].clone().requires_grad_(True)
+    ro = O.decoder_forward(p, cfg, omel, b["spk"], octx, b["lengths"], b["f0"], b["energy"], b["accent"])
+    lo, _ = O.decoder_loss(ro, b["lengths"], 2)
+    lo.backward()
+    ul = b["lengths"] // 2
+    m = (torch.arange(Tn // 2)[None] < ul[:, None])[:, None]
+    zh, zo = out["z_mel"].detach().cpu(), ro["z_mel"].detach()
+    zerr = rel_err(zh * m, zo * m)
+    lerr = abs(float(lm) - float(lo)) / abs(float(lo))
+    worst, worst_n, worst_el = 0.0, "", 0.0
+    for n, q in dec.named_parameters():
+        go = p[n].grad
+        gn = float(go.norm())
+        mine = float(q.grad.norm())
+        r = abs(mine - gn) / (gn + 1e-6)
+        el = float((q.grad.cpu() - go).abs().max()) / (float(go.abs().max()) + 1e-12)
+        if r > worst:
+            worst, worst_n = r, n
+        if float(go.abs().max()) >= 1e-7:
+            worst_el = max(worst_el, el)
+    flagged = dec._grad_scale.x8_saturated_passes
+    hmax = float(max(o_.abs().max() for o_ in out["log_s_list"]))
+    print(f"f8x on '{variant}': z rel {zerr:.2e}, loss rel {lerr:.2e}, grad.mel rel {rel_err(mel.grad.cpu(), omel.grad):.2e}, "
+          f"worst grad-norm rel {worst:.2e} ({worst_n}), worst elementwise grad rel {worst_el:.2e}, max |log s| {hmax:.2f}, "
+          f"e4m3-saturation reports so far {flagged}")
+    assert zerr < 1e-4 and lerr < 1e-4
+    assert rel_err(mel.grad.cpu(), omel.grad) < 5e-4 and rel_err(ctx.grad.cpu(), octx.grad) < 5e-4
+    assert worst < 5e-4, (worst_n, worst)
+    assert worst_el < 5e-4
+    dec.check_saturation()
+
+
+def test_precision_guard_measures_and_switches(monkeypatch):
+    """The decoder's runtime guard: the first training forward measures the FP8-cross scheme against the exact split
+    scheme on the last flow step (asynchronously); with the tolerance forced to zero the next poll switches the decoder
+    to h3 with a RuntimeWarning (FloatingPointError under RADMMM_CHECK_SATURATION=1)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    monkeypatch.setenv("RADMMM_PRECISION", "f8x")
+    monkeypatch.setenv("RADMMM_F8X_MIN_ROWS", "0")
+    monkeypatch.delenv("RADMMM_CHECK_SATURATION", raising=False)
+    kw = dict(KW2, n_flows=2)
+    cfg = O.DecoderConfig(**kw)
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(T(O.procedural_decoder_state(O.decoder_state_shapes(cfg))))
+    dec = dec.to(DEV).train()
+    b = {k: v.to(DEV) for k, v in T(O.synthetic_batch(4, 256, cfg, 5, ragged=True)).items()}
+    sl = SequenceLength(b["lengths"])
+
+    def fwd():
+        return dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+
+    fwd()
+    last, trips = dec.precision_guard_status()
+    assert last is not None and 0.0 < last < 5e-5 and trips == 0 and dec.gemm_precision == "f8x"
+    z_f8x = fwd()["z_mel"].detach().clone()
+    dec.precision_guard_every = 1
+    dec.precision_guard_tol = 0.0                            # any difference is now "off budget"
+    fwd()
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="switching this decoder"):
+        z_h3 = fwd()["z_mel"].detach()
+    assert dec.gemm_precision == "h3" and dec.precision_guard_status()[1] == 1
+    assert 0.0 < rel_err(z_f8x.cpu(), z_h3.cpu()) < 1e-4     # really another scheme, and both inside the parity bar
+    # strict mode raises instead
+    dec.gemm_precision = "f8x"
+    monkeypatch.setenv("RADMMM_CHECK_SATURATION", "1")
+    fwd()
+    torch.cuda.synchronize()
+    with pytest.raises(FloatingPointError, match="accuracy budget"):
+        fwd()
+
+
+def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
+    """BASELINE configs[4]: configs/RADMMM_16khz_model_config.yaml dims + n_splines = 2 (decoders.py:94,132), 8 flows, masked
+    batch-norm in the FiLM predictors (training mode: statistics over the whole batch), B = 32, T = 2000 ragged -- the
+    launches no other test reaches (M = 32 000 tiles, split-K weight gradients over 32 000 frames, FiLM convs at 32 000
+    rows, the spline kernels on 266 MB of parameters per flow).  The batch-norm couples the utterances, so the CPU oracle
+    runs the WHOLE batch (forward + NLL + backward, ~1-2 min on the GPU box's host cores): z, log-det, log_s sums and NLL
+    at 1e-4; d loss / d mel at 2e-3 (L2) and the parameter-gradient norms at 1e-3: measured 9.9e-4 / 5.6e-4 in BOTH product
+    schemes (RADMMM_TEST_C5_PRECISION=h3: z 2e-6, same gradient figures), i.e. not the split arithmetic -- the batch
+    statistics of the masked batch-norm (E[x^2] - mean^2 over 32 000 frames in fp32) and their gradient sums are evaluated
+    in a different order than torch-CPU's, and the spline flows sit right on top of the mel input."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    import os
+    monkeypatch.setenv("RADMMM_PRECISION", os.environ.get("RADMMM_TEST_C5_PRECISION", "f8x"))
+    kw = dict(KW2, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
+    cfg = O.DecoderConfig(**kw)
+    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    dec.precision_guard_every = 0
+    B, Tn = 32, 2000
+    b = T(O.synthetic_batch(B, Tn, cfg, 2024, ragged=True))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    mel = gb["mel"].clone().requires_grad_(True)
+    torch.cuda.reset_peak_memory_stats()
+    out = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+    crit = RADMMMLoss(n_group_size=2)
+    lm = crit(out, None, sl, 0)["loss_mel"][0]
+    lm.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert torch.isfinite(out["z_mel"]).all() and torch.isfinite(lm) and torch.isfinite(mel.grad).all()
+    p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
+             and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
+    omel = b["mel"].clone().requires_grad_(True)
+    ro = O.decoder_forward(p, cfg, omel, b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
+    lo, _ = O.decoder_loss(ro, b["lengths"], 2)
+    lo.backward()
+    ul = b["lengths"] // 2
+    m = (torch.arange(Tn // 2)[None] < ul[:, None])[:, None]
+    zerr = rel_err(out["z_mel"].detach().cpu() * m, ro["z_mel"].detach() * m)
+    lerr = abs(float(lm.detach()) - float(lo.detach())) / abs(float(lo.detach()))
+    lserr = 0.0
+    for a, c in zip(out["log_s_list"], ro["log_s_list"]):
+        sa, sc = float((a.detach().cpu() * m).sum()), float((c.detach() * m).sum())
+        lserr = max(lserr, abs(sa - sc) / max(1.0, abs(sc)))
+    for a, c in zip(out["log_det_W_list"], ro["log_det_W_list"]):
+        assert abs(float(a) - float(c)) < 1e-4 * max(1.0, abs(float(c)))
+    gerr = rel_err(mel.grad.cpu(), omel.grad)
+    gd = (mel.grad.cpu() - omel.grad).abs()
+    gl2 = float(gd.norm() / omel.grad.norm())
+    gfrac = float((gd > 5e-4 * omel.grad.abs().max()).float().mean())
+    worst, worst_n = 0.0, ""
+    for n, q in dec.named_parameters():
+        assert q.grad is not None and torch.isfinite(q.grad).all(), n
+        go = p[n].grad
+        gn, mine = float(go.norm()), float(q.grad.norm())
+        r = abs(mine - gn) / (gn + 1e-6)
+        if r > worst and gn > 1e-7:
+            worst, worst_n = r, n
+    print(f"configs[4] at B=32, T=2000: z rel {zerr:.2e}, log_s sums rel {lserr:.2e}, NLL rel {lerr:.2e}, d/d mel max-rel {gerr:.2e} / L2-rel {gl2:.2e} / fraction of elements off by > 5e-4 of the max {gfrac:.2e}, "
+          f"worst grad-norm rel {worst:.2e} ({worst_n}); peak device memory {peak:.1f} GiB")
+    assert zerr < 1e-4 and lserr < 1e-4 and lerr < 1e-4
+    assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3
+    assert worst < 1e-3, (worst_n, worst)
