@@ -456,11 +456,14 @@ int radmmm_wgrad_rm8(const void* GYh, const void* GYx, int ldg, int g8_exp, cons
  * radmmm_lstm_bwd overwrites G with the pre-activation gradients dG; the input / weight / bias
  * gradients are plain GEMMs of dG (dW_ih = dG^T x, dx = dG W_ih, db = colsum dG, dW_hh[d] = dG_d^T h_prev).
  * gscale: device scalar, power of two bringing dG into fp16 range (e.g. 2^floor(log2(64 / max|dy|))).
- * One launch per time step by default; RADMMM_LSTM_PERSISTENT=1 runs all steps in one launch with a grid
- * barrier (counters in the tail of hsplit / dcbuf) when the grid fits one workgroup per CU. */
+ * All T steps run in ONE launch when the grid (ceil(H/8) x 2 x ceil(B/32) workgroups) fits one workgroup per CU: the
+ * workgroups hand h / the partial recurrent gradients from step to step through memory, the data being its own ready
+ * flag (csrc/lstm.hip).  The forward pass then needs hseq, radmmm_lstm_hseq_bytes(B, T, H) bytes of scratch (one operand
+ * slot per step); that function returns 0, and hseq may be null, when the dimensions take the launch-per-step path. */
 int64_t radmmm_lstm_scratch_bytes(int B, int H, int which);
+int64_t radmmm_lstm_hseq_bytes(int B, int T, int H);
 int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, const int32_t* lens, void* wsplit, void* hsplit,
-                    int B, int T, int H, radmmm_stream_t stream);
+                    void* hseq, int B, int T, int H, radmmm_stream_t stream);
 int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const float* W_hh, const int32_t* lens, void* wtpack,
                     float* P, float* dcbuf, int B, int T, int H, const float* gscale, radmmm_stream_t stream);
 

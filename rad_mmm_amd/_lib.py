@@ -158,7 +158,7 @@ def _load() -> C.CDLL:
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
         "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
-        "radmmm_lstm_fwd": [p, p, p, p, p, p, p, i, i, i, p],
+        "radmmm_lstm_fwd": [p, p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_stream_create_masked": [i, C.POINTER(C.c_void_p)],
         "radmmm_stream_destroy": [p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
@@ -185,7 +185,7 @@ def _load() -> C.CDLL:
                        "radmmm_mas_scratch_bytes": [i, i, i],
                        "radmmm_film_bwd_scratch_floats": [i, i],
                        "radmmm_stft_mel_scratch_floats": [i, i, i, i, i],
-                       "radmmm_lstm_scratch_bytes": [i, i, i],
+                       "radmmm_lstm_scratch_bytes": [i, i, i], "radmmm_lstm_hseq_bytes": [i, i, i],
                        "radmmm_sumsq_scratch_floats": []}.items():
         fn = getattr(lib, name)
         fn.argtypes = args

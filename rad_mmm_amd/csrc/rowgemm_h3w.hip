@@ -9,6 +9,8 @@ namespace radmmm {
 int launch_h3d_pr1(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 int launch_h3d_pr2(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 int launch_h3d_pr3(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
+// rowgemm_rs.hip: role-split kernel (8 consumer + 4 producer waves), FP8-cross scheme, EK_PLAIN / EK_SPLIT
+int launch_rowgemm_rs(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 }  // namespace radmmm
 
 namespace {
@@ -98,7 +100,15 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
       ek = p.Ch ? EK_SPLIT : EK_PLAIN;
     }
   }
-  if (d.nprod == 2) return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);       // FP8 cross terms
+  if (d.nprod == 2) {                                                                 // FP8 cross terms
+    static const int rs_mode = [] {                    // RADMMM_DEBUG: RADMMM_RS=0 / 1 forces the 4-wave / role-split kernel
+      const char* e = debug_env("RADMMM_RS");
+      return e ? atoi(e) : -1;
+    }();
+    const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT);   // (that instantiation spills)
+    if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
+    return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);
+  }
   if (d.nprod == 1) return launch_h3d_pr1(mb, ek, d, stream, a_bytes, b_bytes);       // 16-bit throughput mode
   return launch_h3d_pr3(mb, ek, d, stream, a_bytes, b_bytes);
 }

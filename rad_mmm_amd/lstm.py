@@ -53,7 +53,9 @@ class BiLSTMFn(torch.autograd.Function):
         c = torch.empty(B * T, 2 * H, device=x.device, dtype=torch.float32)
         wsplit = _scratch(B, H, 0, x)
         hsplit = _scratch(B, H, 1, x)
-        check(lib.radmmm_lstm_fwd(ptr(G), ptr(W_hh), ptr(y), ptr(c), ptr(lens), ptr(wsplit), ptr(hsplit), B, T, H,
+        nq = int(lib.radmmm_lstm_hseq_bytes(B, T, H))            # > 0: all T steps in one launch, one operand slot per step
+        hseq = torch.empty(nq // 4, device=x.device, dtype=torch.float32) if nq else None
+        check(lib.radmmm_lstm_fwd(ptr(G), ptr(W_hh), ptr(y), ptr(c), ptr(lens), ptr(wsplit), ptr(hsplit), ptr(hseq), B, T, H,
                                   stream()), "lstm_fwd")
         ctx.dims = (B, T, I, H)
         ctx.save_for_backward(x2, G, c, y, W_ih, W_hh, lens if lens is not None else torch.empty(0, device=x.device), *xpair)
