@@ -11,6 +11,9 @@ int launch_h3d_pr2(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t 
 int launch_h3d_pr3(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 // rowgemm_rs.hip: role-split kernel (8 consumer + 4 producer waves), FP8-cross scheme, EK_PLAIN / EK_SPLIT
 int launch_rowgemm_rs(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
+// rowgemm_win.hip: 5-tap convs with the A rows of a k slice fetched once for all taps (shared window), FP8-cross scheme
+bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d);
+int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 }  // namespace radmmm
 
 namespace {
@@ -107,6 +110,8 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
     }();
     const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT);   // (that instantiation spills)
     if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
+    const char* we = debug_env("RADMMM_WIN");         // RADMMM_DEBUG: RADMMM_WIN=0 keeps the per-tap A tiles (A/B runs, tests)
+    if (!(we && atoi(we) == 0) && rowgemm_win_ok(mb, ek, d)) return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
     return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);
   }
   if (d.nprod == 1) return launch_h3d_pr1(mb, ek, d, stream, a_bytes, b_bytes);       // 16-bit throughput mode

@@ -238,3 +238,53 @@ def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
     assert zerr < 1e-4 and lserr < 1e-4 and lerr < 1e-4
     assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3
     assert worst < 1e-3, (worst_n, worst)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Shared-window 5-tap GEMM (csrc/rowgemm_win.hip): the A rows of a k slice are fetched once for all five taps.  Same
+# operands, same MFMAs in the same order as the per-tap-tile kernel (rowgemm_h3d): the outputs must be IDENTICAL, bit for
+# bit, whatever the dilation, the utterance lengths and the position of the utterance boundaries inside the tiles.
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,lens,mb", [(3, 300, [300, 251, 170], 7), (4, 256, [256, 256, 100, 31], 8), (2, 500, [500, 333], 7),
+                                         (5, 224, [224, 224, 223, 1, 120], 7)])
+@pytest.mark.parametrize("dil", [1, 2, 4, 8])
+@pytest.mark.parametrize("kind", ["fwd", "dgrad"])
+def test_shared_window_gemm_is_bit_identical_to_per_tap_tiles(B, T, lens, mb, dil, kind, monkeypatch):
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    dev = torch.device("cuda:0")
+    Wc, taps = 512, 5
+    N = B * T
+    gen = torch.Generator().manual_seed(B * 1000 + T + dil)
+    x = torch.nn.functional.softplus(torch.randn(N, Wc, generator=gen) * 2).to(dev) if kind == "fwd" else (torch.randn(N, Wc, generator=gen) * 3e-3).to(dev)
+    w = (torch.randn(Wc, Wc, taps, generator=gen) * 0.03).to(dev)
+    bias = (torch.randn(Wc, generator=gen) * 0.1).to(dev)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=dev)
+    S = 1.0 if kind == "fwd" else 2048.0
+    xe = ops.X8_ACT_EXP if kind == "fwd" else ops.X8_GRAD_EXP
+    Ah, Al = ops.split_f16(x, Wc, S, Wc, 2, xe)
+    Wh, Wl, _ = ops.split_weight(w, None, Wc, nprod=2)
+    monkeypatch.setenv("RADMMM_H3W_MB", str(mb))
+    outs = {}
+    for win in ("0", "1"):
+        monkeypatch.setenv("RADMMM_WIN", win)
+        Cf = torch.full((N, Wc), float("nan"), device=dev)
+        Ch, Cl = ops._halves(N, Wc, like=x)
+        Clo = torch.empty(N, Wc, device=dev, dtype=torch.float16)
+        Ch.fill_(float("nan")), Cl.zero_(), Clo.fill_(float("nan"))
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        common = dict(nprod=2, a8_exp=xe, b8_exp=ops.X8_W_EXP, acc_scale=1.0 / (S * ops.W_SCALE), T=T, sat_flag=flag,
+                      Ah=Ah, Al=Al, lda_h=Wc, Bh=Wh, Bl=Wl, ldb_h=Wc, b_tap_stride_h=Wh.stride(0), C=Cf, ldc=Wc, M=N, N=Wc,
+                      K=Wc, taps=taps, dil=dil, lens=lens_d, Ch=Ch, Cl=Cl, Clo=Clo, ldch=Wc, split_fmt=ops.SPLIT_X8A,          # (act=1 below: RADMMM_ACT_SOFTPLUS)
+                      ch_x8_exp=xe)
+        if kind == "fwd":           # the in_layer conv of a WN layer (partial conv, softplus, split copy): ops.py forward
+            rowgemm_h3(sign=1, a_mask_mode=1, bias=bias, pconv=1, ratio_taps=taps, ratio_dil=dil, postmask=1,
+                       act=1, ch_scale=1.0, **common)
+        else:                       # its data gradient (mirrored taps, no input mask, premask)
+            rowgemm_h3(sign=-1, a_mask_mode=0, premask=1, ch_scale=S, **common)
+        torch.cuda.synchronize()
+        outs[win] = (Cf.cpu(), Ch.cpu(), Cl.cpu(), Clo.cpu())
+    for name, a, b in zip(("C", "Ch", "Cl (8-bit cross array)", "Clo"), outs["1"], outs["0"]):
+        assert torch.equal(a.view(torch.int16 if a.dtype == torch.float16 else torch.int32),
+                           b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)), name
+    assert bool(torch.isfinite(outs["1"][0]).all()) and float(outs["1"][0].abs().max()) > 0
