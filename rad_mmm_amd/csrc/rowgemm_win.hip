@@ -24,8 +24,11 @@
 //
 // Everything else is rowgemm_h3d's: one workgroup per CU, (32 MB) x 256 tile, 4 waves x (MB x 2) accumulators, B rows
 // interleaved for the direct epilogue (rowgemm_h3w_kernel.h), one barrier per K step, pinned instruction order.
-// Scope: taps = 5, dilation <= 8, FP8-cross scheme, epilogue kinds PLAIN / SPLIT / DGRAD, MB 7 / 8, no extra K segment
+// Scope: taps = 5, dilation <= 8, FP8-cross scheme, epilogue kinds PLAIN / SPLIT / DGRAD (the latter also with the extra K
+// segment of the fused data gradient), MB 7 / 8
 // (rowgemm_h3w.hip decides; everything else keeps rowgemm_h3d).
+#include <type_traits>
+
 #include "rowgemm_h3w_kernel.h"
 
 namespace {
@@ -45,26 +48,30 @@ struct WGeo {
   static constexpr int DUMP = W_BASE + 2 * W_BYTES; // 1 KiB per wave for the surplus DMA slots
   static constexpr int SMEM = DUMP + 4096;
   static constexpr int NPW = (2 * WP + 3) / 4;      // window pieces per wave and k slice
-  static constexpr int SPT = (NPW + WTAPS - 1) / WTAPS;   // ... per K step
-  static constexpr int NP = 8 + SPT;                // DMA pieces per wave and K step
+  static constexpr int WPT = (NPW + 2) / 3;         // ... per K step, all in the first three taps of the slice before
+  static constexpr int nw(int tap) { return tap >= 3 ? 0 : (NPW - WPT * tap < WPT ? (NPW - WPT * tap > 0 ? NPW - WPT * tap : 0) : WPT); }
+  static constexpr int bstart(int tap) { return nw(tap) > 3 ? nw(tap) : 3; }   // first item that may overwrite the B stage
   static_assert(W_BASE % 1024 == 0 && W_BYTES % 1024 == 0 && SMEM <= 160 * 1024, "LDS map");
 };
 
-template <int MB, int T>
+template <int MB, int TAP, int T>
 __device__ __forceinline__ void pin_items_win() {
-  constexpr int NT = 2 * MB, NP = WGeo<MB>::NP;
+  using G = WGeo<MB>;
+  constexpr int NT = 2 * MB;
   if constexpr (T < NT - LOOKAHEAD) {
     __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, T == 0 ? 2 : 3, 0);
-    if constexpr (T < NP) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
-    pin_items_win<MB, T + 1>();
+    if constexpr (T < G::nw(TAP) || (T >= G::bstart(TAP) && T < G::bstart(TAP) + 8)) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
+    pin_items_win<MB, TAP, T + 1>();
   }
 }
 
-template <int MB, int EK>
+// one K step (compile-time tap) -- see the kernel
+template <int MB, int EK, bool XT>
 __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes, const int b_bytes) {
   using G = WGeo<MB>;
-  constexpr int NT = 2 * MB, D = LOOKAHEAD, NPW = G::NPW, SPT = G::SPT;
+  constexpr int NT = 2 * MB, D = LOOKAHEAD, NPW = G::NPW;
+  static_assert(NT - D >= G::bstart(0) + 8, "DMA slots of a step");
   static_assert(D <= 2, "the look-ahead items belong to row block 0");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
@@ -85,6 +92,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   // ---- DMA setup.  This lane's row within a 16-row piece and its (source-side swizzled) chunk:
   const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
   int w_vo[NPW], w_dst[NPW], w_isl[NPW], b_voff[4], b_dst[4];
+  // readable frames of the (at most) two utterances of this tile: two loads, issued together, before anything depends on them
+  const int nutt = p.M / p.T;
+  const bool masked = p.a_mask_mode && p.lens;
+  const int lim0 = masked ? p.lens[b0] : p.T;
+  const int lim1 = b0 + 1 < nutt ? (masked ? p.lens[b0 + 1] : p.T) : 0;
 #pragma unroll
   for (int k = 0; k < NPW; ++k) {
     const int c = 4 * k + wave;                                       // wave-uniform: piece c of 2 WP (hi plane, then cross plane)
@@ -95,14 +107,13 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     const bool s1 = wr >= seg1;
     const int b = b0 + (s1 ? 1 : 0);
     const int f = s1 ? wr - seg1 - 2 * dil : t0 - 2 * dil + wr;
-    const bool used = c < 2 * G::WP && (s1 ? (nb < G::BMR && wr < G::BMR + 8 * dil) : true) && (long long)b * p.T < p.M;
-    int lim = 0;
-    if (used) lim = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
+    const bool used = c < 2 * G::WP && (s1 ? (nb < G::BMR && wr < G::BMR + 8 * dil) : true);
+    const int lim = used ? (s1 ? lim1 : lim0) : 0;
     w_vo[k] = (f >= 0 && f < lim) ? ((b * p.T + f) * q.lda_h + d_chunk * 8) * 2 : OOB;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int j = 4 * k + wave;
+    const int j = 4 * wave + k;                                       // THIS wave's 64 B rows: nobody else reads them
     const int lr = 16 * j + d_row;                                    // LDS row 0 .. 255, interleaved as in rowgemm_h3d
     const int n = n0 + (lr & ~63) + 2 * (lr & 31) + ((lr >> 5) & 1);
     b_voff[k] = n < p.N ? (n * q.ldb_h + d_chunk * 8) * 2 : OOB;
@@ -183,11 +194,19 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     else if (i > 0) cross(i - 1, 1);
   };
 
-  // ---- prologue: window of k slice 0, B tile of step 0
+  // ---- K loop.  Who waits for what:
+  //   B tile: wave-private rows.  B(s) sits in REGISTERS during step s (read at the tail of step s - 1), so its LDS stage
+  //     (s & 1) is free from item 3 of step s on and receives B(s + 2): two K steps of flight time for every piece, and
+  //     the only synchronisation is this wave's own vmcnt -- at the end of step s everything but the step's own DMA
+  //     instructions must have landed (in-order counter: that is B(s + 1) and all older pieces).
+  //   A window of slice kb + 1: all of it is issued in taps 0..2 of slice kb (two to four K steps of flight time); the ONE
+  //     barrier per k slice, after tap 4, publishes it to the other waves and frees window kb - 1 for slice kb + 2's DMA.
 #pragma unroll
   for (int k = 0; k < NPW; ++k) dma_win(k, 0, 0);
 #pragma unroll
   for (int w = 0; w < 8; ++w) dma_b(w, 0, 0, 0);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) dma_b(w, 1, 1, 0);
   __syncthreads();
   read_b(0, 0);
   read_b(0, 1);
@@ -196,45 +215,97 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
 #pragma unroll
     for (int t = 0; t < D; ++t) read_a(t, sh);
   }
+  auto kstep = [&](auto tapc, int kb, int bsel) __attribute__((always_inline)) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int NW = G::nw(tap), BS = G::bstart(tap);
+    const int sh = shift_of(tap, kb);
+    const int ntap = tap == WTAPS - 1 ? 0 : tap + 1, nkb = tap == WTAPS - 1 ? kb + 1 : kb;      // tile of step + 1
+    constexpr int tap2 = (tap + 2) % WTAPS;                                                       // tile of step + 2
+    const int kb2 = kb + (tap + 2) / WTAPS;
+    // items 0 .. NT-D-1: fragments of item t + D | MFMAs of item t | one DMA piece
+#pragma unroll
+    for (int t = 0; t < NT - D; ++t) {
+      read_a(t + D, sh);
+      mfma_item(t);
+      if (t < NW) dma_win(G::WPT * tap + t, (kb + 1) & 1, kb + 1);
+      else if (t >= BS && t < BS + 8) dma_b(t - BS, bsel, tap2, kb2);
+    }
+    pin_items_win<MB, tap, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 8) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = NT - D; t < NT; ++t) mfma_item(t);
+    cross(MB - 1, 1);
+    read_b(bsel ^ 1, 0);
+    read_b(bsel ^ 1, 1);
+    {
+      const int shn = shift_of(ntap, nkb);
+#pragma unroll
+      for (int t = 0; t < D; ++t) read_a(t, shn);
+    }
+  };
   int bsel = 0;                                                       // B stage of the current step
   for (int kb = 0; kb < kpt; ++kb) {
+    kstep(std::integral_constant<int, 0>{}, kb, bsel); bsel ^= 1;
+    kstep(std::integral_constant<int, 1>{}, kb, bsel); bsel ^= 1;
+    kstep(std::integral_constant<int, 2>{}, kb, bsel); bsel ^= 1;
+    kstep(std::integral_constant<int, 3>{}, kb, bsel); bsel ^= 1;
+    kstep(std::integral_constant<int, 4>{}, kb, bsel); bsel ^= 1;
+  }
+  __syncthreads();                                                    // stray fragment reads / DMA past the last tile
+
+  // ---- optional EXTRA K segment (include/radmmm_hip.h: extra_tap): acc += A2 . B[taps], A2 = the rows extra_a_rows below,
+  // no shift, no mask.  It runs AFTER all tap slices (rowgemm_h3d interleaves it per k slice: same products, another fp32
+  // summation order), as a plain double-buffered loop -- one A tile and one B tile per K step, one barrier per step -- in
+  // the LDS the windows no longer need.
+  if constexpr (XT) {
+    int x_vo[MB], x_dst[MB], x_isl[MB];
 #pragma unroll
-    for (int tap = 0; tap < WTAPS; ++tap) {
-      const int sh = shift_of(tap, kb);
-      const int ntap = tap == WTAPS - 1 ? 0 : tap + 1, nkb = tap == WTAPS - 1 ? kb + 1 : kb;      // tile of step + 1
-      // items 0 .. NT-D-1: fragments of item t + D | MFMAs of item t | one DMA piece: the B tile of step + 1, then this
-      // step's share of the window of k slice kb + 1
+    for (int k = 0; k < MB; ++k) {
+      const int c = 4 * k + wave;                                     // piece c of 4 MB: 16-row groups of the hi plane, then of the cross plane
+      x_isl[k] = c >= 2 * MB ? 1 : 0;
+      const int j = x_isl[k] ? c - 2 * MB : c;
+      const int r = m0 + 16 * j + d_row;
+      x_vo[k] = r < p.M ? ((q.extra_a_rows + r) * q.lda_h + d_chunk * 8) * 2 : OOB;
+      x_dst[k] = x_isl[k] * G::W_PLANE + j * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) wrow[i] = G::W_BASE / ROWB + 32 * i + (lane & 31);
+    auto dma_x = [&](int w, int par, int kb) __attribute__((always_inline)) {      // piece w of 0 .. MB + 7 of tile kb
+      if (w < MB) dma16(x_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + G::W_BASE + par * G::W_BYTES + x_dst[w]), x_vo[w] + kb * (BK * 2));
+      else dma_b(w - MB, par, WTAPS, kb);
+    };
+#pragma unroll
+    for (int w = 0; w < MB + 8; ++w) dma_x(w, 0, 0);
+    __syncthreads();
+    read_b(0, 0);
+    read_b(0, 1);
+#pragma unroll
+    for (int t = 0; t < D; ++t) read_a(t, 0);
+    for (int kb = 0; kb < kpt; ++kb) {
+      const int par = kb & 1, sh = par * (G::W_BYTES / ROWB);
 #pragma unroll
       for (int t = 0; t < NT - D; ++t) {
         read_a(t + D, sh);
         mfma_item(t);
-        if (t < 8) dma_b(t, bsel ^ 1, ntap, nkb);
-        else if (t < 8 + SPT) {
-          const int k = SPT * tap + (t - 8);                          // (compile-time)
-          if (k < NPW) dma_win(k, (kb + 1) & 1, kb + 1);
-          else dma16(rAh, (lds_u32_ptr)(sm + G::DUMP + wave * 1024), OOB);   // keep the instruction count of a step fixed
-        }
+        if (2 * t < MB + 8) dma_x(2 * t, par ^ 1, kb + 1);
+        if (2 * t + 1 < MB + 8) dma_x(2 * t + 1, par ^ 1, kb + 1);
       }
-      pin_items_win<MB, 0>();
-      // every read of this step's stage / window rows has been issued: retire them and this wave's DMA, meet the other
-      // waves, then the last D items' MFMAs and the first fragments of the next step
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = NT - D; t < NT; ++t) mfma_item(t);
       cross(MB - 1, 1);
-      bsel ^= 1;
-      read_b(bsel, 0);
-      read_b(bsel, 1);
-      {
-        const int shn = shift_of(ntap, nkb);
+      read_b(par ^ 1, 0);
+      read_b(par ^ 1, 1);
 #pragma unroll
-        for (int t = 0; t < D; ++t) read_a(t, shn);
-      }
+      for (int t = 0; t < D; ++t) read_a(t, sh ^ (G::W_BYTES / ROWB));
     }
+    __syncthreads();
   }
-  __syncthreads();                                                    // stray fragment reads / DMA past the last tile
 
   const radmmm::EpilogueCtx ec(p);
   float sat = 0.f;
@@ -252,11 +323,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   radmmm::raise_sat_flag(p.sat_flag, sat, (p.Ch && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, p.ch_x8_exp) : 0.f);
 }
 
-template <int MB, int EK>
+template <int MB, int EK, bool XT>
 int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = WGeo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_win_kernel<MB, EK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_win_kernel<MB, EK, XT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_win<%d,%d>): %s", MB, EK, hipGetErrorString(e));
@@ -267,16 +338,17 @@ int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK, XT>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_win");
 }
 
 template <int MB>
 int launch_win_ek(int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  if (d.extra_tap) return launch_win<MB, EK_DGRAD, true>(d, stream, a_bytes, b_bytes);      // (rowgemm_win_ok: this kind only)
   switch (ek) {
-    case EK_SPLIT: return launch_win<MB, EK_SPLIT>(d, stream, a_bytes, b_bytes);
-    case EK_DGRAD: return launch_win<MB, EK_DGRAD>(d, stream, a_bytes, b_bytes);
-    default: return launch_win<MB, EK_PLAIN>(d, stream, a_bytes, b_bytes);
+    case EK_SPLIT: return launch_win<MB, EK_SPLIT, false>(d, stream, a_bytes, b_bytes);
+    case EK_DGRAD: return launch_win<MB, EK_DGRAD, false>(d, stream, a_bytes, b_bytes);
+    default: return launch_win<MB, EK_PLAIN, false>(d, stream, a_bytes, b_bytes);
   }
 }
 
@@ -290,7 +362,7 @@ bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d) {
   if (mb != 7) return false;
 #endif
   return d.nprod == 2 && (mb == 7 || mb == 8) && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_DGRAD) && p.taps == WTAPS &&
-         !d.extra_tap && p.dil >= 1 && p.dil <= WDMAX && p.T >= 32 * mb && p.M % p.T == 0 && (p.sign == 1 || p.sign == -1);
+         (!d.extra_tap || (ek == EK_DGRAD && !p.a_mask_mode)) && p.dil >= 1 && p.dil <= WDMAX && p.T >= 32 * mb && p.M % p.T == 0 && (p.sign == 1 || p.sign == -1);
 }
 int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
 #ifndef RADMMM_QUICK

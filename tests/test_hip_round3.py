@@ -288,3 +288,53 @@ def test_shared_window_gemm_is_bit_identical_to_per_tap_tiles(B, T, lens, mb, di
         assert torch.equal(a.view(torch.int16 if a.dtype == torch.float16 else torch.int32),
                            b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)), name
     assert bool(torch.isfinite(outs["1"][0]).all()) and float(outs["1"][0].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,lens,mb", [(3, 300, [300, 251, 170], 7), (4, 256, [256, 256, 100, 31], 8)])
+@pytest.mark.parametrize("dil", [1, 4, 8])
+def test_shared_window_fused_data_gradient_matches_per_tap_tiles(B, T, lens, mb, dil, monkeypatch):
+    """The fused data gradient of ops.AffineFlowStepH3Fn.backward (5-tap in_layer part + 1x1 res_skip part as the extra K
+    segment, softplus' of the hidden state and the partial-conv row scale in the epilogue, split copy out) on the
+    shared-window kernel: the extra segment runs after the tap slices there, so the fp32 sums differ in their order --
+    equal to a few 1e-7 of the largest element, and the 8-bit / fp16 copies equal up to that rounding."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    dev = torch.device("cuda:0")
+    Wc, taps = 512, 5
+    N = B * T
+    gen = torch.Generator().manual_seed(B * 77 + T + dil)
+    a1 = (torch.randn(N, Wc, generator=gen) * 3e-3).to(dev)
+    a2 = (torch.randn(N, Wc, generator=gen) * 3e-3).to(dev)
+    Hs = (torch.randn(N, Wc, generator=gen) * 2).to(dev)               # pre-activation hidden state (dact_src)
+    w1 = (torch.randn(Wc, Wc, taps, generator=gen) * 0.03).to(dev)
+    w2 = (torch.randn(Wc, Wc, 1, generator=gen) * 0.03).to(dev)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=dev)
+    S = 2048.0
+    pair_h, pair_l = ops._halves(2 * N, Wc, like=a1)
+    for src, lo in ((a1, 0), (a2, N)):
+        h, l = ops.split_f16(src, Wc, S, Wc, 2, ops.X8_GRAD_EXP)
+        pair_h[lo: lo + N], pair_l[lo: lo + N] = h, l
+    W1h, W1l, _ = ops.split_weight(w1, None, Wc, nprod=2)
+    W2h, W2l, _ = ops.split_weight(w2, None, Wc, nprod=2)
+    stack_h, stack_l = ops._halves(taps + 1, Wc, Wc, like=a1)
+    stack_h[:taps], stack_l[:taps], stack_h[taps:], stack_l[taps:] = W1h, W1l, W2h, W2l
+    monkeypatch.setenv("RADMMM_H3W_MB", str(mb))
+    outs = {}
+    for win in ("0", "1"):
+        monkeypatch.setenv("RADMMM_WIN", win)
+        Cf = torch.full((N, Wc), float("nan"), device=dev)
+        Ch, Cl = ops._halves(N, Wc, like=a1)
+        Ch.fill_(float("nan")), Cl.zero_()
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        rowgemm_h3(nprod=2, a8_exp=ops.X8_GRAD_EXP, b8_exp=ops.X8_W_EXP, acc_scale=1.0 / (S * ops.W_SCALE), T=T, sat_flag=flag,
+                   Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=stack_h, Bl=stack_l, ldb_h=Wc, b_tap_stride_h=stack_h.stride(0),
+                   taps=taps, dil=dil, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N,
+                   C=Cf, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens_d, dact_src=Hs, lddact=Wc, dact=1, rowscale=2, ratio_taps=taps,
+                   ratio_dil=dil, Ch=Ch, Cl=Cl, ldch=Wc, ch_scale=S, split_fmt=ops.SPLIT_X8A, ch_x8_exp=ops.X8_GRAD_EXP)
+        torch.cuda.synchronize()
+        outs[win] = (Cf.cpu(), Ch.float().cpu())
+    ref, got = outs["0"], outs["1"]
+    assert bool(torch.isfinite(got[0]).all()) and float(got[0].abs().max()) > 0
+    assert float((got[0] - ref[0]).abs().max()) <= 1e-6 * float(ref[0].abs().max())
+    assert float((got[1] - ref[1]).abs().max()) <= 2e-3 * float(ref[1].abs().max())      # (fp16 hi parts: one ulp at most)
