@@ -493,9 +493,11 @@ def main():
             kdur, kflop = time_dominant_kernel_h3(N, T // cfg.n_group_size, nprod=2 if f8x else 3)
             # executed MFMA work in f16-equivalent products: 3 f16 products, or 1 f16 + 2 FP8 products at twice the rate
             nprod, peak = (2.0 if f8x else 3.0), PEAK_F16_MFMA_TFLOPS
-            kname = ("rowgemm_h3d_kernel<MB,%d> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, %s)"
-                     % (2 if f8x else 3, N, "hi.hi f16 MFMA + both cross terms in one block-scaled FP8 MFMA per 32-deep k step"
-                        if f8x else "3 f16 MFMA products per fp32 product"))
+            kname = (("rowgemm_win_kernel<7,SPLIT> (rowgemm_win.hip: shared A window over the 5 taps; WN in_layer conv fwd, M=%d "
+                      "N=1024 K=5x1024, hi.hi f16 MFMA + both cross terms in one block-scaled FP8 MFMA per 32-deep k step)" % N)
+                     if f8x else
+                     ("rowgemm_h3d_kernel<MB,3> (rowgemm_h3w.hip; WN in_layer conv fwd, M=%d N=1024 K=5x1024, 3 f16 MFMA "
+                      "products per fp32 product)" % N))
             prec = ("f16 hi.hi product + FP8 (e4m3) cross terms, fp32 accumulate (z max rel err 4e-5, NLL < 4e-6 vs the CPU reference)"
                     if f8x else "split-f16 x3 MFMA products, fp32 accumulate (max rel err 2e-6, below native fp32 MFMA's 4e-6)")
         else:

@@ -21,7 +21,7 @@ def mean(counter, sub):
     vals = []
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "rowgemm_h3d_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if ("rowgemm_win_kernel" in r["Kernel_Name"] or "rowgemm_h3d_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 fetch, nf = mean("FETCH_SIZE", "FETCH_SIZE")
@@ -30,7 +30,7 @@ busy, _ = mean("SQ_VALU_MFMA_BUSY_CYCLES", "mfma")
 sqb, _ = mean("SQ_BUSY_CYCLES", "mfma")
 insts, _ = mean("SQ_INSTS_MFMA", "mfma")
 gui, _ = mean("GRBM_GUI_ACTIVE", "mfma")
-res = {"M": 12800, "kernel": "rowgemm_h3d_kernel (WN in_layer conv fwd, M=12800 N=1024 K=5x1024)",
+res = {"M": 12800, "kernel": "rowgemm_win_kernel / rowgemm_h3d_kernel: whichever `bench.py --dominant-only` launches (WN in_layer conv fwd, M=12800 N=1024 K=5x1024)",
        "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "launches_averaged": [nf, nw],
        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024 if fetch and write else None,
        "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sqb, "SQ_INSTS_MFMA": insts, "GRBM_GUI_ACTIVE": gui,
