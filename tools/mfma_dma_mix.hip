@@ -20,6 +20,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 }
 
 // NW waves per workgroup; per wave and step: NM MFMAs, NP DMA pieces (one after every NM / NP MFMAs); MODE 0 both, 1 MFMA only,
+// 5 both, the DMA pieces addressed WITHOUT a VGPR (buffer resource with ADD_TID_ENABLE, stride 16: lane l reads base + soffset
+// + 16 l -- a contiguous 1 KiB piece; does the per-instruction issue cost come from the 64-lane address operand?),
 // 2 DMA only, 3 both with the pieces staged through VGPRs (buffer_load_dwordx4 of step s + 1 between the MFMAs of the first
 // half of step s, ds_write_b128 between those of the second half), 4 role split: the first NW / 2 waves issue 2 NM MFMAs
 // and no DMA, the others 2 NP pieces and no MFMA
@@ -32,6 +34,8 @@ __global__ __launch_bounds__(NW * 64, 1) void mix(const unsigned char* src, long
   const unsigned char* base = src + (long long)blockIdx.x * window;
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)window, 0x00020000);
   const int lane_off = (lane >> 2) * 2048 + (lane & 3) * 16;           // 16 rows x 64 B (the GEMM's piece)
+  // word1: stride 16 in bits 16..29; word3: ADD_TID_ENABLE (bit 23) on top of the raw-buffer flags
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 16, (int)(window / 16), 1 << 23);   // (with ADD_TID_ENABLE the DATA_FORMAT bits are stride[17:14]: keep them 0)
   constexpr int NACC = NM >= 8 ? 8 : NM;
   f32x16 acc[NACC];
 #pragma unroll
@@ -65,6 +69,20 @@ __global__ __launch_bounds__(NW * 64, 1) void mix(const unsigned char* src, long
         }
       }
       off += NW * NP * 16 * 2048;
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == 5) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m % NACC], 0, 0, 0);
+        if (NP > 0 && (m % (NM / (NP > 0 ? NP : 1))) == 0 && m / (NM / (NP > 0 ? NP : 1)) < NP) {
+          const int w = m / (NM / NP);
+          const int so = __builtin_amdgcn_readfirstlane((off + w * 1024) & (int)(window - 1));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_u32_ptr)(sm + ((it & 1) * NW * NP + wave * NP + w) * 1024), 16, 0, so, 0, 0);
+        }
+      }
+      off += NW * NP * 1024;
       __syncthreads();
       continue;
     }
@@ -117,7 +135,30 @@ void run(const char* name, const unsigned char* d, unsigned long long* dout, flo
   printf("%-44s grid %3d: %6.3f us per step  (%d waves x %d MFMA + %d DMA pieces)\n", name, grid, us / iters, NW, NM, NP);
 }
 
+// does the TID-addressed resource deliver lane l the 16 bytes at base + soffset + 16 l?
+__global__ void verify_tid(const unsigned* src, int bytes, int soff, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned buf[256];
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(src), 16, bytes / 16, 1 << 23);
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_u32_ptr)buf, 16, 0, soff, 0, 0);
+#endif
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += 64) out[i] = buf[i];
+}
+
 int main() {
+  {
+    unsigned *vs, *vo, h[1024], o[256];
+    for (int i = 0; i < 1024; ++i) h[i] = i;
+    hipMalloc(&vs, 4096);
+    hipMalloc(&vo, 1024);
+    hipMemcpy(vs, h, 4096, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(verify_tid, dim3(1), dim3(64), 0, 0, vs, 4096, 2048, vo);
+    hipMemcpy(o, vo, 1024, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 256; ++i) bad += o[i] != (unsigned)(512 + i);
+    printf("TID-addressed LDS-DMA (no VGPR operand): %s (word 0 = %u, word 255 = %u; expected 512 .. 767)\n", bad ? "WRONG DATA" : "data correct", o[0], o[255]);
+  }
   unsigned char* d;
   unsigned long long* dout;
   float* sink;
@@ -139,6 +180,7 @@ int main() {
     run<4, 56, 14, 3>("4 waves, MFMA + pieces staged through VGPRs", d, dout, sink, grid, iters);
     run<8, 28, 7, 3>("8 waves, MFMA + pieces staged through VGPRs", d, dout, sink, grid, iters);
     run<8, 28, 7, 4>("8 waves, role split (4 MFMA waves, 4 DMA waves)", d, dout, sink, grid, iters);
+    run<4, 56, 14, 5>("4 waves, MFMA + DMA addressed by TID (no VGPR)", d, dout, sink, grid, iters);
   }
   return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
