@@ -14,6 +14,8 @@ int launch_rowgemm_rs(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream
 // rowgemm_win.hip: 5-tap convs with the A rows of a k slice fetched once for all taps (shared window), FP8-cross scheme
 bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d);
 int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
+// rowgemm_win8.hip: the same with two waves per SIMD (the tile split by rows over 8 waves)
+int launch_rowgemm_win8(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 }  // namespace radmmm
 
 namespace {
@@ -111,7 +113,12 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
     const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT);   // (that instantiation spills)
     if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
     const char* we = debug_env("RADMMM_WIN");         // RADMMM_DEBUG: RADMMM_WIN=0 keeps the per-tap A tiles (A/B runs, tests)
-    if (!(we && atoi(we) == 0) && rowgemm_win_ok(mb, ek, d)) return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
+    if (!(we && atoi(we) == 0) && rowgemm_win_ok(mb, ek, d)) {
+      const char* w8 = debug_env("RADMMM_WIN8");      // RADMMM_DEBUG: 1 = the 8-wave variant for the kinds it is built for
+      if (w8 && atoi(w8) == 1 && (ek == EK_PLAIN || ek == EK_SPLIT) && !d.extra_tap)
+        return launch_rowgemm_win8(mb, ek, d, stream, a_bytes, b_bytes);
+      return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
+    }
     return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);
   }
   if (d.nprod == 1) return launch_h3d_pr1(mb, ek, d, stream, a_bytes, b_bytes);       // 16-bit throughput mode
