@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total/avg ms, share) from a rocprofv3 --kernel-trace results .db
 (rocpd sqlite schema), for when the --stats CSVs were not merged back.
-usage: kernel_stats.py results.db [steps] [--hist SUBSTR]
+usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps]
   -> prints a table; with `steps`, also ms per step; with --hist, the launch-duration clusters of the
      kernels whose name contains SUBSTR (one kernel serves several GEMM shapes: the per-shape average is
-     what bench.py's roofline leg times, the all-shapes average is what --stats prints)."""
+     what bench.py's roofline leg times, the all-shapes average is what --stats prints); with --gaps, how much of the
+     busiest window (the last `steps` steps: the 60 % of the dispatches at the end of the trace) the GPU spent between
+     kernels (end of one dispatch -> start of the next, same device), by gap size."""
 import sqlite3
 import sys
 
 
 def main():
     argv = list(sys.argv[1:])
+    gaps = "--gaps" in argv
+    if gaps:
+        argv.remove("--gaps")
     hist = None
     if "--hist" in argv:
         i = argv.index("--hist")
@@ -31,6 +36,21 @@ def main():
             line += f" {t / 1e6 / steps:8.2f}"
         print(line)
     print(f"{'TOTAL':70s} {sum(r[1] for r in rows):7d} {tot / 1e6:10.2f}")
+    if gaps:
+        ev = db.execute(f"select d.start, d.end from {kd} d order by d.start").fetchall()
+        ev = ev[int(len(ev) * 0.4):]                                  # the timed steps at the end of the run
+        span = ev[-1][1] - ev[0][0]
+        busy, idle, cur_end = 0, [], ev[0][0]
+        for s0, e0 in ev:
+            if s0 > cur_end:
+                idle.append(s0 - cur_end)
+            busy += max(0, e0 - max(s0, cur_end))
+            cur_end = max(cur_end, e0)
+        print(f"\nlast {len(ev)} dispatches: span {span / 1e6:.2f} ms, some kernel running {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %), "
+              f"idle {sum(idle) / 1e6:.2f} ms in {len(idle)} gaps")
+        for lo, hi in ((0, 2e3), (2e3, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e12)):
+            g = [x for x in idle if lo <= x < hi]
+            print(f"  gaps {lo / 1e3:6.0f} .. {hi / 1e3 if hi < 1e12 else float('inf'):6.0f} us: {len(g):6d}  total {sum(g) / 1e6:7.3f} ms")
     if hist:
         durs = [r[0] / 1e3 for r in db.execute(
             f"select d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id where s.kernel_name like ?",
