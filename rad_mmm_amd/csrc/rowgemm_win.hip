@@ -34,6 +34,10 @@
 namespace {
 
 constexpr int WTAPS = 5, WDMAX = 8;
+#ifndef RADMMM_WIN_LOOKAHEAD
+#define RADMMM_WIN_LOOKAHEAD 2
+#endif
+constexpr int WLOOK = RADMMM_WIN_LOOKAHEAD;          // fragment look-ahead in pipeline items (measured: 2 / 3 / 4)
 
 template <int MB>
 struct WGeo {
@@ -58,7 +62,7 @@ template <int MB, int TAP, int T>
 __device__ __forceinline__ void pin_items_win() {
   using G = WGeo<MB>;
   constexpr int NT = 2 * MB;
-  if constexpr (T < NT - LOOKAHEAD) {
+  if constexpr (T < NT - WLOOK) {
     __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2, 0);
     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, T == 0 ? 2 : 3, 0);
     if constexpr (T < G::nw(TAP) || (T >= G::bstart(TAP) && T < G::bstart(TAP) + 8)) __builtin_amdgcn_sched_group_barrier(SGB_VMEM, 1, 0);
@@ -70,9 +74,8 @@ __device__ __forceinline__ void pin_items_win() {
 template <int MB, int EK, bool XT>
 __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes, const int b_bytes) {
   using G = WGeo<MB>;
-  constexpr int NT = 2 * MB, D = LOOKAHEAD, NPW = G::NPW;
+  constexpr int NT = 2 * MB, D = WLOOK, NPW = G::NPW;
   static_assert(NT - D >= G::bstart(0) + 8, "DMA slots of a step");
-  static_assert(D <= 2, "the look-ahead items belong to row block 0");
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const radmmm_rowgemm_desc& p = q.base;
   const int tid = threadIdx.x, lane = tid & 63;
