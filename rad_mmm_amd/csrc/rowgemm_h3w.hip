@@ -113,7 +113,9 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
     const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT);   // (that instantiation spills)
     if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
     const char* we = debug_env("RADMMM_WIN");         // RADMMM_DEBUG: RADMMM_WIN=0 keeps the per-tap A tiles (A/B runs, tests)
-    if (!(we && atoi(we) == 0) && rowgemm_win_ok(mb, ek, d)) {
+    const char* wx = debug_env("RADMMM_WIN_XT");      // RADMMM_DEBUG: 0 = launches with the extra K segment keep rowgemm_h3d (A/B runs)
+    const bool xt_ok = !d.extra_tap || !(wx && atoi(wx) == 0);
+    if (!(we && atoi(we) == 0) && xt_ok && rowgemm_win_ok(mb, ek, d)) {
       const char* w8 = debug_env("RADMMM_WIN8");      // RADMMM_DEBUG: 1 = the 8-wave variant for the kinds it is built for
       if (w8 && atoi(w8) == 1 && (ek == EK_PLAIN || ek == EK_SPLIT) && !d.extra_tap)
         return launch_rowgemm_win8(mb, ek, d, stream, a_bytes, b_bytes);

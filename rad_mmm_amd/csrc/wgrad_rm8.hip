@@ -64,27 +64,30 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 }
 
 struct Frag { i32x2 lo, hi; };
-// fp16 hi planes: LDS address of this lane's 8 bytes of (32-channel unit u, k block kb) -- rows k and k + 4 of the lane's
-// half k block (wgrad_rm.hip)
-__device__ __forceinline__ unsigned frag_addr(const unsigned char* arr, int u, int kb, int lane) {
+// Fragment addressing.  All lane-dependent parts of a fragment's LDS address are computed ONCE (round 3, second pass: the K
+// step carried ~270 VALU instructions beside its 48 MFMAs -- more than the MFMA gaps hide -- of which 30 were these address
+// sums and ~110 the per-piece DMA masks); per step only the stage base is added, everything else is an immediate offset.
+//   fp16 hi planes (wgrad_rm.hip): this lane's 8 bytes of (32-channel unit u, k block kb) -- rows k and k + 4 of the lane's
+//   half k block: k = 16 kb + 8 (gq >> 1) + (p >> 2), byte k * 512 + ((u ^ (p >> 2)) << 6) + (gq & 1) * 32 + (p & 3) * 8.  The XOR
+//   touches the two low bits of u only: base[u & 3] + (u >> 2) * 256 (+ 8192 for k block 1, + 2048 for rows k + 4).
+__device__ __forceinline__ int hi_lane_base(int q, int lane) {
   const int p = lane & 15, gq = lane >> 4;
-  const int k = 16 * kb + 8 * (gq >> 1) + (p >> 2);
-  const int off = k * 512 + ((u ^ (p >> 2)) << 6) + (gq & 1) * 32 + (p & 3) * 8;
-  return (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(arr + off));
+  return (8 * (gq >> 1) + (p >> 2)) * 512 + ((q ^ (p >> 2)) << 6) + (gq & 1) * 32 + (p & 3) * 8;
 }
+template <int OFF>
 __device__ __forceinline__ void frag_issue(Frag& f, unsigned addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + 2048) : "memory");
 }
 __device__ __forceinline__ f16x8 frag_val(const Frag& f) {
   return __builtin_bit_cast(f16x8, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3));
 }
 // lo8 planes: this lane's (channel (gq & 1) * 16 + p of unit u, frames 8 h .. 8 h + 7 of k block 0) -- row r = 8 h + (p >> 1)
-// supplies the 8-byte segment (p & 1); k block 1 lies 16 rows = 4096 bytes further (same r & 7)
-__device__ __forceinline__ unsigned frag8_addr(const unsigned char* arr, int u, int lane) {
+// supplies the 8-byte segment (p & 1); k block 1 lies 16 rows = 4096 bytes further (same r & 7).  The XOR with r & 7 = p >> 1
+// touches all three bits of u: one lane base per unit.
+__device__ __forceinline__ int lo8_lane_base(int u, int lane) {
   const int p = lane & 15, gq = lane >> 4;
   const int r = 8 * (gq >> 1) + (p >> 1);
-  const int off = r * 256 + ((u ^ (r & 7)) << 5) + (gq & 1) * 16 + (p & 1) * 8;
-  return (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(arr + off));
+  return r * 256 + ((u ^ (r & 7)) << 5) + (gq & 1) * 16 + (p & 1) * 8;
 }
 __device__ __forceinline__ void frag8_issue(Frag& f, unsigned addr) {      // .lo: k block 0, .hi: k block 1
   asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:4096" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
@@ -96,21 +99,19 @@ __device__ __forceinline__ void frag_wait3(Frag& a, Frag& b, Frag& c) {
 }
 // e4m3(hi * 2^e) of the 16 fp16 values of a fragment pair (k block 0, k block 1) -> 16 bytes in fragment order.
 // inv = 2^-e: the instruction divides by its scale operand; saturating under MODE.FP16_OVFL.
+__device__ __forceinline__ int cvt4_fp8(int lo2, int hi2, float inv) {
+  // two packed conversions into the two halves of ONE register.  As inline asm with a write-only destination: the builtin's
+  // destination is read-modify-write, and the compiler materialises its (dead) initial value with a v_mov -- 40 per K step.
+  int o;
+  asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %3\n\tv_cvt_scalef32_pk_fp8_f16 %0, %2, %3 op_sel:[0,0,1]" : "=&v"(o) : "v"(lo2), "v"(hi2), "v"(inv));
+  return o;
+}
 __device__ __forceinline__ i32x4 hi8_of(const Frag& f0, const Frag& f1, float inv) {
   i32x4 r;
-  const int src[4] = {f0.lo[0], f0.lo[1], f0.hi[0], f0.hi[1]};
-  const int src1[4] = {f1.lo[0], f1.lo[1], f1.hi[0], f1.hi[1]};
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    i16x2 o = {0, 0};
-    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_bit_cast(f16x2, src[2 * d]), inv, false);
-    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_bit_cast(f16x2, src[2 * d + 1]), inv, true);
-    r[d] = __builtin_bit_cast(int, o);
-    i16x2 q = {0, 0};
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(f16x2, src1[2 * d]), inv, false);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(f16x2, src1[2 * d + 1]), inv, true);
-    r[2 + d] = __builtin_bit_cast(int, q);
-  }
+  r[0] = cvt4_fp8(f0.lo[0], f0.lo[1], inv);
+  r[1] = cvt4_fp8(f0.hi[0], f0.hi[1], inv);
+  r[2] = cvt4_fp8(f1.lo[0], f1.lo[1], inv);
+  r[3] = cvt4_fp8(f1.hi[0], f1.hi[1], inv);
   return r;
 }
 
@@ -180,23 +181,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
   const __amdgpu_buffer_rsrc_t rXh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.Xh), 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rGl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.GYl), 0, a.gl_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rXl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.Xl), 0, a.xl_bytes, 0x00020000);
-  int p_k[12], p_off[12];
-  int p_t[6], p_b[6], p_lim[6];                                  // X pieces: 4 hi row pairs, 2 lo8 row quads
-  int* lim_tab = reinterpret_cast<int*>(sm + SMEM);              // readable frames per utterance: min(len, T) or T
+  // Masks.  Array ends need none: a frame beyond R (or, with a tap shift, before 0) is an offset outside the buffer and the
+  // DMA writes zeros.  What needs one is the X frame of a row leaving its utterance's readable range [0, lim): per piece
+  // this lane's row k of the 32-frame window and c = k + shift are constants, the window's position is UNIFORM --
+  // (w_b, w_t) = utterance and frame-in-utterance of its first frame, lim0 / lim1 the readable frames of utterances w_b and
+  // w_b + 1 (T >= 32: a window meets at most one boundary) -- and lives in scalar registers: a row is readable iff
+  //   k + w_t < T ?  0 <= c + w_t < lim0  :  0 <= c + w_t - T < lim1
+  // (5 vector compares / adds per X piece and step; the mask logic is scalar).  Pieces of steps beyond the split's end go to
+  // stages nobody reads, whatever they fetch.
+  int p_k[12], p_off[12], p_c[12];
   const int nb = a.R / a.T;
-  for (int i = tid; i < nb; i += 256) {
-    const int l = (a.x_mask && a.lens) ? a.lens[i] : a.T;
-    lim_tab[i] = l < a.T ? l : a.T;
-  }
-  __syncthreads();                                               // (advance_t reads the table before the first K-step barrier)
-  auto init_x = [&](int slot, int f0) __attribute__((always_inline)) {
-    const int b = f0 / a.T;
-    const int bc = b < nb ? b : nb - 1;
-    const int l = (a.x_mask && a.lens) ? a.lens[bc] : a.T;
-    p_b[slot] = b;
-    p_t[slot] = f0 - b * a.T;                                    // frame within its utterance
-    p_lim[slot] = l < a.T ? l : a.T;
+  auto lim_of = [&](int b) __attribute__((always_inline)) {
+    if (b >= nb) return 0;
+    if (!(a.x_mask && a.lens)) return a.T;
+    const int l = a.lens[b];
+    return l < a.T ? l : a.T;
   };
+  int w_b = (step_lo * BK) / a.T, w_t = step_lo * BK - w_b * a.T;
+  int lim0 = lim_of(w_b), lim1 = lim_of(w_b + 1);
 #pragma unroll
   for (int w = 0; w < 8; ++w) {
     const int isx = w >> 2, pr = 4 * (w & 3) + wave;
@@ -205,9 +207,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
     const int ch = c0 + u * 32 + (lane & 3) * 8;
     p_k[w] = k;
+    p_c[w] = k + shift;
     const int f0 = step_lo * BK + k;                             // GY frame of this row at the split's first step
     p_off[w] = ch < ld ? ((f0 + (isx ? shift : 0)) * ld + ch) * 2 : OOB;
-    if (isx) init_x(w & 3, f0);
   }
 #pragma unroll
   for (int w = 8; w < 12; ++w) {
@@ -217,47 +219,34 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
     const int ch = c0 + u * 32 + (lane & 1) * 16;
     p_k[w] = k;
+    p_c[w] = k + shift;
     const int f0 = step_lo * BK + k;
     const int pitch = isx ? a.xl_pitch : a.gl_pitch, bs = isx ? a.xl_bstride : a.gl_bstride, bo = isx ? a.xl_boff : a.gl_boff;
     p_off[w] = ch < ld ? (f0 + (isx ? shift : 0)) * pitch + (ch >> 5) * bs + bo + (ch & 31) : OOB;
-    if (isx) init_x(4 + ((w - 8) & 1), f0);
   }
   const int g_step = BK * a.ldg * 2, x_step = BK * a.ldx * 2, gl_step = BK * a.gl_pitch, xl_step = BK * a.xl_pitch;
-  // piece w of relative step `rel` into stage `buf`; call with consecutive rel (the counters advance)
+  // piece w of relative step `rel` into stage `buf`; the window state must be that of step `rel` (advance_window)
   auto dma_piece = [&](int buf, int w, int rel) __attribute__((always_inline)) {
     const bool lo8 = w >= 8;
     const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
-    const int f = (step_lo + rel) * BK + p_k[w];
-    int ok = -(int)((f < a.R) & (rel < nsteps));                  // the GY frame exists and belongs to this split
-    if (isx) {
-      const int slot = lo8 ? 4 + ((w - 8) & 1) : (w & 3);
-      const int ts = p_t[slot] + shift;                           // partner frame, counted within the utterance
-      ok &= -(int)((unsigned)ts < (unsigned)p_lim[slot]);
-    }
     const int stepb = lo8 ? (isx ? xl_step : gl_step) : (isx ? x_step : g_step);
-    const int vo = ((p_off[w] + rel * stepb) & ok) | (OOB & ~ok);
+    int vo = p_off[w] + rel * stepb;                             // (OOB + anything stays beyond 2^31 = out of range)
+    if (isx) {
+      const int x = p_c[w] + w_t;
+      const bool ok = (p_k[w] + w_t < a.T) ? ((unsigned)x < (unsigned)lim0) : ((unsigned)(x - a.T) < (unsigned)lim1);
+      vo = ok ? vo : OOB;
+    }
     const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
     dma16(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo);
   };
-  auto advance_t = [&]() __attribute__((always_inline)) {        // the X pieces' rows move on by one K step
-    unsigned p_lim_new[6];
-#pragma unroll
-    for (int w = 0; w < 6; ++w) {
-      int t = p_t[w] + BK;
-      const int wrap = t >= a.T ? 1 : 0;                         // T >= 32: at most one utterance boundary per step
-      t -= wrap ? a.T : 0;
-      const int b = p_b[w] + wrap;
-      p_t[w] = t;
-      p_b[w] = b;
-      unsigned lv;                                               // (asm: a compiler-visible LDS read would wait for the DMA in flight)
-      const unsigned la = (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)(lim_tab + (b < nb ? b : nb - 1)));
-      asm volatile("ds_read_b32 %0, %1" : "=v"(lv) : "v"(la) : "memory");
-      p_lim_new[w] = lv;
+  auto advance_window = [&]() __attribute__((always_inline)) {   // the window moves on by one K step (scalar work)
+    w_t += BK;
+    if (w_t >= a.T) {
+      w_t -= a.T;
+      ++w_b;
+      lim0 = lim1;
+      lim1 = lim_of(w_b + 1);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p_lim_new[0]), "+v"(p_lim_new[1]), "+v"(p_lim_new[2]), "+v"(p_lim_new[3]), "+v"(p_lim_new[4]),
-                 "+v"(p_lim_new[5]) : : "memory");
-#pragma unroll
-    for (int w = 0; w < 6; ++w) p_lim[w] = (int)p_lim_new[w];
   };
 
   f32x16 acc[8][2];
@@ -279,28 +268,46 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     // offsets -- zeros into a stage nobody reads -- so that every step issues exactly 12 pieces per wave)
 #pragma unroll
     for (int w = 0; w < 12; ++w) dma_piece(0, w, 0);
-    advance_t();
+    advance_window();
 #pragma unroll
     for (int w = 0; w < 12; ++w) dma_piece(1, w, 1);
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     int buf = 0;
+    // lane parts of the fragment addresses (stage-relative; arrays: GYh at 0, Xh at HARR, GYl8 at 2 HARR, Xl8 behind it)
+    const unsigned sm_base = (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)sm);
+    unsigned ah_base[4], a8_base[8], bh_base[2], b8_base[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ah_base[q] = sm_base + hi_lane_base(q, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a8_base[i] = sm_base + 2 * HARR + lo8_lane_base(i, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = 2 * wave + j;
+      bh_base[j] = sm_base + HARR + hi_lane_base(u & 3, lane) + (u >> 2) * 256;
+      b8_base[j] = sm_base + 2 * HARR + LARR + lo8_lane_base(u, lane);
+    }
     for (int s = 0; s < nsteps; ++s) {
-      advance_t();                                                 // the counters follow the tile being fetched: s + 2
+      advance_window();                                            // the window follows the tile being fetched: s + 2
       const int l_rel = s + 2;
       const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
-      const unsigned char* st = sm + buf * STAGE;
+      const unsigned sb = (unsigned)(buf * STAGE);
+      unsigned ah[4], a8a[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ah[q] = ah_base[q] + sb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a8a[i] = a8_base[i] + sb;
       // B side (X, this wave's two 32-channel units): fp16 hi fragments of both k blocks + the FP8 operand [lo8 | hi8]
       Frag xb0[2], xb1[2], xb8[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        frag_issue(xb0[j], frag_addr(st + HARR, 2 * wave + j, 0, lane));
-        frag_issue(xb1[j], frag_addr(st + HARR, 2 * wave + j, 1, lane));
-        frag8_issue(xb8[j], frag8_addr(st + 2 * HARR + LARR, 2 * wave + j, lane));
+        frag_issue<0>(xb0[j], bh_base[j] + sb);
+        frag_issue<8192>(xb1[j], bh_base[j] + sb);
+        frag8_issue(xb8[j], b8_base[j] + sb);
       }
       Frag ga0[2], ga1[2], ga8[2];                                  // A side (GY), two slots
-      frag_issue(ga0[0], frag_addr(st, 0, 0, lane));
-      frag_issue(ga1[0], frag_addr(st, 0, 1, lane));
-      frag8_issue(ga8[0], frag8_addr(st + 2 * HARR, 0, lane));
+      frag_issue<0>(ga0[0], ah[0]);
+      frag_issue<8192>(ga1[0], ah[0]);
+      frag8_issue(ga8[0], a8a[0]);
       frag_wait3<12>(xb0[0], xb1[0], xb8[0]);                       // (6 B + 6 A read instructions are younger than B's first unit)
       frag_wait3<6>(xb0[1], xb1[1], xb8[1]);
       f16x8 bh0[2], bh1[2];
@@ -317,9 +324,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
       for (int i = 0; i < 8; ++i) {
         const int sl = i & 1;
         if (i + 1 < 8) {                                            // next row block's fragments ahead of this one's MFMAs
-          frag_issue(ga0[sl ^ 1], frag_addr(st, i + 1, 0, lane));
-          frag_issue(ga1[sl ^ 1], frag_addr(st, i + 1, 1, lane));
-          frag8_issue(ga8[sl ^ 1], frag8_addr(st + 2 * HARR, i + 1, lane));
+          if (i + 1 < 4) {
+            frag_issue<0>(ga0[sl ^ 1], ah[(i + 1) & 3]);
+            frag_issue<8192>(ga1[sl ^ 1], ah[(i + 1) & 3]);
+          } else {
+            frag_issue<256>(ga0[sl ^ 1], ah[(i + 1) & 3]);
+            frag_issue<8192 + 256>(ga1[sl ^ 1], ah[(i + 1) & 3]);
+          }
+          frag8_issue(ga8[sl ^ 1], a8a[i + 1]);
           frag_wait3<6>(ga0[sl], ga1[sl], ga8[sl]);
         } else {
           frag_wait3<0>(ga0[sl], ga1[sl], ga8[sl]);
