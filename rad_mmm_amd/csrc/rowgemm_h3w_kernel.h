@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
       const int b = r / p.T;
       a_t[k] = r - b * p.T;
       a_lim[k] = (p.a_mask_mode && p.lens) ? p.lens[b] : p.T;
-      a_base[k] = (b * p.T * q.lda_h + d_chunk * 8) * 2;
+      a_base[k] = ((b * p.T + a_t[k]) * q.lda_h + d_chunk * 8) * 2;      // this lane's row at shift 0
     }
     a_dst[k] = real ? a_isl[k] * G::A_BYTES + j * 1024 : -1;
     a_vo[k] = OOB;
@@ -427,12 +427,12 @@ __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgem
   auto set_tap = [&](int tap) __attribute__((always_inline)) {
     const bool ex = tap >= p.taps;                                 // the extra segment: no shift, rows of the second matrix
     const int s = ex ? 0 : p.sign * (tap - p.taps / 2) * p.dil;
-    const int xb = ex ? extra_bytes : 0;
+    const int sb = s * q.lda_h * 2 + (ex ? extra_bytes : 0);      // uniform byte offset of the tap (no per-lane multiply)
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
       const int ts = a_t[k] + s;
       const int ok = -(int)((ts >= 0) & (ts < a_lim[k]));        // all ones when the frame is readable
-      a_vo[k] = ((a_base[k] + ts * q.lda_h * 2 + xb) & ok) | (OOB & ~ok);
+      a_vo[k] = ((a_base[k] + sb) & ok) | (OOB & ~ok);
     }
   };
   // piece w of 0 .. NP-1 of tile (tap, kb) into stage `buf`
