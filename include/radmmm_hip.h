@@ -119,6 +119,14 @@ typedef struct {
   int32_t* sat_flag;     /* optional device int: OR-ed with 1 when a split output exceeded the fp16 range (was clamped) */
   void* Clo;             /* optional, with Ch and an 8-bit split_fmt: [M][ldch] halves, the fp16 lo part fp16(ch_scale*v - Ch)
                             as well (the row-major pair Ch / Clo is what radmmm_wgrad_rm contracts) */
+  /* optional (radmmm_rowgemm_h3 only): colsum_out[n] = sum over the rows r inside their utterance's length (all rows when
+   * the launch has no row scale) of the epilogue's value BEFORE its row scale -- x_r[n] of step (6) below, after the
+   * act' factor.  With rowscale = 2 this is the bias gradient of the partial conv whose data gradient the launch computes
+   * (common.py:179-191 backward), i.e. radmmm_colsum(C, row_weight 2) without the pass over C: the kernels with the direct
+   * epilogue sum it from the accumulators (one partial row per row tile in colsum_scratch, added up in a fixed order:
+   * deterministic), every other path runs radmmm_colsum on C afterwards.  colsum_scratch: device scratch of
+   * radmmm_rowgemm_h3_colsum_scratch_floats(M, N) floats. */
+  float* colsum_out; float* colsum_scratch;
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
@@ -150,6 +158,7 @@ typedef struct {
 } radmmm_rowgemm_h3_desc;
 
 int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);
+int64_t radmmm_rowgemm_h3_colsum_scratch_floats(int M, int N);
 
 /* ------------------------------------------------------------------------------------
  * Weight-gradient GEMM (contraction over frames), fp32 MFMA:

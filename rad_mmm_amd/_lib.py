@@ -60,6 +60,7 @@ class RowGemmDesc(C.Structure):
         ("split_fmt", C.c_int), ("ch_x8_exp", C.c_int), ("c2h_x8_exp", C.c_int),
         ("sat_flag", C.c_void_p),
         ("Clo", C.c_void_p),
+        ("colsum_out", C.c_void_p), ("colsum_scratch", C.c_void_p),
     ]
 
 
@@ -180,7 +181,7 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    for name, args in {"radmmm_colsum_scratch_floats": [i, i],
+    for name, args in {"radmmm_colsum_scratch_floats": [i, i], "radmmm_rowgemm_h3_colsum_scratch_floats": [i, i],
                        "radmmm_masked_reduce_scratch_floats": [i, i, i],
                        "radmmm_mas_scratch_bytes": [i, i, i],
                        "radmmm_film_bwd_scratch_floats": [i, i],

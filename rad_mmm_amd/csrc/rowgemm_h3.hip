@@ -195,6 +195,7 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
                                                       abs(p.ch_x8_exp) <= 16 && abs(p.c2h_x8_exp) <= 16),
                  "rowgemm_h3: 8-bit split outputs need ld %% 32 == 0 and |x8_exp| <= 16");
   RADMMM_REQUIRE(d->nprod >= 0 && d->nprod <= 3, "rowgemm_h3: nprod");
+  RADMMM_REQUIRE(!p.colsum_out || (p.colsum_scratch && !p.add && !p.C2), "rowgemm_h3: colsum_out needs colsum_scratch (and no add / C2 input)");
   RADMMM_REQUIRE(d->nprod != 2 || (abs(d->a8_exp) <= 16 && abs(d->b8_exp) <= 16 && d->lda_h % 32 == 0 && d->ldb_h % 32 == 0 &&
                                    d->b_tap_stride_h % 32 == 0),
                  "rowgemm_h3: nprod 2 needs ld %% 32 == 0 and |x8_exp| <= 16");
@@ -232,5 +233,16 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL(rowgemm_h3_kernel, dim3(ntm * ntn), dim3(256), SMEM_BYTES, static_cast<hipStream_t>(stream), *d,
                      (int)a_bytes, (int)b_bytes);
-  return radmmm::check_launch("rowgemm_h3");
+  const int rc = radmmm::check_launch("rowgemm_h3");
+  if (rc || !p.colsum_out) return rc;
+  return radmmm_colsum(p.C, p.ldc, p.colsum_out, p.colsum_scratch, p.M, p.N, p.rowscale == 2 ? 2 : (p.rowscale == 1 ? 1 : 0), p.T,
+                       p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
+}
+
+// scratch of the optional column sums (radmmm_rowgemm_desc.colsum_scratch): one partial row per row tile of the smallest
+// tile height (padded to whole column tiles), or what radmmm_colsum wants when a launch falls back to it
+extern "C" int64_t radmmm_rowgemm_h3_colsum_scratch_floats(int M, int N) {
+  const int64_t fused = (int64_t)((M + 127) / 128) * ((N + 255) / 256 * 256);
+  const int64_t plain = radmmm_colsum_scratch_floats(M, N);
+  return fused > plain ? fused : plain;
 }

@@ -69,7 +69,27 @@ int gemm_cu_slots() {
   return slots;
 }
 
+static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes, int* mb_out,
+                                    int* ek_out);
+
+extern "C" int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, radmmm_stream_t stream);
+extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch, int rows, int cols, int row_weight, int T,
+                             const int32_t* lens, int taps, int dil, int square, radmmm_stream_t stream);
+
+// the launch + (optional) the column sums of its pre-row-scale values: from the direct epilogue's per-tile partial rows, or,
+// when the launch took the generic epilogue, by radmmm_colsum over C (weights 1 / ratio: the same sum)
 int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  int mb = 0, ek = 0;
+  const int rc = launch_rowgemm_h3w_inner(d, stream, a_bytes, b_bytes, &mb, &ek);
+  const radmmm_rowgemm_desc& p = d.base;
+  if (rc || !p.colsum_out) return rc;
+  if (ek != EK_GENERIC) return radmmm_colsum_final(p.colsum_scratch, p.colsum_out, (p.M + 32 * mb - 1) / (32 * mb), p.N, stream);
+  return radmmm_colsum(p.C, p.ldc, p.colsum_out, p.colsum_scratch, p.M, p.N, p.rowscale == 2 ? 2 : (p.rowscale == 1 ? 1 : 0), p.T,
+                       p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
+}
+
+static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes, int* mb_out,
+                                    int* ek_out) {
   int mb = pick_h3w_mb(d.base.M, d.base.N, gemm_cu_slots());
   if (const char* e = debug_env("RADMMM_H3W_MB")) {
     const int v = atoi(e);
@@ -105,19 +125,21 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
       ek = p.Ch ? EK_SPLIT : EK_PLAIN;
     }
   }
+  *mb_out = mb;
+  *ek_out = ek;
   if (d.nprod == 2) {                                                                 // FP8 cross terms
     static const int rs_mode = [] {                    // RADMMM_DEBUG: RADMMM_RS=0 / 1 forces the 4-wave / role-split kernel
       const char* e = debug_env("RADMMM_RS");
       return e ? atoi(e) : -1;
     }();
-    const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT);   // (that instantiation spills)
+    const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT) && !p.colsum_out;   // (that instantiation spills)
     if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
     const char* we = debug_env("RADMMM_WIN");         // RADMMM_DEBUG: RADMMM_WIN=0 keeps the per-tap A tiles (A/B runs, tests)
     const char* wx = debug_env("RADMMM_WIN_XT");      // RADMMM_DEBUG: 0 = launches with the extra K segment keep rowgemm_h3d (A/B runs)
     const bool xt_ok = !d.extra_tap || !(wx && atoi(wx) == 0);
     if (!(we && atoi(we) == 0) && xt_ok && rowgemm_win_ok(mb, ek, d)) {
       const char* w8 = debug_env("RADMMM_WIN8");      // RADMMM_DEBUG: 1 = the 8-wave variant for the kinds it is built for
-      if (w8 && atoi(w8) == 1 && (ek == EK_PLAIN || ek == EK_SPLIT) && !d.extra_tap)
+      if (w8 && atoi(w8) == 1 && (ek == EK_PLAIN || ek == EK_SPLIT) && !d.extra_tap && !p.colsum_out)
         return launch_rowgemm_win8(mb, ek, d, stream, a_bytes, b_bytes);
       return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
     }

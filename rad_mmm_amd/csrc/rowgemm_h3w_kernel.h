@@ -246,6 +246,10 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   }
   const int left = (p.M - m0 + 31) / 32;
   const int nblk = left < MB ? left : MB;
+  // optional column sums of the value before its row scale, over the rows inside their utterance (include/radmmm_hip.h:
+  // colsum_out): two running sums per lane, combined across the lane halves and written as this tile's partial row below
+  const bool cs_on = p.colsum_scratch != nullptr;
+  float cs0 = 0.f, cs1 = 0.f;
 #pragma unroll 1
   for (int I = 0; I < nblk; ++I) {
     const int r0 = m0 + I * 32;
@@ -268,6 +272,11 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
         x0 *= dactf(side[e][0]);
         x1 *= dactf(side[e][1]);
       }
+      if (cs_on) {                                                 // (uniform)
+        const float m = (rf.z != 0.f && ru + 4 * h < p.M) ? 1.f : 0.f;
+        cs0 = fmaf(m, x0, cs0);
+        cs1 = fmaf(m, x1, cs1);
+      }
       x0 = actf(x0 * rf.z);
       x1 = actf(x1 * rf.z);
       f32x2 y;
@@ -286,6 +295,16 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     if constexpr (SIDE) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) side[e] = side_n[e];
+    }
+  }
+  if (cs_on) {
+    cs0 += __shfl_xor(cs0, 32);
+    cs1 += __shfl_xor(cs1, 32);
+    if (h == 0 && cok) {
+      f32x2 o;
+      o[0] = cs0; o[1] = cs1;
+      const int ldcs = (p.N + 255) & ~255;                         // (radmmm_rowgemm_h3_colsum_scratch_floats)
+      *reinterpret_cast<f32x2*>(p.colsum_scratch + (long long)(m0 / (32 * MB)) * ldcs + col) = o;
     }
   }
 }

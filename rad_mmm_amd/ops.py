@@ -1181,6 +1181,16 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # gQ_j live in one [2N, Wc] pair (rows [0, N) / [N, 2N)) and the transposed weights of in_layer j+1 and res_skip j
         # in one [taps + 1] tap stack.  RADMMM_FUSED_DGRAD=0 keeps the two-launch arrangement (A/B runs).
         fuse = debug_env("RADMMM_FUSED_DGRAD", "1") != "0"
+        # bias gradients of the in_layer convs and of the start conv: column sums of the data-gradient GEMMs' values before
+        # their row scale, taken from the accumulators in the epilogue (radmmm_rowgemm_desc.colsum_out) instead of a pass
+        # over the 52 MB output each.  RADMMM_FUSED_COLSUM=0: the separate radmmm_colsum launches (A/B runs).
+        fuse_cs = use_rm and debug_env("RADMMM_FUSED_COLSUM", "1") != "0"
+        cs_scratch = _empty(int(lib.radmmm_rowgemm_h3_colsum_scratch_floats(N, Wc)), like=z_in) if fuse_cs else None
+
+        def cs_args(param):
+            gb = grad_out(param)
+            gb = gb if (gb is not None and gb.numel() == Wc) else _empty(Wc, like=z_in)
+            return gb, dict(colsum_out=gb, colsum_scratch=cs_scratch)
         pair_h = pair_l = None           # [2N, Wc]: g_conv_{j+1} split in the first half, gQ_j goes into the second
         WT_prev = None                   # (WiT stack [kt+1][Wc][Wc] of layer j+1 with its last slot free, kt, dil)
         x_prev = None
@@ -1212,16 +1222,19 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             gclo = lo16()
             epi = dict(C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens, dact_src=H[j + 1], lddact=Wc, dact=act,
                        rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, Clo=gclo, ldch=Wc, ch_scale=SG)
+            cs_here = fuse_cs and (fused or G is None)         # (a launch with an `add` input keeps the separate pass)
+            gb, cs = cs_args(in_p[3 * j + 2]) if cs_here else (None, {})
             if fused:
                 WTh, WTl, ktn, dn = WT_prev
                 transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
                 rowgemm_h3(Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=WTh, Bl=WTl, ldb_h=Wc, b_tap_stride_h=WTh.stride(0), taps=ktn,
-                           dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout)
+                           dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout, **cs)
             else:
                 WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
-                rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout)
+                rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout, **cs)
             if use_rm:
-                g_in[3 * j + 2] = colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d, out=grad_out(in_p[3 * j + 2]))
+                g_in[3 * j + 2] = gb if cs_here else colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d,
+                                                            out=grad_out(in_p[3 * j + 2]))
                 slabs = wg_rm((gch, gclo if gclo is not None else gcl), Hpair[j], Wc, Wc, kt, d, lens if partial else None)
             elif (kt // 2) * d <= _TS_FRONT:
                 gy_t, g_in[3 * j + 2] = transpose_split_act(g_conv, Wc, B, T, None, 0, SG, "gy",
@@ -1253,10 +1266,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 if j == 0:
                     Gh, Gl = _halves(N, Wc, like=z_in)
                     Glo = lo16()
+                g_start_b, cs = cs_args(start_b) if (fuse_cs and j == 0) else (None, {})
                 rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
                            C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
                            a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
-                           Clo=Glo if j == 0 else None, ldch=Wc, ch_scale=SG, **gin, **gout)
+                           Clo=Glo if j == 0 else None, ldch=Wc, ch_scale=SG, **gin, **gout, **cs)
                 pair_h = pair_l = None
             check_saturation(box)
             if j == 2 and nl >= 3:
@@ -1265,7 +1279,8 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 notify_grads_final([end_w, end_b] + [t for jj in range(2, nl) for t in (*in_p[3 * jj: 3 * jj + 3], *res_p[3 * jj: 3 * jj + 3])])
         perm = (h, D, 0)
         if use_rm:
-            g_start_b = colsum(G, Wc, out=grad_out(start_b))
+            if not fuse_cs:
+                g_start_b = colsum(G, Wc, out=grad_out(start_b))
             slabs = wg_rm((Gh, Glo if Glo is not None else Gl), X0pair, Wc, Kp, 1, 1)
         else:
             gy_t, g_start_b = transpose_split_act(G, Wc, B, T, None, 0, SG, "gy", colsum=(0, None, 1, 1),
