@@ -126,6 +126,76 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_lds_kernel(
   }
 }
 
+// The same result without LDS and with every global load in flight at once (round 3): thread t owns input channels
+// 4t .. 4t + 3 of this output channel for ALL taps -- in checkpoint order ([ci][tap]) that is ONE contiguous run of 4 * TAPS
+// floats of v and of dv, and TAPS 16-byte pieces (x splits) of the slab planes.  The kernels above issue their loads in
+// three dependent waves (slabs -> LDS, then v, then inv_norm / g after the block sum): ~4 memory round trips per workgroup,
+// which is what a launch with one workgroup per output channel costs (20 us for a 1x1 conv's 12 MB, 32 us for a 5-tap
+// conv's 100 MB); here the only dependency is the block sum.  Needs the 16-byte conditions of the VEC path.
+template <int TAPS>
+__global__ __launch_bounds__(256) void weightnorm_bwd_reg_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ inv_norm,
+    const float* __restrict__ dW, int splits, long long split_stride, float* __restrict__ dv,
+    float* __restrict__ dg, int Cout, int Cin, int ldw, int perm_split, int off_lo, int off_hi,
+    const float* __restrict__ poison) {
+  __shared__ float sh[17];
+  const int co = blockIdx.x;
+  const long long n = (long long)Cin * TAPS;
+  const float inv = inv_norm[co], gg = g[co], pz = poison ? poison[0] : 0.f;
+  constexpr int MAXJ = 2;                                           // Cin <= 2048 (the host checks)
+  float4 vv[MAXJ][TAPS], gs[MAXJ][TAPS];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int ci = threadIdx.x * 4 + j * 1024;
+    const bool on = ci < Cin;
+    const int cic = on ? ci : 0;
+    const int col = perm_col(cic, perm_split, off_lo, off_hi);
+    const float* vp = v + (long long)co * n + (long long)cic * TAPS;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) vv[j][k] = on ? *reinterpret_cast<const float4*>(vp + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+      const float* plane = dW + ((long long)k * Cout + co) * ldw + col;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (on) {
+#pragma unroll 4
+        for (int sp = 0; sp < splits; ++sp) {
+          const float4 t = *reinterpret_cast<const float4*>(plane + sp * split_stride);
+          s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+        }
+      }
+      gs[j][k] = s0;                                               // gradient of channels ci .. ci + 3 at tap k
+    }
+  }
+  // element (channel c of the four, tap k) sits at c * TAPS + k of the thread's run
+  auto run_at = [](const float4 (&r)[TAPS], int idx) { const float4 q = r[idx >> 2]; return (idx & 3) == 0 ? q.x : (idx & 3) == 1 ? q.y : (idx & 3) == 2 ? q.z : q.w; };
+  auto chan_of = [](const float4& q, int c) { return c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w; };
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) dot = fmaf(chan_of(gs[j][k], c), run_at(vv[j], c * TAPS + k), dot);
+  dot = block_sum(dot, sh);
+  if (threadIdx.x == 0) dg[co] = dot * inv + pz;                   // poison: 0, or NaN after a non-finite upstream gradient
+  const float a = gg * inv, b = gg * dot * inv * inv * inv;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int ci = threadIdx.x * 4 + j * 1024;
+    if (ci < Cin) {
+      float o[4 * TAPS];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) o[c * TAPS + k] = a * chan_of(gs[j][k], c) - b * run_at(vv[j], c * TAPS + k);
+      float* dp = dv + (long long)co * n + (long long)ci * TAPS;
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) *reinterpret_cast<float4*>(dp + 4 * k) = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ WN input assembly
 __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     const float* __restrict__ ctx, int ldctx, const float* __restrict__ z, int ldz,
@@ -525,7 +595,19 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = Cin % 4 == 0 && perm_split % 4 == 0 && off_lo % 4 == 0 && off_hi % 4 == 0 && ldw % 4 == 0 &&
                      split_stride % 4 == 0 && a16(dW) && a16(v) && a16(dv);
-    if (vec)
+    static const bool reg_ok = !(radmmm::debug_env("RADMMM_WNBWD_REG") && atoi(radmmm::debug_env("RADMMM_WNBWD_REG")) == 0);
+    if (vec && reg_ok && Cin <= 2048 && (taps == 1 || taps == 3 || taps == 5)) {
+      // (Cin % 4 == 0 and 16-byte aligned v / dv rows: every thread's run of 4 * taps floats starts on a 16-byte boundary)
+      if (taps == 1)
+        hipLaunchKernelGGL(weightnorm_bwd_reg_kernel<1>, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW, splits,
+                           (long long)split_stride, dv, dg, Cout, Cin, ldw, perm_split, off_lo, off_hi, poison);
+      else if (taps == 3)
+        hipLaunchKernelGGL(weightnorm_bwd_reg_kernel<3>, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW, splits,
+                           (long long)split_stride, dv, dg, Cout, Cin, ldw, perm_split, off_lo, off_hi, poison);
+      else
+        hipLaunchKernelGGL(weightnorm_bwd_reg_kernel<5>, dim3(Cout), dim3(256), 0, ST(stream), v, g, inv_norm, dW, splits,
+                           (long long)split_stride, dv, dg, Cout, Cin, ldw, perm_split, off_lo, off_hi, poison);
+    } else if (vec)
       hipLaunchKernelGGL(weightnorm_bwd_lds_kernel<true>, dim3(Cout), dim3(256), lds, ST(stream), v, g, inv_norm, dW,
                          splits, (long long)split_stride, dv, dg, Cout, Cin, taps, ldw, perm_split, off_lo, off_hi, poison);
     else
