@@ -32,8 +32,9 @@ def main():
     lens = torch.tensor(sorted([int(T * (0.6 + 0.4 * i / max(1, B - 1))) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)
     gy = (torch.randn(B, T, 2 * H, generator=g) * 1e-3).to(dev)
     outs = {}
-    for mode in ("1", "0"):
-        os.environ["RADMMM_LSTM_PERSISTENT"] = mode
+    for mode in ("1", "1p", "0"):
+        os.environ["RADMMM_LSTM_PERSISTENT"] = mode[0]
+        os.environ["RADMMM_LSTM_PROBE"] = "3" if mode.endswith("p") else "0"
         for _ in range(2):
             y = bilstm(lstm, x, lens)
             (y * gy).sum().backward()
@@ -52,7 +53,7 @@ def main():
             tf += e[0].elapsed_time(e[1])
             tb += e[1].elapsed_time(e[2])
         outs[mode] = (y.detach().clone(), x.grad.clone(), lstm.weight_hh_l0.grad.clone())
-        print(f"RADMMM_LSTM_PERSISTENT={mode}: forward {tf / args.iters:.3f} ms, backward {tb / args.iters:.3f} ms "
+        print(f"RADMMM_LSTM_PERSISTENT={mode[0]} PROBE={os.environ['RADMMM_LSTM_PROBE']}: forward {tf / args.iters:.3f} ms, backward {tb / args.iters:.3f} ms "
               f"(B={B} T'={T} I={I} H={H}; includes the input projection and the gradient GEMMs)")
     a, b = outs["1"], outs["0"]
     for n, u, v in zip(("y", "dx", "dW_hh"), a, b):
