@@ -236,12 +236,24 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       read_a(t + D, sh);
       mfma_item(t);
       if (t < NW) dma_win(G::WPT * tap + t, (kb + 1) & 1, kb + 1);
+#ifdef RADMMM_WIN_FAKE_B6                         // TIMING-ONLY build (wrong results): what would six B pieces per wave and step cost?
+      else if (t >= BS && t < BS + 6) dma_b(t - BS, bsel, tap2, kb2);
+#else
       else if (t >= BS && t < BS + 8) dma_b(t - BS, bsel, tap2, kb2);
+#endif
     }
     pin_items_win<MB, tap, 0>();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RADMMM_WIN_FAKE_B6
+    if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifdef RADMMM_WIN_FAKE_B6
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 6) : "memory");
+#else
     else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 8) : "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = NT - D; t < NT; ++t) mfma_item(t);
