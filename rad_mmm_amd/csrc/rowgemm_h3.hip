@@ -242,7 +242,7 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
 // scratch of the optional column sums (radmmm_rowgemm_desc.colsum_scratch): one partial row per row tile of the smallest
 // tile height (padded to whole column tiles), or what radmmm_colsum wants when a launch falls back to it
 extern "C" int64_t radmmm_rowgemm_h3_colsum_scratch_floats(int M, int N) {
-  const int64_t fused = (int64_t)((M + 127) / 128) * ((N + 255) / 256 * 256);
+  const int64_t fused = (int64_t)((M + 127) / 128) * N;
   const int64_t plain = radmmm_colsum_scratch_floats(M, N);
   return fused > plain ? fused : plain;
 }

@@ -303,8 +303,8 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     if (h == 0 && cok) {
       f32x2 o;
       o[0] = cs0; o[1] = cs1;
-      const int ldcs = (p.N + 255) & ~255;                         // (radmmm_rowgemm_h3_colsum_scratch_floats)
-      *reinterpret_cast<f32x2*>(p.colsum_scratch + (long long)(m0 / (32 * MB)) * ldcs + col) = o;
+      // partial row of this row tile, pitch N (radmmm_colsum_final's layout); col is even and N even: 8-byte aligned
+      *reinterpret_cast<f32x2*>(p.colsum_scratch + (long long)(m0 / (32 * MB)) * p.N + col) = o;
     }
   }
 }

@@ -344,7 +344,7 @@ def test_shared_window_fused_data_gradient_matches_per_tap_tiles(B, T, lens, mb,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("win", ["1", "0"])
-@pytest.mark.parametrize("kind", ["dgrad_rowscale2", "plain_premask"])
+@pytest.mark.parametrize("kind", ["dgrad_rowscale2", "plain_premask", "plain_premask_N544"])
 def test_gemm_epilogue_column_sums_equal_a_pass_over_the_output(kind, win, monkeypatch):
     """radmmm_rowgemm_desc.colsum_out: the bias gradient of the conv whose data gradient a launch computes, summed from the
     accumulators in the direct epilogue (one partial row per row tile, fixed order), against radmmm_colsum over the stored
@@ -353,31 +353,32 @@ def test_gemm_epilogue_column_sums_equal_a_pass_over_the_output(kind, win, monke
     from rad_mmm_amd._lib import rowgemm_h3, lib
     dev = torch.device("cuda:0")
     B, T, Wc, taps, dil = 3, 300, 512, 5, 2
+    Nout = 544 if kind.endswith("N544") else Wc            # (a width that is not a multiple of the 256-column tile)
     N = B * T
     gen = torch.Generator().manual_seed(5)
     a1 = (torch.randn(N, Wc, generator=gen) * 3e-3).to(dev)
-    Hs = (torch.randn(N, Wc, generator=gen) * 2).to(dev)
-    w1 = (torch.randn(Wc, Wc, taps, generator=gen) * 0.03).to(dev)
+    Hs = (torch.randn(N, Nout, generator=gen) * 2).to(dev)
+    w1 = (torch.randn(Nout, Wc, taps, generator=gen) * 0.03).to(dev)
     lens_d = torch.tensor([300, 251, 170], dtype=torch.int32, device=dev)
     S = 2048.0
     Ah, Al = ops.split_f16(a1, Wc, S, Wc, 2, ops.X8_GRAD_EXP)
     Wh, Wl, _ = ops.split_weight(w1, None, Wc, nprod=2)
     monkeypatch.setenv("RADMMM_H3W_MB", "7")
     monkeypatch.setenv("RADMMM_WIN", win)
-    Cf = torch.full((N, Wc), float("nan"), device=dev)
-    Ch, Cl = ops._halves(N, Wc, like=a1)
-    got = torch.full((Wc,), float("nan"), device=dev)
-    scratch = torch.empty(int(lib.radmmm_rowgemm_h3_colsum_scratch_floats(N, Wc)), device=dev)
+    Cf = torch.full((N, Nout), float("nan"), device=dev)
+    Ch, Cl = ops._halves(N, Nout, like=a1)
+    got = torch.full((Nout,), float("nan"), device=dev)
+    scratch = torch.empty(int(lib.radmmm_rowgemm_h3_colsum_scratch_floats(N, Nout)), device=dev)
     common = dict(nprod=2, a8_exp=ops.X8_GRAD_EXP, b8_exp=ops.X8_W_EXP, acc_scale=1.0 / (S * ops.W_SCALE), T=T,
                   Ah=Ah, Al=Al, lda_h=Wc, Bh=Wh, Bl=Wl, ldb_h=Wc, b_tap_stride_h=Wh.stride(0), taps=taps, dil=dil, sign=-1,
-                  a_mask_mode=0, C=Cf, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens_d, Ch=Ch, Cl=Cl, ldch=Wc, ch_scale=S,
+                  a_mask_mode=0, C=Cf, ldc=Nout, M=N, N=Nout, K=Wc, lens=lens_d, Ch=Ch, Cl=Cl, ldch=Nout, ch_scale=S,
                   split_fmt=ops.SPLIT_X8A, ch_x8_exp=ops.X8_GRAD_EXP, colsum_out=got, colsum_scratch=scratch)
     if kind == "dgrad_rowscale2":
-        rowgemm_h3(dact_src=Hs, lddact=Wc, dact=1, rowscale=2, ratio_taps=taps, ratio_dil=dil, **common)
-        ref = ops.colsum(Cf, Wc, 2, T, lens_d, taps, dil)
+        rowgemm_h3(dact_src=Hs, lddact=Nout, dact=1, rowscale=2, ratio_taps=taps, ratio_dil=dil, **common)
+        ref = ops.colsum(Cf, Nout, 2, T, lens_d, taps, dil)
     else:
         rowgemm_h3(premask=1, **common)
-        ref = ops.colsum(Cf, Wc)
+        ref = ops.colsum(Cf, Nout)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(got).all()) and float(ref.abs().max()) > 0
     assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
