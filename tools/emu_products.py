@@ -4,6 +4,8 @@ every WN convolution (forward product and data-gradient product) replaced by an 
 
   h3     Ah.Bh + Ah.Bl + Al.Bh          three f16 MFMA products (the shipped parity mode)          3.00 units
   f8x    Ah.Bh + q8(Ah).q8(Bl) + q8(Al).q8(Bh)   cross terms on the FP8 pipe (e4m3, 2x rate)       2.00 units
+  f6x    the same with MXFP6 operands (e2m3, one shared power-of-two scale per 32 channels of K: the block-scaled
+         v_mfma_scale_f32_32x32x64_f8f6f4 runs FP6 at the FP4 rate, 4x f16)                           1.50 units
   2pa    Ah.Bh + Al.Bh                  activations exact, weights rounded once to f16               2.00 units
   2pb    Ah.Bh + Ah.Bl                  weights exact, activations rounded once to f16               2.00 units
   1p     Ah.Bh                          the 16-bit throughput mode                                    1.00 unit
@@ -48,8 +50,35 @@ def q8_lo(lo):
     return q8(lo * 2048.0) / 2048.0
 
 
-def product(conv, a, b, sa, sb):
+def q6_blocks(x, dim):
+    """MXFP6 (e2m3) image of x with one E8M0 scale per block of 32 along `dim` (the contraction axis): scale = 2^(floor(log2
+    (block max)) - 2) puts the block maximum into [4, 8); values round to nearest even on e2m3's grid (step 1/8 below 2, 1/4 below
+    4, 1/2 up to 7.5; saturating at 7.5)."""
+    xm = x.movedim(dim, -1)
+    shp = xm.shape
+    n = shp[-1]
+    pad = (-n) % 32
+    if pad:
+        xm = F.pad(xm, (0, pad))
+    blk = xm.reshape(*xm.shape[:-1], -1, 32)
+    amax = blk.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 2.0)
+    v = (blk / scale).clamp(-7.5, 7.5)
+    e = torch.floor(torch.log2(v.abs().clamp_min(1.0)))
+    step = torch.exp2(e - 3.0)
+    q = torch.round(v / step) * step                      # (torch.round: half to even)
+    q = q.clamp(-7.5, 7.5) * scale
+    q = q.reshape(*xm.shape)[..., :n].reshape(shp)
+    return q.movedim(-1, dim)
+
+
+KDIMS = (1, 1)        # contraction axis of (a, b): channels of x and Cin of w forward; channels of gy and Cout of w backward
+
+
+def product(conv, a, b, sa, sb, kdims=(1, 1)):
     """conv(a_operand, b_operand) under MODE; a scaled by sa, b by sb (powers of two)."""
+    global KDIMS
+    KDIMS = kdims
     if MODE == "exact":
         return conv(a, b)
     ah, al = f16_split(a * sa)
@@ -58,6 +87,9 @@ def product(conv, a, b, sa, sb):
         r = conv(ah, bh) + conv(ah, bl) + conv(al, bh)
     elif MODE == "f8x":
         r = conv(ah, bh) + conv(q8(ah), q8_lo(bl)) + conv(q8_lo(al), q8(bh))
+    elif MODE == "f6x":
+        ka, kb = KDIMS
+        r = conv(ah, bh) + conv(q6_blocks(ah, ka), q6_blocks(bl, kb)) + conv(q6_blocks(al, ka), q6_blocks(bh, kb))
     elif MODE == "2pa":
         r = conv(ah, bh) + conv(al, bh)
     elif MODE == "2pb":
@@ -83,7 +115,7 @@ class EmuConv(torch.autograd.Function):
         if GRAD_S[0] is None:
             amax = float(gy.abs().max())
             GRAD_S[0] = 2.0 ** np.floor(np.log2(16.0 / amax)) if amax > 0 else 1.0
-        gx = product(lambda a, b: F.conv_transpose1d(a, b, None, 1, pad, 0, 1, dil), gy, w, GRAD_S[0], W_SCALE)
+        gx = product(lambda a, b: F.conv_transpose1d(a, b, None, 1, pad, 0, 1, dil), gy, w, GRAD_S[0], W_SCALE, (1, 0))
         gw = torch.nn.grad.conv1d_weight(x, w.shape, gy, 1, pad, dil)
         return gx, gw, None, None
 
@@ -106,7 +138,7 @@ def run(tag):
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in O.procedural_decoder_state(O.decoder_state_shapes(cfg)).items()}
     b = {k: torch.from_numpy(v) for k, v in O.synthetic_batch(int(g["B"]), int(g["T"]), cfg, 1234, bool(g["ragged"])).items()}
     res = {}
-    for mode in ("exact", "h3", "f8x", "2pa", "2pb", "1p"):
+    for mode in ("exact", "h3", "f8x", "f6x", "2pa", "2pb", "1p"):
         global MODE
         MODE = mode
         GRAD_S[0] = None
@@ -126,7 +158,7 @@ def run(tag):
     m = (torch.arange(res["exact"]["z"].shape[2])[None] < ul[:, None])[:, None]
     ex = res["exact"]
     rows = []
-    for mode, units in (("h3", 3.0), ("f8x", 2.0), ("2pa", 2.0), ("2pb", 2.0), ("1p", 1.0)):
+    for mode, units in (("h3", 3.0), ("f8x", 2.0), ("f6x", 1.5), ("2pa", 2.0), ("2pb", 2.0), ("1p", 1.0)):
         r = res[mode]
         zerr = float(((r["z"] - ex["z"]) * m).abs().max() / (ex["z"] * m).abs().max())
         lerr = abs(r["loss"] - ex["loss"]) / abs(ex["loss"])
