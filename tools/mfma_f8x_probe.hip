@@ -113,6 +113,14 @@ __global__ __launch_bounds__(256, 1) void rate_kernel(const int* __restrict__ sr
         }
         acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[x], b8[0], acc[i][0], 0, 0, 0, sc_lo, 0, sc_hi);
         acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[x], b8[1], acc[i][1], 0, 0, 0, sc_lo, 0, sc_hi);
+      } else if constexpr (MODE == 3) {     // the same with MXFP6 (e2m3) operands: format codes 2 / 2, 24 of the 32 bytes used
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x][kb], bh[0][kb], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x][kb], bh[1][kb], acc[i][1], 0, 0, 0);
+        }
+        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[x], b8[0], acc[i][0], 2, 2, 0, sc_lo, 0, sc_hi);
+        acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[x], b8[1], acc[i][1], 2, 2, 0, sc_lo, 0, sc_hi);
       } else {                               // single product (throughput mode)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -206,6 +214,8 @@ int main() {
     rate<2>(src, "2 x f16 (single product)", name);
     rate<0>(src, "6 x f16 (split-f16 x3)", name);
     rate<1>(src, "2 x f16 + 1 x scaled f8 (K=64)", name);
+    rate<3>(src, "2 x f16 + 1 x scaled f6 (K=64)", name);
+    rate<3>(src, "2 x f16 + 1 x scaled f6 (K=64)", name);
   }
   return 0;
 }
