@@ -377,6 +377,14 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
+// the same with a wave-uniform byte offset in the instruction's SCALAR offset operand (no vector add per piece; the
+// scalar offset takes part in the range check on gfx950, so an out-of-range vector offset stays out of range)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 template <int MB, int PR, int EK>
 __global__ __launch_bounds__(256, 1) void rowgemm_h3d_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes,
                                                               const int b_bytes) {

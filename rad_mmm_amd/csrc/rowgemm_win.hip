@@ -131,18 +131,6 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Al), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bh), 0, b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Bl), 0, b_bytes, 0x00020000);
-  // window piece k (compile-time) of k slice kb into window `par`
-  auto dma_win = [&](int k, int par, int kb) __attribute__((always_inline)) {
-    const int dst = w_dst[k] < 0 ? G::DUMP + wave * 1024 : G::W_BASE + par * G::W_BYTES + w_dst[k];
-    dma16(w_isl[k] ? rAl : rAh, (lds_u32_ptr)(sm + dst), w_vo[k] + kb * (BK * 2));
-  };
-  // B piece w (0 .. 7) of tile (tap, kb) into B stage `buf`
-  auto dma_b = [&](int w, int buf, int tap, int kb) __attribute__((always_inline)) {
-    const int k = w & 3, arr = w >> 2;
-    const int vo = b_voff[k] + (int)(tap * q.b_tap_stride_h * 2) + kb * (BK * 2);
-    dma16(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + buf * G::B_STAGE + b_dst[k] + arr * G::B_BYTES), vo);
-  };
-
   f32x16 acc[MB][2];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -151,128 +139,157 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- fragment addressing
-  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3, half = lane >> 5;
-  const int f_off0 = f_row + (((0 + half) ^ f_swz) << 4);            // B tiles: fixed rows, as in rowgemm_h3d
-  const int f_off1 = f_row + (((2 + half) ^ f_swz) << 4);
-  int wrow[MB];                                                       // LDS row (in 64-byte units from sm) of tile row 32 i + (lane & 31) at shift 0, window 0
+  // ---- fragment addressing: NO arithmetic in the K loop.  The byte address of (row block i, tap) -- window 0, hi plane,
+  // k block 0 / 1 -- is computed once per tile (2 x 35 registers); the window parity and the cross plane are immediate
+  // offsets of the ds_read (the parity moves a row by 2 WR = 576 rows: the XOR swizzle, which follows (row >> 2) & 3, does
+  // not change), the k block flips bit 5.
+  const int half = lane >> 5;
+  static_assert((2 * G::WR) % 16 == 0 && G::W_BYTES + G::W_PLANE < 65536, "window parity / plane as ds_read immediates");
+  int aad0[MB][WTAPS], aad1[MB][WTAPS];
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int ri = 32 * i + (lane & 31);
-    wrow[i] = G::W_BASE / ROWB + ri + 2 * dil + (ri >= nb ? 4 * dil : 0);
-  }
-  // byte offset of (row block i, k block 0) for the uniform row shift sh (tap shift + window parity); k block 1 is ^ 32
-  auto a_off = [&](int i, int sh) __attribute__((always_inline)) {
-    const int w = wrow[i] + sh;
-    return (w << 6) + (((half ^ (w >> 2)) & 3) << 4);
-  };
-  auto shift_of = [&](int tap, int kb) __attribute__((always_inline)) {
-    return sg * (tap - WTAPS / 2) * dil + (kb & 1) * (G::W_BYTES / ROWB);
-  };
-
-  f16x8 fah[NT], fal[NT], bh[2][2], bl[2][2];
-  auto read_a = [&](int t, int sh) __attribute__((always_inline)) {   // item t = 2 i + kblock
-    const int o = a_off(t >> 1, sh) ^ ((t & 1) << 5);
-    fah[t] = *reinterpret_cast<const f16x8*>(sm + o);
-    fal[t] = *reinterpret_cast<const f16x8*>(sm + o + G::W_PLANE);
-  };
-  auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
-    const unsigned char* sB = sm + bsel * G::B_STAGE + wave * 64 * ROWB;
-    const int fo = kb ? f_off1 : f_off0;
+    const int w0 = G::W_BASE / ROWB + ri + 2 * dil + (ri >= nb ? 4 * dil : 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bh[kb][j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + fo);
-      bl[kb][j] = *reinterpret_cast<const f16x8*>(sB + G::B_BYTES + j * 32 * ROWB + fo);
+    for (int tp = 0; tp < WTAPS; ++tp) {
+      const int w = w0 + sg * (tp - WTAPS / 2) * dil;
+      aad0[i][tp] = (w << 6) + (((half ^ (w >> 2)) & 3) << 4);
+      aad1[i][tp] = aad0[i][tp] ^ 32;
     }
+  }
+  const int f_row = (lane & 31) * ROWB, f_swz = (lane >> 2) & 3;
+  const int bad0 = wave * 64 * ROWB + f_row + (((0 + half) ^ f_swz) << 4);   // B tiles: fixed rows, as in rowgemm_h3d
+  const int bad1 = wave * 64 * ROWB + f_row + (((2 + half) ^ f_swz) << 4);
+
+  f16x8 fah[NT], fal[NT], bh[2][2][2], bl[2][2][2];                   // B fragments: [register set][k block][column block]
+  auto read_hi = [&](int t, auto tapc, auto parc) __attribute__((always_inline)) {        // item t = 2 i + kblock
+    constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
+    fah[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1][tap] + par * G::W_BYTES);
+  };
+  auto read_lo = [&](int t, auto tapc, auto parc) __attribute__((always_inline)) {
+    constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
+    fal[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1][tap] + par * G::W_BYTES + G::W_PLANE);
+  };
+  auto read_b1 = [&](int set, int stage, int kb, int j) __attribute__((always_inline)) {
+    const int fo = kb ? bad1 : bad0;
+    bh[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + stage * G::B_STAGE + j * 32 * ROWB + fo);
+    bl[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + stage * G::B_STAGE + G::B_BYTES + j * 32 * ROWB + fo);
   };
   const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;       // E8M0 block scales (rowgemm_h3d, PR 2)
   const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
-  auto cross = [&](int i, int j) __attribute__((always_inline)) {
+  auto cross = [&](int set, int i, int j) __attribute__((always_inline)) {
     const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, fal[2 * i]), __builtin_bit_cast(i32x4, fal[2 * i + 1]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
-    const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[0][j]), __builtin_bit_cast(i32x4, bl[1][j]),
+    const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
   };
-  auto mfma_item = [&](int t) __attribute__((always_inline)) {
-    const int kb = t & 1, i = t >> 1;
-    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][0], acc[i][0], 0, 0, 0);
-    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[kb][1], acc[i][1], 0, 0, 0);
-    if (kb == 1) cross(i, 0);
-    else if (i > 0) cross(i - 1, 1);
+  // DMA with the step's position as the instruction's SCALAR offset (no vector add per piece; an out-of-range vector offset
+  // stays out of range: the scalar offset takes part in the range check on gfx950)
+  auto dma_win2 = [&](int k, int par, int kb) __attribute__((always_inline)) {
+    const int dst = w_dst[k] < 0 ? G::DUMP + wave * 1024 : G::W_BASE + par * G::W_BYTES + w_dst[k];
+    dma16s(w_isl[k] ? rAl : rAh, (lds_u32_ptr)(sm + dst), w_vo[k], kb * (BK * 2));
   };
+  auto dma_b2 = [&](int w, int buf, int soff) __attribute__((always_inline)) {
+    const int k = w & 3, arr = w >> 2;
+    dma16s(arr == 0 ? rBh : rBl, (lds_u32_ptr)(sm + buf * G::B_STAGE + b_dst[k] + arr * G::B_BYTES), b_voff[k], soff);
+  };
+  const int b_tap_bytes = (int)(q.b_tap_stride_h * 2);
 
-  // ---- K loop.  Who waits for what:
-  //   B tile: wave-private rows.  B(s) sits in REGISTERS during step s (read at the tail of step s - 1), so its LDS stage
-  //     (s & 1) is free from item 3 of step s on and receives B(s + 2): two K steps of flight time for every piece, and
-  //     the only synchronisation is this wave's own vmcnt -- at the end of step s everything but the step's own DMA
-  //     instructions must have landed (in-order counter: that is B(s + 1) and all older pieces).
-  //   A window of slice kb + 1: all of it is issued in taps 0..2 of slice kb (two to four K steps of flight time); the ONE
-  //     barrier per k slice, after tap 4, publishes it to the other waves and frees window kb - 1 for slice kb + 2's DMA.
+  // ---- K loop (round 4).  One wave per SIMD issues EVERYTHING in order, so whatever stands between two MFMAs must fit
+  // under the first one's 32 (f16) / 64 (fp8) cycles or the matrix pipe idles (tools/issue_cost_probe.hip: <= 4 light
+  // instructions or one LDS / DMA instruction per f16 MFMA).  Round 3's sched_group_barrier pins left bursts of 28 reads +
+  // 11 DMA pieces without an MFMA in three of the five steps of a slice; here the step is a sequence of SLOTS, each closed
+  // by a sched_barrier(0) the scheduler cannot move anything across:
+  //     slot A: MFMA acc[i][0] (f16) | hi fragment of item t + 2              (+ 2 B reads in the step's last two items)
+  //     slot B: MFMA acc[i][1] (f16) | cross fragment of item t + 2           (+ 2 B reads ...)
+  //     slot C: cross MFMA (fp8, 64 cycles) | one DMA piece
+  // Who waits for what:
+  //   B tile: wave-private rows.  B(s + 1) is read into the OTHER register set during the last two items of step s, behind
+  //     this wave's own vmcnt (in-order counter: everything but the step's own pieces has landed), so the first MFMA of
+  //     step s + 1 finds its operands in registers; the stage is free for B(s + 3)... i.e. B(s + 2) goes into stage s & 1
+  //     from the first slot of step s on: two K steps of flight time.
+  //   A window of slice kb + 1: issued in taps 0..2 of slice kb; the ONE barrier per slice sits behind the last read of
+  //     the old window (item 11 of tap 4, whose look-ahead reads item 13), and publishes the new one for the look-ahead
+  //     reads of items 12 / 13 (items 0 / 1 of the next slice).
+  //   The look-ahead crosses the step boundary: items 12 / 13 read items 0 / 1 of the NEXT step (next tap's row shift).
 #pragma unroll
-  for (int k = 0; k < NPW; ++k) dma_win(k, 0, 0);
+  for (int k = 0; k < NPW; ++k) dma_win2(k, 0, 0);
 #pragma unroll
-  for (int w = 0; w < 8; ++w) dma_b(w, 0, 0, 0);
+  for (int w = 0; w < 8; ++w) dma_b2(w, 0, 0);
 #pragma unroll
-  for (int w = 0; w < 8; ++w) dma_b(w, 1, 1, 0);
+  for (int w = 0; w < 8; ++w) dma_b2(w, 1, b_tap_bytes);
   __syncthreads();
-  read_b(0, 0);
-  read_b(0, 1);
-  {
-    const int sh = shift_of(0, 0);
 #pragma unroll
-    for (int t = 0; t < D; ++t) read_a(t, sh);
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) read_b1(0, 0, kb, j);
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    read_hi(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    read_lo(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   }
-  auto kstep = [&](auto tapc, int kb, int bsel) __attribute__((always_inline)) {
-    constexpr int tap = decltype(tapc)::value;
-    constexpr int NW = G::nw(tap), BS = G::bstart(tap);
-    const int sh = shift_of(tap, kb);
-    const int ntap = tap == WTAPS - 1 ? 0 : tap + 1, nkb = tap == WTAPS - 1 ? kb + 1 : kb;      // tile of step + 1
-    constexpr int tap2 = (tap + 2) % WTAPS;                                                       // tile of step + 2
-    const int kb2 = kb + (tap + 2) / WTAPS;
-    // items 0 .. NT-D-1: fragments of item t + D | MFMAs of item t | one DMA piece
+  constexpr int TW = NT - 2;                                          // the step's wait (and the slice's barrier) stand in front of item TW
+  auto kstep = [&](auto tapc, auto parc, int kb) __attribute__((always_inline)) {
+    constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;      // par = kb & 1
+    constexpr int set = (par + tap) & 1;                              // step index 5 kb + tap is even / odd: B register set AND B stage
+    constexpr int NW = G::nw(tap);
+    constexpr int ntap = tap == WTAPS - 1 ? 0 : tap + 1, npar = tap == WTAPS - 1 ? (par ^ 1) : par;   // tile of step + 1
+    constexpr int tap2 = (tap + 2) % WTAPS;                           // tile of step + 2
+    const int soff2 = tap2 * b_tap_bytes + (kb + (tap + 2) / WTAPS) * (BK * 2);
+    using TapC = std::integral_constant<int, tap>;
+    using ParC = std::integral_constant<int, par>;
+    using NTapC = std::integral_constant<int, ntap>;
+    using NParC = std::integral_constant<int, npar>;
+    static_assert(NW + 8 <= NT - 2, "DMA slots of a step");
 #pragma unroll
-    for (int t = 0; t < NT - D; ++t) {
-      read_a(t + D, sh);
-      mfma_item(t);
-      if (t < NW) dma_win(G::WPT * tap + t, (kb + 1) & 1, kb + 1);
-#ifdef RADMMM_WIN_FAKE_B6                         // TIMING-ONLY build (wrong results): what would six B pieces per wave and step cost?
-      else if (t >= BS && t < BS + 6) dma_b(t - BS, bsel, tap2, kb2);
-#else
-      else if (t >= BS && t < BS + 8) dma_b(t - BS, bsel, tap2, kb2);
-#endif
+    for (int t = 0; t < NT; ++t) {
+      const int kbk = t & 1, i = t >> 1;
+      if (t == TW) {
+        // everything but this step's own pieces has landed: B(s + 1) in particular; in the slice's last step every read of
+        // the old window has been issued (and is waited for), the barrier publishes the new window
+        if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(NW + 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 8) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // slot A
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][0], acc[i][0], 0, 0, 0);
+      if (t + D < NT) read_hi(t + D, TapC{}, ParC{});
+      else read_hi(t + D - NT, NTapC{}, NParC{});
+      if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // slot B
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][1], acc[i][1], 0, 0, 0);
+      if (t + D < NT) read_lo(t + D, TapC{}, ParC{});
+      else read_lo(t + D - NT, NTapC{}, NParC{});
+      if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // slot C (items 1 .. 13; the 14th follows the loop)
+      if (t > 0) {
+        if (kbk == 1) cross(set, i, 0);
+        else cross(set, i - 1, 1);
+        const int c = t - 1;
+        if (c < NW) dma_win2(G::WPT * tap + c, par ^ 1, kb + 1);
+        else if (c - NW < 8) dma_b2(c - NW, set, soff2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    pin_items_win<MB, tap, 0>();
+    cross(set, MB - 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef RADMMM_WIN_FAKE_B6
-    if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    if constexpr (tap == WTAPS - 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-#ifdef RADMMM_WIN_FAKE_B6
-    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 6) : "memory");
-#else
-    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW + 8) : "memory");
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = NT - D; t < NT; ++t) mfma_item(t);
-    cross(MB - 1, 1);
-    read_b(bsel ^ 1, 0);
-    read_b(bsel ^ 1, 1);
-    {
-      const int shn = shift_of(ntap, nkb);
-#pragma unroll
-      for (int t = 0; t < D; ++t) read_a(t, shn);
-    }
   };
-  int bsel = 0;                                                       // B stage of the current step
-  for (int kb = 0; kb < kpt; ++kb) {
-    kstep(std::integral_constant<int, 0>{}, kb, bsel); bsel ^= 1;
-    kstep(std::integral_constant<int, 1>{}, kb, bsel); bsel ^= 1;
-    kstep(std::integral_constant<int, 2>{}, kb, bsel); bsel ^= 1;
-    kstep(std::integral_constant<int, 3>{}, kb, bsel); bsel ^= 1;
-    kstep(std::integral_constant<int, 4>{}, kb, bsel); bsel ^= 1;
+  for (int kb = 0; kb < kpt; kb += 2) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    kstep(std::integral_constant<int, 0>{}, P0{}, kb);
+    kstep(std::integral_constant<int, 1>{}, P0{}, kb);
+    kstep(std::integral_constant<int, 2>{}, P0{}, kb);
+    kstep(std::integral_constant<int, 3>{}, P0{}, kb);
+    kstep(std::integral_constant<int, 4>{}, P0{}, kb);
+    kstep(std::integral_constant<int, 0>{}, P1{}, kb + 1);
+    kstep(std::integral_constant<int, 1>{}, P1{}, kb + 1);
+    kstep(std::integral_constant<int, 2>{}, P1{}, kb + 1);
+    kstep(std::integral_constant<int, 3>{}, P1{}, kb + 1);
+    kstep(std::integral_constant<int, 4>{}, P1{}, kb + 1);
   }
   __syncthreads();                                                    // stray fragment reads / DMA past the last tile
 
@@ -291,11 +308,33 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       x_vo[k] = r < p.M ? ((q.extra_a_rows + r) * q.lda_h + d_chunk * 8) * 2 : OOB;
       x_dst[k] = x_isl[k] * G::W_PLANE + j * 1024;
     }
+    // (round 3's item schedule, compiler-ordered: the segment is 1/6 of this launch's K steps)
+    int wrow[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) wrow[i] = G::W_BASE / ROWB + 32 * i + (lane & 31);
+    auto a_off = [&](int i, int sh) __attribute__((always_inline)) {
+      const int w = wrow[i] + sh;
+      return (w << 6) + (((half ^ (w >> 2)) & 3) << 4);
+    };
+    auto read_a = [&](int t, int sh) __attribute__((always_inline)) {   // item t = 2 i + kblock
+      const int o = a_off(t >> 1, sh) ^ ((t & 1) << 5);
+      fah[t] = *reinterpret_cast<const f16x8*>(sm + o);
+      fal[t] = *reinterpret_cast<const f16x8*>(sm + o + G::W_PLANE);
+    };
+    auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
+      read_b1(0, bsel, kb, 0);
+      read_b1(0, bsel, kb, 1);
+    };
+    auto mfma_item = [&](int t) __attribute__((always_inline)) {
+      const int kb = t & 1, i = t >> 1;
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[0][kb][0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[0][kb][1], acc[i][1], 0, 0, 0);
+      if (kb == 1) cross(0, i, 0);
+      else if (i > 0) cross(0, i - 1, 1);
+    };
     auto dma_x = [&](int w, int par, int kb) __attribute__((always_inline)) {      // piece w of 0 .. MB + 7 of tile kb
       if (w < MB) dma16(x_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + G::W_BASE + par * G::W_BYTES + x_dst[w]), x_vo[w] + kb * (BK * 2));
-      else dma_b(w - MB, par, WTAPS, kb);
+      else dma_b2(w - MB, par, WTAPS * b_tap_bytes + kb * (BK * 2));
     };
 #pragma unroll
     for (int w = 0; w < MB + 8; ++w) dma_x(w, 0, 0);
@@ -318,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = NT - D; t < NT; ++t) mfma_item(t);
-      cross(MB - 1, 1);
+      cross(0, MB - 1, 1);
       read_b(par ^ 1, 0);
       read_b(par ^ 1, 1);
 #pragma unroll
@@ -382,7 +421,7 @@ bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d) {
   if (mb != 7) return false;
 #endif
   return d.nprod == 2 && (mb == 7 || mb == 8) && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_DGRAD) && p.taps == WTAPS &&
-         (!d.extra_tap || (ek == EK_DGRAD && !p.a_mask_mode)) && p.dil >= 1 && p.dil <= WDMAX && p.T >= 32 * mb && p.M % p.T == 0 && (p.sign == 1 || p.sign == -1);
+         (!d.extra_tap || (ek == EK_DGRAD && !p.a_mask_mode)) && (p.K / BK) % 2 == 0 && p.dil >= 1 && p.dil <= WDMAX && p.T >= 32 * mb && p.M % p.T == 0 && (p.sign == 1 || p.sign == -1);
 }
 int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
 #ifndef RADMMM_QUICK

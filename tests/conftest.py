@@ -22,6 +22,25 @@ def pytest_configure(config):
         subprocess.check_call(["bash", os.path.join(ROOT, "rad_mmm_amd", "csrc", "build.sh")])
 
 
+def host_threads() -> int:
+    """CPU threads this process may really use (affinity mask capped by the cgroup CPU quota).  torch's default is the
+    host's core count: on a box whose container is limited to a few cores the CPU oracle then runs oversubscribed and
+    5-10x slower -- round 3's GPU suite spent 600 of its 1170 s there."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def pytest_sessionstart(session):
+    import torch
+    torch.set_num_threads(host_threads())
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name)) as f:
         return {k: f[k] for k in f.files}

@@ -8,6 +8,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_dma_mix.hip -o tools/mfma_dma_mix.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -83,6 +84,63 @@ __global__ __launch_bounds__(NW * 64, 1) void mix(const unsigned char* src, long
         }
       }
       off += NW * NP * 1024;
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == 6) {                      // as MODE 0, but wave w issues its pieces w MFMAs later: no two waves issue a piece at the same time
+      constexpr int EV = NM / (NP > 0 ? NP : 1);
+      auto body = [&](auto woff) __attribute__((always_inline)) {
+        constexpr int WOFF = decltype(woff)::value;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m % NACC], 0, 0, 0);
+          if (m >= WOFF && (m - WOFF) % EV == 0 && (m - WOFF) / EV < NP) {
+            const int w = (m - WOFF) / EV;
+            const int vo = (off + w * 16 * 2048 + lane_off) & (int)(window - 1);
+            dma16(r, (lds_u32_ptr)(sm + ((it & 1) * NW * NP + wave * NP + w) * 1024), vo);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      switch (wave & 3) {
+        case 0: body(std::integral_constant<int, 0>{}); break;
+        case 1: body(std::integral_constant<int, 1>{}); break;
+        case 2: body(std::integral_constant<int, 2>{}); break;
+        default: body(std::integral_constant<int, 3>{}); break;
+      }
+      off += NW * NP * 16 * 2048;
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == 8 || MODE == 9) {         // MODE 7 with OUT-OF-RANGE pieces (8: the DMA writes zeros, no memory traffic) / one lane only (9)
+      constexpr int EV = NM / (NP > 0 ? NP : 1);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m % NACC], 0, 0, 0);
+        if (m % EV == 0 && m / EV < NP) {
+          const int w = m / EV;
+          const int vo = MODE == 8 ? 0x7fffffff : ((lane == 0 ? (off + w * 16 * 2048) & (int)(window - 1) : 0x7fffffff));
+          dma16(r, (lds_u32_ptr)(sm + ((it & 1) * NW * NP + wave * NP + w) * 1024), vo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      off += NW * NP * 16 * 2048;
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == 7) {                      // MODE 0 with the same hard pins as MODE 6 (all waves aligned)
+      constexpr int EV = NM / (NP > 0 ? NP : 1);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m % NACC], 0, 0, 0);
+        if (m % EV == 0 && m / EV < NP) {
+          const int w = m / EV;
+          const int vo = (off + w * 16 * 2048 + lane_off) & (int)(window - 1);
+          dma16(r, (lds_u32_ptr)(sm + ((it & 1) * NW * NP + wave * NP + w) * 1024), vo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      off += NW * NP * 16 * 2048;
       __syncthreads();
       continue;
     }
@@ -181,6 +239,12 @@ int main() {
     run<8, 28, 7, 3>("8 waves, MFMA + pieces staged through VGPRs", d, dout, sink, grid, iters);
     run<8, 28, 7, 4>("8 waves, role split (4 MFMA waves, 4 DMA waves)", d, dout, sink, grid, iters);
     run<4, 56, 14, 5>("4 waves, MFMA + DMA addressed by TID (no VGPR)", d, dout, sink, grid, iters);
+    run<4, 56, 14, 7>("4 waves, MFMA + DMA, pinned, waves aligned", d, dout, sink, grid, iters);
+    run<4, 56, 14, 6>("4 waves, MFMA + DMA, pinned, waves STAGGERED by one MFMA", d, dout, sink, grid, iters);
+    run<4, 56, 14, 8>("4 waves, MFMA + 14 OUT-OF-RANGE DMA pieces (no traffic)", d, dout, sink, grid, iters);
+    run<4, 56, 14, 9>("4 waves, MFMA + 14 DMA pieces with ONE lane in range", d, dout, sink, grid, iters);
+    run<4, 56, 7, 7>("4 waves, MFMA + half the DMA, pinned, aligned", d, dout, sink, grid, iters);
+    run<4, 56, 7, 6>("4 waves, MFMA + half the DMA, pinned, STAGGERED", d, dout, sink, grid, iters);
   }
   return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
