@@ -326,6 +326,9 @@ def main():
     ap.add_argument("--rccl-channels", type=int, default=None,
                     help="N > 1: pin RCCL to this many channels (NCCL_MIN/MAX_NCHANNELS) and size the GEMM grids for the "
                          "remaining CUs; default 8 (rad_mmm_amd.ddp.reserve_collective_cus)")
+    ap.add_argument("--step-only", action="store_true",
+                    help="profiling aid (tools/prof_step.sh): run warm-up + timed steps, print ms per step and exit -- no roofline "
+                         "leg, no extra legs, so that a kernel trace holds nothing but the steps")
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     ap.add_argument("--dominant-only", action="store_true",
                     help="launch only the roofline leg's kernel (the PMC passes of tools/pmc_dominant.sh wrap this)")
@@ -482,6 +485,11 @@ def main():
                          bucket_order=[reducer.buckets[i]["key"] for i in reducer._order],
                          bucket_mbytes=[round(reducer.buckets[i]["flat"].numel() * 4 / 1e6, 1) for i in reducer._order])
 
+    if args.step_only:
+        if rank == 0:
+            print(json.dumps({"step_only": True, "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "steps": args.steps,
+                              "warmup": args.warmup, "loss": loss_val}))
+        return
     if rank == 0:
         N = B * (T // cfg.n_group_size)
         h3 = dec.gemm_precision in ("h3", "f8x")

@@ -9,13 +9,12 @@ namespace radmmm {
 int launch_h3d_pr1(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 int launch_h3d_pr2(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 int launch_h3d_pr3(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
-// rowgemm_rs.hip: role-split kernel (8 consumer + 4 producer waves), FP8-cross scheme, EK_PLAIN / EK_SPLIT
-int launch_rowgemm_rs(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 // rowgemm_win.hip: 5-tap convs with the A rows of a k slice fetched once for all taps (shared window), FP8-cross scheme
 bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d);
 int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
-// rowgemm_win8.hip: the same with two waves per SIMD (the tile split by rows over 8 waves)
-int launch_rowgemm_win8(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
+// rowgemm_one.hip: 1-tap convs (no extra K segment) on a three-stage A ring with wave-private B tiles, FP8-cross scheme
+bool rowgemm_one_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d);
+int launch_rowgemm_one(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes);
 }  // namespace radmmm
 
 namespace {
@@ -128,21 +127,12 @@ static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t
   *mb_out = mb;
   *ek_out = ek;
   if (d.nprod == 2) {                                                                 // FP8 cross terms
-    static const int rs_mode = [] {                    // RADMMM_DEBUG: RADMMM_RS=0 / 1 forces the 4-wave / role-split kernel
-      const char* e = debug_env("RADMMM_RS");
-      return e ? atoi(e) : -1;
-    }();
-    const bool rs_ok = (ek == EK_PLAIN || ek == EK_SPLIT) && p.N % 32 == 0 && !(mb == 8 && ek == EK_SPLIT) && !p.colsum_out;   // (that instantiation spills)
-    if (rs_ok && rs_mode == 1) return launch_rowgemm_rs(mb, ek, d, stream, a_bytes, b_bytes);
     const char* we = debug_env("RADMMM_WIN");         // RADMMM_DEBUG: RADMMM_WIN=0 keeps the per-tap A tiles (A/B runs, tests)
     const char* wx = debug_env("RADMMM_WIN_XT");      // RADMMM_DEBUG: 0 = launches with the extra K segment keep rowgemm_h3d (A/B runs)
     const bool xt_ok = !d.extra_tap || !(wx && atoi(wx) == 0);
-    if (!(we && atoi(we) == 0) && xt_ok && rowgemm_win_ok(mb, ek, d)) {
-      const char* w8 = debug_env("RADMMM_WIN8");      // RADMMM_DEBUG: 1 = the 8-wave variant for the kinds it is built for
-      if (w8 && atoi(w8) == 1 && (ek == EK_PLAIN || ek == EK_SPLIT) && !d.extra_tap && !p.colsum_out)
-        return launch_rowgemm_win8(mb, ek, d, stream, a_bytes, b_bytes);
-      return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
-    }
+    if (!(we && atoi(we) == 0) && xt_ok && rowgemm_win_ok(mb, ek, d)) return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
+    const char* oe = debug_env("RADMMM_ONE");         // RADMMM_DEBUG: RADMMM_ONE=0 keeps rowgemm_h3d for the 1-tap launches (A/B runs, tests)
+    if (!(oe && atoi(oe) == 0) && rowgemm_one_ok(mb, ek, d)) return launch_rowgemm_one(mb, ek, d, stream, a_bytes, b_bytes);
     return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);
   }
   if (d.nprod == 1) return launch_h3d_pr1(mb, ek, d, stream, a_bytes, b_bytes);       // 16-bit throughput mode

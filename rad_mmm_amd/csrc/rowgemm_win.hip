@@ -29,7 +29,7 @@
 // (rowgemm_h3w.hip decides; everything else keeps rowgemm_h3d).
 #include <type_traits>
 
-#include "rowgemm_h3w_kernel.h"
+#include "rowgemm_onetap.h"
 
 namespace {
 
@@ -296,8 +296,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   // ---- optional EXTRA K segment (include/radmmm_hip.h: extra_tap): acc += A2 . B[taps], A2 = the rows extra_a_rows below,
   // no shift, no mask.  It runs AFTER all tap slices (rowgemm_h3d interleaves it per k slice: same products, another fp32
   // summation order), as a plain double-buffered loop -- one A tile and one B tile per K step, one barrier per step -- in
-  // the LDS the windows no longer need.
+  // the LDS the windows no longer need -- rowgemm_onetap.h's loop (three A stages, wave-private B, slot-pinned order).
   if constexpr (XT) {
+    using OG = OneGeo<MB>;                                            // B stages where they were, a ring of three A stages behind them
     int x_vo[MB], x_dst[MB], x_isl[MB];
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
@@ -306,64 +307,13 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       const int j = x_isl[k] ? c - 2 * MB : c;
       const int r = m0 + 16 * j + d_row;
       x_vo[k] = r < p.M ? ((q.extra_a_rows + r) * q.lda_h + d_chunk * 8) * 2 : OOB;
-      x_dst[k] = x_isl[k] * G::W_PLANE + j * 1024;
+      x_dst[k] = OG::A_BASE + x_isl[k] * OG::A_PLANE + j * 1024;
     }
-    // (round 3's item schedule, compiler-ordered: the segment is 1/6 of this launch's K steps)
-    int wrow[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) wrow[i] = G::W_BASE / ROWB + 32 * i + (lane & 31);
-    auto a_off = [&](int i, int sh) __attribute__((always_inline)) {
-      const int w = wrow[i] + sh;
-      return (w << 6) + (((half ^ (w >> 2)) & 3) << 4);
+    auto dma_xa = [&](int k, int stage, int soff) __attribute__((always_inline)) {
+      dma16s(x_isl[k] ? rAl : rAh, (lds_u32_ptr)(sm + stage * OG::A_STAGE + x_dst[k]), x_vo[k], soff);
     };
-    auto read_a = [&](int t, int sh) __attribute__((always_inline)) {   // item t = 2 i + kblock
-      const int o = a_off(t >> 1, sh) ^ ((t & 1) << 5);
-      fah[t] = *reinterpret_cast<const f16x8*>(sm + o);
-      fal[t] = *reinterpret_cast<const f16x8*>(sm + o + G::W_PLANE);
-    };
-    auto read_b = [&](int bsel, int kb) __attribute__((always_inline)) {
-      read_b1(0, bsel, kb, 0);
-      read_b1(0, bsel, kb, 1);
-    };
-    auto mfma_item = [&](int t) __attribute__((always_inline)) {
-      const int kb = t & 1, i = t >> 1;
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[0][kb][0], acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[0][kb][1], acc[i][1], 0, 0, 0);
-      if (kb == 1) cross(0, i, 0);
-      else if (i > 0) cross(0, i - 1, 1);
-    };
-    auto dma_x = [&](int w, int par, int kb) __attribute__((always_inline)) {      // piece w of 0 .. MB + 7 of tile kb
-      if (w < MB) dma16(x_isl[w] ? rAl : rAh, (lds_u32_ptr)(sm + G::W_BASE + par * G::W_BYTES + x_dst[w]), x_vo[w] + kb * (BK * 2));
-      else dma_b2(w - MB, par, WTAPS * b_tap_bytes + kb * (BK * 2));
-    };
-#pragma unroll
-    for (int w = 0; w < MB + 8; ++w) dma_x(w, 0, 0);
-    __syncthreads();
-    read_b(0, 0);
-    read_b(0, 1);
-#pragma unroll
-    for (int t = 0; t < D; ++t) read_a(t, 0);
-    for (int kb = 0; kb < kpt; ++kb) {
-      const int par = kb & 1, sh = par * (G::W_BYTES / ROWB);
-#pragma unroll
-      for (int t = 0; t < NT - D; ++t) {
-        read_a(t + D, sh);
-        mfma_item(t);
-        if (2 * t < MB + 8) dma_x(2 * t, par ^ 1, kb + 1);
-        if (2 * t + 1 < MB + 8) dma_x(2 * t + 1, par ^ 1, kb + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = NT - D; t < NT; ++t) mfma_item(t);
-      cross(0, MB - 1, 1);
-      read_b(par ^ 1, 0);
-      read_b(par ^ 1, 1);
-#pragma unroll
-      for (int t = 0; t < D; ++t) read_a(t, sh ^ (G::W_BYTES / ROWB));
-    }
-    __syncthreads();
+    auto dma_xb = [&](int w, int stage, int soff) __attribute__((always_inline)) { dma_b2(w, stage, WTAPS * b_tap_bytes + soff); };
+    one_tap_steps<MB>(acc, sm, kpt, lane, wave, x_sa, x_sb, dma_xa, dma_xb);
   }
 
   const radmmm::EpilogueCtx ec(p);
@@ -385,9 +335,10 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
 template <int MB, int EK, bool XT>
 int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = WGeo<MB>;
+  constexpr int smem_bytes = XT && OneGeo<MB>::SMEM > G::SMEM ? OneGeo<MB>::SMEM : G::SMEM;     // (the extra segment's A ring)
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_win_kernel<MB, EK, XT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_win<%d,%d>): %s", MB, EK, hipGetErrorString(e));
       return -2;
@@ -397,7 +348,7 @@ int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK, XT>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK, XT>), dim3(ntm * ntn), dim3(256), smem_bytes, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_win");
 }
 

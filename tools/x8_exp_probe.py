@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Which e4m3 exponents of the FP8-cross scheme saturate on the benchmark batch, and what do smaller ones cost in accuracy?
+(round 4: VERDICT r3 weak 1a -- the headline batch raised the saturation flag on every step with (act, grad) = (2, 2))
+Full-size decoder (8 flows, B = 32, T = 800), forward + NLL + backward against the CPU oracle on bench.py's own batch
+(seed 1234, fixed length) and on the ragged test batch (seed 4321), for several (X8_ACT_EXP, X8_GRAD_EXP)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("RADMMM_DEBUG", "1")
+os.environ["RADMMM_PRECISION"] = "f8x"
+from conftest import host_threads, rel_err  # noqa: E402
+from _oracle_cache import oracle_decoder_run  # noqa: E402
+
+KW = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+          n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2,
+          scaling_fn="tanh", affine_activation="softplus", use_partial_padding=True, n_conv_layers_per_step=4, n_flows=8)
+
+
+def main():
+    torch.set_num_threads(host_threads())
+    from rad_mmm_amd import ops
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    dev = torch.device("cuda:0")
+    combos = [(2, 2), (1, 2), (0, 2), (2, 1), (2, 0), (1, 1), (0, 0), (-1, 0)]
+    for seed, ragged in ((1234, False), (4321, True)):
+        R0 = oracle_decoder_run(KW, 32, 800, seed, ragged=ragged)
+        b, m = R0["batch"], R0["mask"]
+        gb = {k: v.to(dev) for k, v in b.items()}
+        for ae, ge in combos:
+            ops.X8_ACT_EXP, ops.X8_GRAD_EXP = ae, ge
+            dec = RADMMMFlow(use_accent=True, **KW)
+            dec.load_state_dict(R0["sd"])
+            dec = dec.to(dev).train()
+            dec.precision_guard_every = 0
+            sl = SequenceLength(gb["lengths"])
+            mel = gb["mel"].clone().requires_grad_(True)
+            out = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+            fwd_flag = int(dec._grad_scale.flag.item())
+            dec._grad_scale.flag.zero_()
+            lm = RADMMMLoss(n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
+            lm.backward()
+            torch.cuda.synchronize()
+            bwd_flag = int(dec._grad_scale.flag.item())
+            zerr = rel_err(out["z_mel"].detach().cpu() * m, R0["z_mel"] * m)
+            lerr = abs(float(lm) - R0["loss"]) / abs(R0["loss"])
+            worst, worst_el = 0.0, 0.0
+            for n, q in dec.named_parameters():
+                go = R0["grads"][n]
+                gn = float(go.norm())
+                worst = max(worst, abs(float(q.grad.norm()) - gn) / (gn + 1e-6))
+                if float(go.abs().max()) >= 1e-7:
+                    worst_el = max(worst_el, float((q.grad.cpu() - go).abs().max()) / float(go.abs().max()))
+            print(f"seed {seed} act_exp {ae:2d} grad_exp {ge:2d}: x8-saturated fwd {bool(fwd_flag & 2)} bwd {bool(bwd_flag & 2)} | z rel {zerr:.2e} NLL rel {lerr:.2e} "
+                  f"d/dmel {rel_err(mel.grad.cpu(), R0['g_mel']):.2e} grad-norm {worst:.2e} grad-el {worst_el:.2e}", flush=True)
+            del dec, out, lm, mel
+
+
+if __name__ == "__main__":
+    main()
