@@ -56,8 +56,10 @@ enum { RADMMM_SCALE_TANH = 0, RADMMM_SCALE_EXP = 1, RADMMM_SCALE_SIGMOID = 2, RA
 #define RADMMM_SPLIT_F16 0
 #define RADMMM_SPLIT_X8A 1
 #define RADMMM_SPLIT_X8B 2
-/* options of a split producer: format, exponent e of the 8-bit parts, optional saturation flag (device int, OR-ed
- * with 1 when |scale * x| > 60000 was clamped) */
+/* options of a split producer: format, exponent e of the 8-bit parts, optional saturation flag (device int, OR-ed with
+ * bit 0 when |scale * x| > 60000 was clamped; with bit 1 when an element's 8-bit parts left e4m3's range (|scale * x| *
+ * 2^e > 448: that element keeps single-product accuracy) and then also, one-hot, with bit 1 + L, L = ceil(log2(|scale * x|
+ * * 2^e / 448)) clamped to 1 .. 6: by how many powers of two e was too large) */
 typedef struct { int fmt; int x8_exp; int32_t* sat_flag;
                  void* lo16; /* optional, 8-bit formats only: the fp16 lo part fp16(s*x - hi) as well, same pitch as the hi
                                 array (radmmm_wn_input_fwd, radmmm_dact_mul_transposed): feeds radmmm_wgrad_rm */
@@ -116,7 +118,7 @@ typedef struct {
   void* C2h; void* C2l; int ldc2h; float c2h_scale;
   /* split format of Ch/Cl and C2h/C2l (RADMMM_SPLIT_*, see "split formats" below) and the exponents of their 8-bit parts */
   int split_fmt; int ch_x8_exp; int c2h_x8_exp;
-  int32_t* sat_flag;     /* optional device int: OR-ed with 1 when a split output exceeded the fp16 range (was clamped) */
+  int32_t* sat_flag;     /* optional device int: saturation report of the split outputs, bits as in radmmm_split_opts.sat_flag */
   void* Clo;             /* optional, with Ch and an 8-bit split_fmt: [M][ldch] halves, the fp16 lo part fp16(ch_scale*v - Ch)
                             as well (the row-major pair Ch / Clo is what radmmm_wgrad_rm contracts) */
   /* optional (radmmm_rowgemm_h3 only): colsum_out[n] = sum over the rows r inside their utterance's length (all rows when

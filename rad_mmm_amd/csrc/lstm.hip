@@ -138,10 +138,24 @@ __global__ void lstm_pack_wt_kernel(const float* __restrict__ W, _Float16* __res
 //             i.e. after every reader of step s is done with it (data dependence; no fence needed).
 // Per step the chain is now: store (write-through) -> visible -> the consumer's outstanding load returns.
 // All workgroups of the grid must be resident at once: the host only takes this path when the grid has at most one
-// workgroup per CU.  A wait that does not complete within ~seconds traps (a loud launch failure) instead of hanging.
+// workgroup per CU slot it may use (use_persistent below) and launches it cooperatively (the runtime checks the grid against
+// the device; a refused launch falls back to one launch per step).  Workgroups that other kernels (RCCL channels, another
+// stream) keep waiting for a CU only DELAY their consumers: a waiting wave polls fast at first, then sleeps between polls,
+// and traps -- a loud launch failure instead of a hung GPU -- only after a minute without progress.
 constexpr int AUX_SC1 = 16;      // cache-policy bit of the raw buffer builtins: sc1 (agent scope) on gfx94x/gfx950
 constexpr unsigned FILL = 0xffffffffu;
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr unsigned SPIN_FAST = 512;                       // polls before the wave starts to sleep between them
+constexpr unsigned long long SPIN_TIMEOUT = 60ull * 100000000ull;   // wall_clock64 ticks (100 MHz): one minute
+// one failed poll: back off, and trap when nothing has arrived for SPIN_TIMEOUT (t0 = first slow poll of this wait)
+__device__ __forceinline__ void spin_wait(unsigned& spins, unsigned long long& t0) {
+  if (++spins < SPIN_FAST) return;
+  __builtin_amdgcn_s_sleep(16);                          // ~1000 cycles: the fabric carries the producers' stores, not polls
+  if ((spins & 255u) == 0) {
+    const unsigned long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    else if (now - t0 > SPIN_TIMEOUT) __builtin_trap();
+  }
+}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned is_fill(const f16x8& f) {
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const LstmArgs a, const i
                                                              : ((d * 2 + (s & 1)) * nbz + bz) * nkb * 1024);
     f16x8 ah[KPW], al[KPW];
     unsigned spins = 0;
+    unsigned long long spin_t0 = 0;
     if (PERSIST && s > 0 && a.probe) {
       // a waiting wave repeats ONE 4-byte load (the first word of its last k block) instead of its 18 KiB of fragments: the
       // full loads, which every word still has to pass, then mostly succeed at once and the fabric carries the producers'
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const LstmArgs a, const i
         const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rl, kl * 1024, hbase, AUX_SC1);
         asm volatile("" ::: "memory");
         if ((unsigned)__builtin_amdgcn_readfirstlane((int)w) != FILL) break;
-        if (++spins > SPIN_LIMIT) __builtin_trap();
+        spin_wait(spins, spin_t0);
       }
     }
     for (;;) {
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const LstmArgs a, const i
       for (int i = 0; i < KPW; ++i) pending |= is_fill(ah[i]) | is_fill(al[i]);
       asm volatile("" ::: "memory");                             // the loads are repeated, not hoisted
       if (!__builtin_amdgcn_ballot_w64(pending != 0)) break;     // every word of this wave's fragments has been written
-      if (++spins > SPIN_LIMIT) __builtin_trap();
+      spin_wait(spins, spin_t0);
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -381,13 +396,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmArgs a, const i
       const bool odd = (s + 1) & 1;
       const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
       unsigned spins = 0;
+      unsigned long long spin_t0 = 0;
       if (PERSIST && s > 0 && a.probe) {                        // (as in the forward kernel: one word of the last producer's block)
         const __amdgpu_buffer_rsrc_t rc = odd ? rc1 : rc0;
         for (;;) {
           const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rc, (NS - 1) * 1024, 0, AUX_SC1);
           asm volatile("" ::: "memory");
           if ((((unsigned)__builtin_amdgcn_readfirstlane((int)w)) ^ tag) & 1u) {
-            if (++spins > SPIN_LIMIT) __builtin_trap();
+            spin_wait(spins, spin_t0);
             continue;
           }
           break;
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmArgs a, const i
         }
         asm volatile("" ::: "memory");                           // the loads are repeated, not hoisted
         if (!__builtin_amdgcn_ballot_w64((pending & 1u) != 0)) break;
-        if (++spins > SPIN_LIMIT) __builtin_trap();
+        spin_wait(spins, spin_t0);
       }
       if (PERSIST) {
 #pragma unroll
@@ -502,33 +518,48 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmArgs a, const i
 }
 
 // One launch for all time steps (the workgroups exchange h / the partial gradients through memory, see above) when every
-// workgroup of the grid can be resident at once (at most one per CU); otherwise, or with RADMMM_LSTM_PERSISTENT=0 under
-// RADMMM_DEBUG, one launch per step.  Measured on MI355X (B = 32, H = 524, T' = 400): see DESIGN.md §4.10.
+// workgroup of the grid can be resident at once: at most one per CU slot this process sizes its grids for (the device's
+// CUs, or RADMMM_GEMM_CUS when a data-parallel run leaves CUs to RCCL's channel kernels, rowgemm_h3w.hip).  Otherwise, or
+// with RADMMM_LSTM_PERSISTENT=0 (a supported switch, read per call), one launch per step.  The launch itself is
+// cooperative (launch_coop): the runtime refuses a grid that cannot be co-resident, and the caller falls back.
+}  // namespace
+namespace radmmm { int gemm_cu_slots(); }
+namespace {
 bool use_persistent(const dim3& grid) {
-  const char* e = radmmm::debug_env("RADMMM_LSTM_PERSISTENT");     // (read per call: the tests flip it)
+  const char* e = getenv("RADMMM_LSTM_PERSISTENT");
   if (e && atoi(e) == 0) return false;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return false;
-  return (long long)grid.x * grid.y * grid.z <= cus;
+  return (long long)grid.x * grid.y * grid.z <= radmmm::gemm_cu_slots();
+}
+template <class K>
+hipError_t launch_coop(K kernel, const dim3& grid, hipStream_t st, LstmArgs a, int s) {
+  void* args[] = {&a, &s};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, dim3(256), args, 0, st);
+  if (e != hipSuccess) (void)hipGetLastError();           // (cleared: the caller falls back to one launch per step)
+  return e;
 }
 
 // size classes: H <= 192 / 384 / 576 / 768 -> (k blocks per wave, producer-slice capacity, output tiles per wave)
-template <bool PERSIST>
-void launch_fwd(const LstmArgs& a, const dim3& grid, hipStream_t st, int s) {
-  if (a.H <= 192) hipLaunchKernelGGL((lstm_fwd_kernel<PERSIST, 3>), grid, dim3(256), 0, st, a, s);
-  else if (a.H <= 384) hipLaunchKernelGGL((lstm_fwd_kernel<PERSIST, 6>), grid, dim3(256), 0, st, a, s);
-  else if (a.H <= 576) hipLaunchKernelGGL((lstm_fwd_kernel<PERSIST, 9>), grid, dim3(256), 0, st, a, s);
-  else hipLaunchKernelGGL((lstm_fwd_kernel<PERSIST, 12>), grid, dim3(256), 0, st, a, s);
+template <bool PERSIST, class K>
+hipError_t launch_one(K kernel, const LstmArgs& a, const dim3& grid, hipStream_t st, int s) {
+  if constexpr (PERSIST) return launch_coop(kernel, grid, st, a, s);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a, s);
+  return hipSuccess;
 }
 template <bool PERSIST>
-void launch_bwd(const LstmArgs& a, const dim3& grid, hipStream_t st, int s) {
-  if (a.H <= 192) hipLaunchKernelGGL((lstm_bwd_kernel<PERSIST, 24, 2>), grid, dim3(256), 0, st, a, s);
-  else if (a.H <= 384) hipLaunchKernelGGL((lstm_bwd_kernel<PERSIST, 48, 3>), grid, dim3(256), 0, st, a, s);
-  else if (a.H <= 576) hipLaunchKernelGGL((lstm_bwd_kernel<PERSIST, 72, 5>), grid, dim3(256), 0, st, a, s);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<PERSIST, 96, 6>), grid, dim3(256), 0, st, a, s);
+hipError_t launch_fwd(const LstmArgs& a, const dim3& grid, hipStream_t st, int s) {
+  if (a.H <= 192) return launch_one<PERSIST>(lstm_fwd_kernel<PERSIST, 3>, a, grid, st, s);
+  if (a.H <= 384) return launch_one<PERSIST>(lstm_fwd_kernel<PERSIST, 6>, a, grid, st, s);
+  if (a.H <= 576) return launch_one<PERSIST>(lstm_fwd_kernel<PERSIST, 9>, a, grid, st, s);
+  return launch_one<PERSIST>(lstm_fwd_kernel<PERSIST, 12>, a, grid, st, s);
 }
+template <bool PERSIST>
+hipError_t launch_bwd(const LstmArgs& a, const dim3& grid, hipStream_t st, int s) {
+  if (a.H <= 192) return launch_one<PERSIST>(lstm_bwd_kernel<PERSIST, 24, 2>, a, grid, st, s);
+  if (a.H <= 384) return launch_one<PERSIST>(lstm_bwd_kernel<PERSIST, 48, 3>, a, grid, st, s);
+  if (a.H <= 576) return launch_one<PERSIST>(lstm_bwd_kernel<PERSIST, 72, 5>, a, grid, st, s);
+  return launch_one<PERSIST>(lstm_bwd_kernel<PERSIST, 96, 6>, a, grid, st, s);
+}
+
 
 // LstmArgs.probe per direction of the pass: bit 0 forward, bit 1 backward.  Measured (tools/lstm_bench.py, B = 32, T' = 400,
 // H = 524): the forward recurrence gains 5 % (2.20 -> 2.09 ms incl. projection), the backward one loses 2 %: default 1.
@@ -607,10 +638,11 @@ extern "C" int radmmm_lstm_fwd(float* G, const float* W_hh, float* y, float* c, 
       radmmm::set_error("lstm_fwd: hipMemsetAsync failed");
       return -2;
     }
-    launch_fwd<true>(a, grid, st, 0);
-  } else {
-    for (int s = 0; s < T; ++s) launch_fwd<false>(a, grid, st, s);
+    if (launch_fwd<true>(a, grid, st, 0) == hipSuccess) return radmmm::check_launch("lstm_fwd");
+    // the cooperative launch was refused (the grid cannot be co-resident right now): per-step launches on the ping-pong
+    // operand buffers (hsplit, zeroed above)
   }
+  for (int s = 0; s < T; ++s) launch_fwd<false>(a, grid, st, s);
   return radmmm::check_launch("lstm_fwd");
 }
 
@@ -641,9 +673,8 @@ extern "C" int radmmm_lstm_bwd(float* G, const float* c, const float* dy, const 
       radmmm::set_error("lstm_bwd: hipMemsetAsync failed");
       return -2;
     }
-    launch_bwd<true>(a, grid, st, 0);
-  } else {
-    for (int s = 0; s < T; ++s) launch_bwd<false>(a, grid, st, s);
+    if (launch_bwd<true>(a, grid, st, 0) == hipSuccess) return radmmm::check_launch("lstm_bwd");
   }
+  for (int s = 0; s < T; ++s) launch_bwd<false>(a, grid, st, s);
   return radmmm::check_launch("lstm_bwd");
 }

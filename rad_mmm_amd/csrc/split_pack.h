@@ -80,15 +80,26 @@ __device__ __forceinline__ float store_split1_fmt(void* hi_, void* lo_, long lon
 // Raise the saturation flag word from this lane's max |scale * x|: bit 0 when the fp16 clamp changed a value
 // (> 60000); bit 1 when the tensor was written in an 8-bit cross format (x8_mul = 2^e > 0) and an element's 8-bit parts
 // left e4m3's range (|scale * x| * 2^e > 448: both its hi8 and, bounded by the same product, its lo8 part clamp) -- that
-// element then carries no cross-term correction, i.e. single-fp16-product accuracy.
+// element then carries no cross-term correction, i.e. single-fp16-product accuracy -- and, one-hot, bit 1 + L for
+// L = ceil(log2(|scale * x| * 2^e / 448)) in 1 .. 6: by how many powers of two the exponent was too large (the host lowers
+// the tensor class's exponent by the highest L it sees, rad_mmm_amd/ops.py GradScale).
 __device__ __forceinline__ void raise_sat_flag(int* flag, float amax, float x8_mul = 0.f) {
   if (!flag) return;
   // one atomic per wave at most, and none when the bits are already set (when a tensor saturates, most lanes see it: a
   // per-lane atomicOr on one address serialises -- measured 13 -> 66 us for a 50 MB split pass)
-  const bool b0 = amax > 60000.f, b1 = x8_mul > 0.f && amax * x8_mul > 448.f;
+  const float r8 = x8_mul > 0.f ? amax * x8_mul * (1.f / 448.f) : 0.f;
+  const bool b0 = amax > 60000.f, b1 = r8 > 1.f;
   const unsigned long long m0 = __ballot(b0), m1 = __ballot(b1);
-  const int bits = (m0 ? 1 : 0) | (m1 ? 2 : 0);
-  if (bits && (threadIdx.x & 63) == (unsigned)__ffsll((long long)(m0 | m1)) - 1 && (__atomic_load_n(flag, __ATOMIC_RELAXED) & bits) != bits)
+  if (!(m0 | m1)) return;
+  int bits = (m0 ? 1 : 0) | (m1 ? 2 : 0);
+  if (m1) {
+    int lvl = 1;                                                   // highest level among the wave's lanes
+#pragma unroll
+    for (int l = 1; l < 6; ++l)
+      if (__ballot(r8 > (float)(1 << l))) lvl = l + 1;
+    bits |= 2 << lvl;
+  }
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)(m0 | m1)) - 1 && (__atomic_load_n(flag, __ATOMIC_RELAXED) & bits) != bits)
     atomicOr(flag, bits);
 }
 

@@ -126,6 +126,13 @@ class BucketedGradReducer:
         def hook(param):
             view = self._views[id(param)]
             if param.grad is not view and param.grad.data_ptr() != view.data_ptr():
+                if id(param) in self._early and self.active:
+                    # declared final (its bucket's all-reduce may already be running on this flat buffer), yet autograd did
+                    # not adopt the sink view (create_graph, an extra reference to the gradient, ...): copying now would
+                    # write pre-reduction data under the collective
+                    raise RuntimeError("BucketedGradReducer: the gradient of a parameter that was announced final "
+                                       "(early bucket start) did not land in its sink -- backward with create_graph / "
+                                       "retained gradient references is not supported with a process group active")
                 view.copy_(param.grad)               # the node did not use the sink (or autograd cloned): one copy
                 param.grad = view
             if id(param) in self._early:         # counted when its node declared it final (ops.notify_grads_final)

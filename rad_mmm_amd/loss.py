@@ -41,29 +41,37 @@ class AttentionCTCLoss(nn.Module):
     goes through ONE F.ctc_loss call: text positions beyond an utterance's length are taken out of its softmax with a
     -1e4 logit (exp underflows to exactly 0 in fp32, so every remaining value is the per-utterance softmax's; a literal
     -inf would turn torch's CTC gradient, exp(lp) - exp(alpha*beta - lp), into NaN at those positions), frames beyond its
-    mel length are ignored through input_lengths.  Same values as the loop (tests/golden/tts_step.npz), no host sync."""
+    mel length are ignored through input_lengths.  Same values as the loop (tests/golden/tts_step.npz).  Host
+    synchronisation: F.ctc_loss copies DEVICE length tensors to the CPU itself (two blocking reads per call); pass the host
+    copies the step already holds (`in_lens_host` / `out_lens_host`: SequenceLength.lengths_host) and the call makes none.
+    The -1e4 mask assumes every real logit lies well above -1e4 + 88 (the attention's log-probabilities are >= ~-1e3)."""
 
     def __init__(self, blank_logprob=-1):
         super().__init__()
         self.blank_logprob = blank_logprob
 
-    def forward(self, attn_logprob, in_lens, out_lens):
+    def forward(self, attn_logprob, in_lens, out_lens, in_lens_host=None, out_lens_host=None):
         padded = F.pad(attn_logprob, (1, 0), value=self.blank_logprob)[:, 0]          # [B, T_mel, 1 + T_txt]
         B, _, C = padded.shape
         cls = torch.arange(C, device=padded.device)
         lp = padded.masked_fill(cls[None, None, :] > in_lens[:, None, None], -1e4)
         lp = torch.log_softmax(lp, -1).transpose(0, 1)                               # [T_mel, B, C]
         targets = cls[1:][None].expand(B, -1)                                        # 1 .. T_txt; the first len count
-        loss = F.ctc_loss(lp, targets, out_lens, in_lens, blank=0, reduction="none", zero_infinity=True)
+        loss = F.ctc_loss(lp, targets, out_lens if out_lens_host is None else out_lens_host,
+                          in_lens if in_lens_host is None else in_lens_host, blank=0, reduction="none", zero_infinity=True)
         return (loss / in_lens.clamp_min(1).to(loss.dtype)).sum() / B
 
 
 class AttentionBinarizationLoss(nn.Module):
-    """loss.py:143-151."""
+    """loss.py:143-151: binary cross entropy (target 1, mean) of the soft attention at the positions the hard alignment
+    selects.  The reference gathers them with a boolean mask (`soft[hard == 1]`: a device -> host read of the count); the
+    same mean as a masked sum -- -sum(hard * max(log soft, -100)) / sum(hard), torch's BCE clamps its log at -100 -- needs
+    none (hard is exactly 0 / 1)."""
 
     def forward(self, hard_attention, soft_attention):
-        sel = soft_attention[hard_attention == 1]
-        return F.binary_cross_entropy(sel, torch.ones_like(sel), reduction="mean")
+        sel = (hard_attention == 1).to(soft_attention.dtype)
+        logp = torch.log(soft_attention).clamp_min(-100.0)
+        return -(sel * logp).sum() / sel.sum()
 
 
 class AttentionLoss(nn.Module):
@@ -78,8 +86,9 @@ class AttentionLoss(nn.Module):
         self.binarization_loss_weight = binarization_loss_weight
         self.ctc_loss_weight = ctc_loss_weight
 
-    def forward(self, attn, attn_soft, attn_logprob, global_step, in_lens, out_lens):
-        loss_dict = {"loss_ctc": (self.attn_ctc_loss(attn_logprob, in_lens, out_lens), self.ctc_loss_weight)}
+    def forward(self, attn, attn_soft, attn_logprob, global_step, in_lens, out_lens, in_lens_host=None, out_lens_host=None):
+        loss_dict = {"loss_ctc": (self.attn_ctc_loss(attn_logprob, in_lens, out_lens, in_lens_host, out_lens_host),
+                                  self.ctc_loss_weight)}
         if global_step > self.kl_loss_start_iter:
             loss_dict["binarization_loss"] = (self.attn_bin_loss(attn, attn_soft), self.binarization_loss_weight)
         else:
@@ -115,7 +124,8 @@ class RADTTSLoss(nn.Module):
         if "attn_logprob" in model_output:
             loss_dict.update(self.attn_loss(model_output["attn"], model_output["attn_soft"],
                                             model_output["attn_logprob"], global_step, in_lens.lengths,
-                                            out_lens.lengths))
+                                            out_lens.lengths, getattr(in_lens, "lengths_host", None),
+                                            getattr(out_lens, "lengths_host", None)))
         return loss_dict
 
 

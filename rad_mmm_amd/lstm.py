@@ -97,7 +97,7 @@ class BiLSTMFn(torch.autograd.Function):
             from . import ops
             box = ctx.box
             SG = ops.grad_scale(box, dy2)
-            flag = ops.sat_flag_of(box)
+            flag = ops.sat_flag_bwd_of(box)
             gh, gl = ops.split_f16(dG, 8 * H, SG, 8 * H, 3, 0, flag)       # row-major split pair of dG: operand of all four GEMMs
             if (xpair is not None and T >= 32 and B <= 1024 and (4 * H) % 8 == 0 and
                     debug_env("RADMMM_WGRAD_RM", "1") != "0"):

@@ -651,13 +651,18 @@ def _halves(*shape, like, zero=False):
     return f(*shape, device=like.device, dtype=torch.float16), f(*shape, device=like.device, dtype=torch.float16)
 
 
-# 8-bit parts of the "FP8 cross terms" scheme (nprod = 2) are written as value * 2^e: activations
-# (softplus outputs, typically 0.01 .. 10) x4, gradients (scaled so that the FIRST backward node's amax is 8 .. 16) x4,
-# weights (x256 already, |w| <= ~1) x1.  e4m3 saturates at 448 and flushes below 2^-9: the gradient exponent was 4 in round
-# 2 (x16: headroom 1.75-3.5x above the first node's amax -- the gradients of the WN outputs, |z|-times larger, saturated in
-# every step of the benchmark; the device flag's bit 1 now reports it) and is 2 now: 7-14x of headroom, and elements below
-# amax / 4000 (instead of / 16000) round to e4m3 subnormals -- their cross terms are 2^-11 of an already negligible product
-X8_ACT_EXP, X8_GRAD_EXP, X8_W_EXP = 2, 2, 0
+# 8-bit parts of the "FP8 cross terms" scheme (nprod = 2) are written as value * 2^e.  e4m3 saturates at
+# 448 and flushes below 2^-9; a saturated element loses its cross-term correction (single-product accuracy, ~5e-4), an
+# element far below the range merely has cross terms that are 2^-11 of an already negligible product.
+#   activations (softplus outputs, typically 0.01 .. 10): x4 -- never seen to saturate (> 112);
+#   weights (x256 already, |w| <= ~1): x1;
+#   gradients, scaled by S so that the FIRST backward node's amax is 8 .. 16: the gradients INSIDE the WN are up to ~200x
+#     that amax (measured on the benchmark batch, tools/x8_exp_probe.py, profiles/r04_x8_exp_probe.txt: saturation reports
+#     stop at e = -3; accuracy is flat from e = 0 down to -6: worst elementwise gradient error 6.2e-5, against 2.2e-4 at
+#     round 3's e = 2, which saturated on every step).  X8_GRAD_EXP is the STARTING value: GradScale lowers a decoder's
+#     exponent by the level the device flag reports whenever a pass saturates (it never needs to come back up).
+X8_ACT_EXP, X8_GRAD_EXP, X8_W_EXP = 2, -4, 0
+X8_GRAD_EXP_MIN = -16
 
 
 def fmt_a(nprod: int) -> int:
@@ -830,24 +835,32 @@ def wgrad_rm8_slabs(gy_pair, g8_exp, x_pair, x8_exp, B, T, Mc, Nc, taps, dil, ac
 
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
-    a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), a device-side
-    flag word OR-ed by every split producer (bit 0: an element exceeded the fp16 range and was clamped; bit 1: an element's
-    8-bit cross-term parts exceeded e4m3's 448 -- that element keeps single-fp16-product accuracy, ~5e-4, instead of the
-    scheme's 4e-5), and the bookkeeping that keeps both off the host's critical path.
+    a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), the exponent of
+    the gradients' 8-bit cross-term parts (`x8_grad_exp`), two device flag words OR-ed by the split producers of the
+    forward (flag[0]) and of the backward (flag[1]) -- bit 0: an element exceeded the fp16 range and was clamped; bit 1: an
+    element's 8-bit cross-term parts exceeded e4m3's 448 (that element keeps single-fp16-product accuracy, ~5e-4, instead
+    of the scheme's 4e-5); bits 2..7, one-hot: by how many powers of two (include/radmmm_hip.h) -- and the bookkeeping that
+    keeps all of it off the host's critical path.
 
     Steady state has NO host synchronisation: the first backward node of pass k queues `amax(|g|)` of its incoming
-    gradient; the next forward queues an asynchronous copy of (amax, flag) to pinned memory behind an event and clears the
-    flag; the first backward node of a later pass polls that event (query, never wait) and adopts the new S.  Only the very
-    first pass of a module synchronises once.
+    gradient; the next forward queues an asynchronous copy of (amax, flags) to pinned memory behind an event and clears the
+    flags; the first backward node of a later pass polls that event (query, never wait) and adopts the new S and, when the
+    backward's 8-bit parts saturated, an exponent lowered by the reported level (`x8_adaptations` counts them; the
+    exponent of a pass is fixed when its first node asks for the scale, so producers and consumers of a pass agree).  Only
+    the very first pass of a module synchronises once.
 
     What happens to a pass that clamped (`reports`, counters `saturated_passes` / `x8_saturated_passes` /
     `nonfinite_passes`):
       * default: one RuntimeWarning per process and kind, the scale is refreshed, training goes on (a raise one step
         later would kill an AMP loop that is about to skip the step anyway, and under DDP only the affected rank would
-        raise and the others hang in the next collective);
-      * RADMMM_CHECK_SATURATION=1 (or strict=True): FloatingPointError -- synchronously after every flow step
-        (`check()`), and for the deferred report after the flag has been MAX-all-reduced when a process group is active,
-        so every rank raises together.
+        raise and the others hang in the next collective).  A gradient pass whose 8-bit parts saturated is counted, the
+        exponent adapts, and the warning is kept for the cases adaptation cannot fix: the forward's activations (fixed
+        exponent) or a gradient exponent already at its floor;
+      * RADMMM_CHECK_SATURATION=1 (or strict=True): FloatingPointError for the fp16 clamp -- synchronously after every flow
+        step (`check()`), and for the deferred report.  With a process group active every decision is rank-independent:
+        the flags are OR-all-reduced before they are looked at (in `check()`, and in every training forward, which then
+        waits for the previous copy instead of polling it), so every rank raises together and the collective sequence is
+        the same on all ranks.
     Non-finite incoming gradients (an fp16-AMP GradScaler overflow step): the split producers clamp NaN / Inf to finite
     values, so the pass's amax is tracked with NaN propagation and `poison` (device fp32[1] = amax * 0: 0, or NaN) is
     added to every weight-norm gain gradient of the pass (radmmm_weightnorm_bwd): GradScaler / clip_grad_norm_ see the
@@ -855,18 +868,21 @@ class GradScale:
 
     def __init__(self, strict: Optional[bool] = None):
         self.S = None
-        self.flag = None          # device int32[1]
+        self.flags = None         # device int32[2]: forward / backward producers
         self.amax = None          # device fp32[1]
         self.poison = None        # device fp32[1]: 0, or NaN when this pass's incoming gradient is not finite
-        self._host = None         # pinned fp32[2]: amax, flag
+        self._host = None         # pinned fp32[3]: amax, forward flags, backward flags
         self._event = None
         self._pending = False
+        self._pending_exp = None  # gradient exponent the pass whose flags are in flight ran with
         self._fwd_id = 0
         self._bwd_id = -1
         self._stats_fwd = -1      # forward id whose backward produced the device stats
         self.strict = strict
+        self.x8_grad_exp = X8_GRAD_EXP
         self.saturated_passes = 0
         self.x8_saturated_passes = 0
+        self.x8_adaptations = 0
         self.nonfinite_passes = 0
 
     _warned = set()
@@ -890,12 +906,21 @@ class GradScale:
         assert k == "S"
         self.S = v
 
+    @property
+    def flag(self):
+        """forward producers' flag word (device int32[1] view)"""
+        return None if self.flags is None else self.flags[0:1]
+
+    @property
+    def flag_bwd(self):
+        return None if self.flags is None else self.flags[1:2]
+
     def _ensure(self, dev):
-        if self.flag is None or self.flag.device != dev:
-            self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        if self.flags is None or self.flags.device != dev:
+            self.flags = torch.zeros(2, device=dev, dtype=torch.int32)
             self.amax = torch.zeros(1, device=dev, dtype=torch.float32)
             self.poison = torch.zeros(1, device=dev, dtype=torch.float32)
-            self._host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._host = torch.zeros(3, dtype=torch.float32).pin_memory()
             self._event = torch.cuda.Event()
             self._pending = False
 
@@ -903,10 +928,20 @@ class GradScale:
         return self.strict if self.strict is not None else os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1"
 
     @staticmethod
+    def _distributed() -> bool:
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    @staticmethod
     def _pow2(amax: float) -> float:
         if not (amax > 0 and math.isfinite(amax)):
             return 1.0
         return float(2.0 ** max(-40, min(40, math.floor(math.log2(16.0 / amax)))))
+
+    @staticmethod
+    def _x8_level(flag: int) -> int:
+        """highest saturation level (1 .. 6) in a flag word, 0 when its 8-bit parts stayed in range"""
+        lv = (flag >> 2) & 0x3f
+        return lv.bit_length() if (flag & 2) else 0
 
     def _report(self, kind: str, msg: str):
         if self._is_strict() and kind == "f16":             # (the e4m3 saturation is a soft loss of accuracy: never an error)
@@ -916,10 +951,30 @@ class GradScale:
             import warnings
             warnings.warn(msg + "  (reported once per process; RADMMM_CHECK_SATURATION=1 turns it into an error)", RuntimeWarning)
 
+    def _account_x8(self, f_fwd: int, f_bwd: int, ran_with_exp):
+        """8-bit saturation of a finished pass: count it, lower the gradient exponent by the reported level, warn about what
+        adaptation cannot fix"""
+        lv_f, lv_b = self._x8_level(f_fwd), self._x8_level(f_bwd)
+        if not (lv_f or lv_b):
+            return
+        self.x8_saturated_passes += 1
+        if lv_b and ran_with_exp is not None:
+            new = max(X8_GRAD_EXP_MIN, min(self.x8_grad_exp, ran_with_exp - lv_b))
+            if new != self.x8_grad_exp:
+                self.x8_grad_exp = new
+                self.x8_adaptations += 1
+        if lv_f or (lv_b and (ran_with_exp is None or ran_with_exp <= X8_GRAD_EXP_MIN)):
+            self._report("x8", "FP8 cross terms saturated in an earlier pass: split-operand elements beyond e4m3's range ("
+                               + ("activations above ~%g" % (448.0 / 2.0 ** X8_ACT_EXP) if lv_f else
+                                  "gradient elements with the exponent at its floor") +
+                               ") lost their cross-term correction (single-fp16-product accuracy, ~5e-4, for those elements); "
+                               "RADMMM_PRECISION=h3 has no such limit")
+
     def _consume(self):
         """host copy is complete: adopt the scale, report what the producers flagged in that earlier pass"""
         self._pending = False
-        amax, flag = float(self._host[0]), int(self._host[1])
+        amax, f_fwd, f_bwd = float(self._host[0]), int(self._host[1]), int(self._host[2])
+        ran_with, self._pending_exp = self._pending_exp, None
         if not math.isfinite(amax):
             # non-finite upstream gradient (AMP overflow step): that pass was poisoned (see the class docstring); keep S,
             # and do not report the clamping the NaN / Inf values caused
@@ -929,12 +984,8 @@ class GradScale:
             return
         if amax > 0:
             self.S = self._pow2(amax)
-        if flag & 2:
-            self.x8_saturated_passes += 1
-            self._report("x8", "FP8 cross terms saturated in an earlier pass: split-operand elements beyond e4m3's range (activations "
-                               "above ~112, gradient elements above ~2-3x the first gradient's maximum) lost their cross-term correction (single-fp16-product accuracy, ~5e-4, for "
-                               "those elements); RADMMM_PRECISION=h3 has no such limit")
-        if flag & 1:
+        self._account_x8(f_fwd, f_bwd, ran_with)
+        if (f_fwd | f_bwd) & 1:
             self.saturated_passes += 1
             self._report("f16", "split-f16 gradient saturated in an earlier backward pass: a gradient element exceeded 2^12 x the "
                                 "first gradient's maximum and was clamped (that pass's gradients are not exact; the scale has been "
@@ -943,47 +994,63 @@ class GradScale:
     def new_forward(self, dev):
         """called by the owning module at the start of a training forward"""
         self._ensure(dev)
-        if self._pending and self._event.query():
+        sync_ranks = self._is_strict() and self._distributed()
+        if self._pending and (sync_ranks or self._event.query()):
+            if sync_ranks:
+                self._event.synchronize()                   # rank-independent: never decide on a rank-local poll
             self._consume()
         if self._stats_fwd == self._fwd_id and not self._pending:
-            # publish the stats of the backward that followed the previous forward, then re-arm the flag
-            flagf = self.flag.float()
-            if self._is_strict() and torch.distributed.is_available() and torch.distributed.is_initialized():
-                torch.distributed.all_reduce(flagf, op=torch.distributed.ReduceOp.MAX)      # every rank raises together
+            # publish the stats of the backward that followed the previous forward, then re-arm the flags
+            fl = self.flags
+            if sync_ranks:
+                fl = self.flags.clone()
+                torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.BOR)          # every rank raises together
             self._host[0:1].copy_(self.amax, non_blocking=True)
-            self._host[1:2].copy_(flagf, non_blocking=True)
+            self._host[1:3].copy_(fl.float(), non_blocking=True)
             self._event.record()
-            self.flag.zero_()
+            self.flags.zero_()
             self._pending = True
+            self._pending_exp = self._bwd_exp
         self._fwd_id += 1
+
+    _bwd_exp = None               # gradient exponent of the most recent backward pass
 
     def scale(self, g: torch.Tensor) -> float:
         """S for this backward pass; the first node of the pass (re)initialises the pass"""
         self._ensure(g.device)
         if self._bwd_id != self._fwd_id:
             self._bwd_id = self._fwd_id
-            if self._pending and self._event.query():
+            if self._pending and not (self._is_strict() and self._distributed()) and self._event.query():
                 self._consume()
             if self.S is None:                              # first pass of this module: one synchronisation
                 self.S = self._pow2(float(g.abs().max()))
             torch.amax(g.detach().abs().reshape(-1), dim=0, keepdim=True, out=self.amax)     # (propagates NaN)
             torch.mul(self.amax, 0.0, out=self.poison)                                     # 0, or NaN for Inf / NaN
             self._stats_fwd = self._fwd_id
+            self._bwd_exp = self.x8_grad_exp                # fixed for the whole pass: producers and consumers agree
         return self.S
 
+    def grad_exp(self) -> int:
+        """exponent of the 8-bit cross-term parts of THIS backward pass's gradient tensors (valid after scale())"""
+        return self._bwd_exp if self._bwd_exp is not None else self.x8_grad_exp
+
     def check(self) -> None:
-        """synchronous: raise FloatingPointError if a split producer has clamped since the flag was last cleared (fp16
-        range; the softer e4m3 saturation of the cross terms is counted and warned about, see `reports`)"""
+        """synchronous: raise FloatingPointError if a split producer has clamped since the flags were last cleared (fp16
+        range; the softer e4m3 saturation of the cross terms is counted, adapts the gradient exponent and is warned about,
+        see `reports`).  With a process group active the flags are OR-all-reduced first: every rank raises together."""
         if self._pending:
             self._event.synchronize()
             self._consume()
-        if self.flag is not None:
-            f = int(self.flag.item())
-            if f:
-                self.flag.zero_()
-            if f & 2:
-                self.x8_saturated_passes += 1
-            if f & 1:
+        if self.flags is not None:
+            fl = self.flags
+            if self._distributed():
+                fl = self.flags.clone()
+                torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.BOR)
+            f_fwd, f_bwd = (int(v) for v in fl.tolist())
+            if f_fwd | f_bwd:
+                self.flags.zero_()
+            self._account_x8(f_fwd, f_bwd, self._bwd_exp)
+            if (f_fwd | f_bwd) & 1:
                 raise FloatingPointError("split-f16 gradient saturated: a gradient element exceeds 2^12 x the first gradient's "
                                          "maximum of this backward pass and was clamped")
 
@@ -999,7 +1066,18 @@ def grad_scale(box, g: torch.Tensor) -> float:
 
 
 def sat_flag_of(box) -> Optional[torch.Tensor]:
+    """flag word of the FORWARD's split producers"""
     return box.flag if isinstance(box, GradScale) else None
+
+
+def sat_flag_bwd_of(box) -> Optional[torch.Tensor]:
+    """flag word of the BACKWARD's split producers (its 8-bit saturation level drives the gradient exponent)"""
+    return box.flag_bwd if isinstance(box, GradScale) else None
+
+
+def grad_x8_exp(box) -> int:
+    """exponent of the gradients' 8-bit cross-term parts for the backward pass in progress (call after grad_scale)"""
+    return box.grad_exp() if isinstance(box, GradScale) else X8_GRAD_EXP
 
 
 def poison_of(box) -> Optional[torch.Tensor]:
@@ -1150,15 +1228,16 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
 
         def wg_rm(gpair, xpair_, Mc_, Nc_, taps_, dil_, lens_=None):
             if rm8:
-                return wgrad_rm8_slabs(gpair, X8_GRAD_EXP, xpair_, X8_ACT_EXP, B, T, Mc_, Nc_, taps_, dil_, 1.0 / SG, lens_)
+                return wgrad_rm8_slabs(gpair, GE, xpair_, X8_ACT_EXP, B, T, Mc_, Nc_, taps_, dil_, 1.0 / SG, lens_)
             return wgrad_rm_slabs(gpair, xpair_, B, T, Mc_, Nc_, taps_, dil_, 1.0 / SG, lens_)
         SG = grad_scale(box, g_zout)
-        flag = sat_flag_of(box)
+        GE = grad_x8_exp(box)                      # exponent of this pass's 8-bit gradient parts (adapts to saturation reports)
+        flag = sat_flag_bwd_of(box)
         poison = poison_of(box)
         fa = fmt_a(NPR)
         inv_acc = 1.0 / (SG * W_SCALE)
-        gin = dict(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, acc_scale=inv_acc, T=T, sat_flag=flag)
-        gout = dict(split_fmt=fa, ch_x8_exp=X8_GRAD_EXP)
+        gin = dict(nprod=NPR, a8_exp=GE, b8_exp=X8_W_EXP, acc_scale=inv_acc, T=T, sat_flag=flag)
+        gout = dict(split_fmt=fa, ch_x8_exp=GE)
 
         gO = torch.zeros(N, ZLD, device=z_in.device, dtype=torch.float32)      # columns >= C stay zero (K = ZLD)
         gz1 = _empty(N, ZLD, like=z_in)
@@ -1167,7 +1246,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_end_b = colsum(gO, C, out=grad_out(end_b))
         g_end_w = grad_out(end_w)
         torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
-        gOh, gOl = split_f16(gO, ZLD, SG, ZLD, NPR, X8_GRAD_EXP, flag)
+        gOh, gOl = split_f16(gO, ZLD, SG, ZLD, NPR, GE, flag)
         WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD, NPR)                    # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
         rowgemm_h3(Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, C=gOUT, ldc=Wc, M=N, N=Wc, K=ZLD, **gin)
@@ -1206,7 +1285,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
             gQlo = lo16()
             gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
-                                                         X8_GRAD_EXP, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo)
+                                                         GE, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo)
             if use_rm:
                 slabs = wg_rm((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], Wc, Wc, 1, 1)
             else:
@@ -1350,13 +1429,14 @@ class ConvNormH3Fn(torch.autograd.Function):
         ldy = y.shape[1]
         box = meta["scale_box"]
         SG = grad_scale(box, gy)
-        flag = sat_flag_of(box)
+        GE = grad_x8_exp(box)
+        flag = sat_flag_bwd_of(box)
         Kp = round_up(Cout, 32)
         rowscale = 2 if partial else (1 if mask_out else 0)
         gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
         gph, gpl = _halves(N, Kp, like=y, zero=(Kp != Cout))       # K padding of the data gradient must read as zeros
         check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
-                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), X8_GRAD_EXP, flag), stream()),
+                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), GE, flag), stream()),
               "dact_mul")
         if xpair is not None:
             g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
@@ -1374,7 +1454,7 @@ class ConvNormH3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gx = torch.zeros_like(x) if x.shape[1] != Cin else torch.empty_like(x)
             WTh, WTl = transpose_split(Wh, Wl, Cout, Cin, Kp, NPR)                   # [taps][Cin][Kp]
-            rowgemm_h3(nprod=NPR, a8_exp=X8_GRAD_EXP, b8_exp=X8_W_EXP, Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp,
+            rowgemm_h3(nprod=NPR, a8_exp=GE, b8_exp=X8_W_EXP, Ah=gph, Al=gpl, lda_h=Kp, Bh=WTh, Bl=WTl, ldb_h=Kp,
                        b_tap_stride_h=WTh.stride(0),
                        acc_scale=1.0 / (SG * W_SCALE), C=gx, ldc=x.shape[1], M=N, N=Cin, K=Kp, taps=taps, dil=dil, sign=-1,
                        T=T, lens=lens, a_mask_mode=0, premask=1 if partial else 0)

@@ -124,8 +124,8 @@ def test_f8x_full_backward_on_other_distributions(variant, monkeypatch):
 
 def test_precision_guard_measures_and_switches(monkeypatch):
     """The decoder's runtime guard: the first training forward measures the FP8-cross scheme against the exact split
-    scheme on the last flow step (asynchronously); with the tolerance forced to zero the next poll switches the decoder
-    to h3 with a RuntimeWarning (FloatingPointError under RADMMM_CHECK_SATURATION=1)."""
+    scheme on the last flow step (asynchronously); with the tolerance forced to zero the second consecutive off-budget
+    measurement switches the decoder to h3 with a RuntimeWarning (FloatingPointError under RADMMM_CHECK_SATURATION=1)."""
     from oracle import radmmm_oracle as O
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -149,10 +149,16 @@ def test_precision_guard_measures_and_switches(monkeypatch):
     z_f8x = fwd()["z_mel"].detach().clone()
     dec.precision_guard_every = 1
     dec.precision_guard_tol = 0.0                            # any difference is now "off budget"
-    fwd()
+    fwd()                                                    # measurement 1
+    torch.cuda.synchronize()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # ONE off-budget measurement does not switch: it is repeated at once
+        fwd()
+    assert dec.gemm_precision == "f8x"
     torch.cuda.synchronize()
     with pytest.warns(RuntimeWarning, match="switching this decoder"):
-        z_h3 = fwd()["z_mel"].detach()
+        z_h3 = fwd()["z_mel"].detach()                       # the second consecutive one does
     assert dec.gemm_precision == "h3" and dec.precision_guard_status()[1] == 1
     assert 0.0 < rel_err(z_f8x.cpu(), z_h3.cpu()) < 1e-4     # really another scheme, and both inside the parity bar
     # strict mode raises instead
@@ -160,84 +166,10 @@ def test_precision_guard_measures_and_switches(monkeypatch):
     monkeypatch.setenv("RADMMM_CHECK_SATURATION", "1")
     fwd()
     torch.cuda.synchronize()
+    fwd()
+    torch.cuda.synchronize()
     with pytest.raises(FloatingPointError, match="accuracy budget"):
         fwd()
-
-
-def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
-    """BASELINE configs[4]: configs/RADMMM_16khz_model_config.yaml dims + n_splines = 2 (decoders.py:94,132), 8 flows, masked
-    batch-norm in the FiLM predictors (training mode: statistics over the whole batch), B = 32, T = 2000 ragged -- the
-    launches no other test reaches (M = 32 000 tiles, split-K weight gradients over 32 000 frames, FiLM convs at 32 000
-    rows, the spline kernels on 266 MB of parameters per flow).  The batch-norm couples the utterances, so the CPU oracle
-    runs the WHOLE batch (forward + NLL + backward, ~1-2 min on the GPU box's host cores): z, log-det, log_s sums and NLL
-    at 1e-4; d loss / d mel at 2e-3 (L2) / 5e-3 (max) and the parameter-gradient norms at 1e-3.  Why not 5e-4: measured
-    9.9e-4 / 2.0e-3 / 5.6e-4 in BOTH product schemes (RADMMM_TEST_C5_PRECISION=h3: z 2e-6, the same gradient figures), and
-    traced to the spline's bin search (tools/spline_layer_probe.py, profiles/r03_spline_bin_edge_ties.txt): with 2.56 M
-    spline elements per flow a handful land within one fp32 ulp of a bin edge, where this kernel's running sum of the
-    softmax widths and torch-CPU's cumsum differ in the last bit and `searchsorted` picks neighbouring bins.  The transform
-    and its log-Jacobian are continuous there (outputs agree to 2e-6), but log-Jacobian's parameter gradient has a kink at
-    every knot, so those elements get the OTHER one-sided gradient -- O(1) relative on the element, 1e-3 of the tensor in
-    L2.  One such element in a 40 000-element layer reproduces the whole effect; without a tie (3 FiLM layers instead of 4
-    on the same inputs) every gradient of the layer agrees to 4e-6."""
-    from oracle import radmmm_oracle as O
-    from rad_mmm_amd.common import SequenceLength
-    from rad_mmm_amd.decoders import RADMMMFlow
-    from rad_mmm_amd.loss import RADMMMLoss
-    import os
-    monkeypatch.setenv("RADMMM_PRECISION", os.environ.get("RADMMM_TEST_C5_PRECISION", "f8x"))
-    kw = dict(KW2, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
-    cfg = O.DecoderConfig(**kw)
-    sd = T(O.procedural_decoder_state(O.decoder_state_shapes(cfg)))
-    dec = RADMMMFlow(use_accent=True, **kw)
-    dec.load_state_dict(sd)
-    dec = dec.to(DEV).train()
-    dec.precision_guard_every = 0
-    B, Tn = 32, 2000
-    b = T(O.synthetic_batch(B, Tn, cfg, 2024, ragged=True))
-    gb = {k: v.to(DEV) for k, v in b.items()}
-    sl = SequenceLength(gb["lengths"])
-    mel = gb["mel"].clone().requires_grad_(True)
-    torch.cuda.reset_peak_memory_stats()
-    out = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
-    crit = RADMMMLoss(n_group_size=2)
-    lm = crit(out, None, sl, 0)["loss_mel"][0]
-    lm.backward()
-    torch.cuda.synchronize()
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    assert torch.isfinite(out["z_mel"]).all() and torch.isfinite(lm) and torch.isfinite(mel.grad).all()
-    p = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
-             and not k.endswith((".p", "lower_diag", "input_mean")) else v) for k, v in sd.items()}
-    omel = b["mel"].clone().requires_grad_(True)
-    ro = O.decoder_forward(p, cfg, omel, b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"])
-    lo, _ = O.decoder_loss(ro, b["lengths"], 2)
-    lo.backward()
-    ul = b["lengths"] // 2
-    m = (torch.arange(Tn // 2)[None] < ul[:, None])[:, None]
-    zerr = rel_err(out["z_mel"].detach().cpu() * m, ro["z_mel"].detach() * m)
-    lerr = abs(float(lm.detach()) - float(lo.detach())) / abs(float(lo.detach()))
-    lserr = 0.0
-    for a, c in zip(out["log_s_list"], ro["log_s_list"]):
-        sa, sc = float((a.detach().cpu() * m).sum()), float((c.detach() * m).sum())
-        lserr = max(lserr, abs(sa - sc) / max(1.0, abs(sc)))
-    for a, c in zip(out["log_det_W_list"], ro["log_det_W_list"]):
-        assert abs(float(a) - float(c)) < 1e-4 * max(1.0, abs(float(c)))
-    gerr = rel_err(mel.grad.cpu(), omel.grad)
-    gd = (mel.grad.cpu() - omel.grad).abs()
-    gl2 = float(gd.norm() / omel.grad.norm())
-    gfrac = float((gd > 5e-4 * omel.grad.abs().max()).float().mean())
-    worst, worst_n = 0.0, ""
-    for n, q in dec.named_parameters():
-        assert q.grad is not None and torch.isfinite(q.grad).all(), n
-        go = p[n].grad
-        gn, mine = float(go.norm()), float(q.grad.norm())
-        r = abs(mine - gn) / (gn + 1e-6)
-        if r > worst and gn > 1e-7:
-            worst, worst_n = r, n
-    print(f"configs[4] at B=32, T=2000: z rel {zerr:.2e}, log_s sums rel {lserr:.2e}, NLL rel {lerr:.2e}, d/d mel max-rel {gerr:.2e} / L2-rel {gl2:.2e} / fraction of elements off by > 5e-4 of the max {gfrac:.2e}, "
-          f"worst grad-norm rel {worst:.2e} ({worst_n}); peak device memory {peak:.1f} GiB")
-    assert zerr < 1e-4 and lserr < 1e-4 and lerr < 1e-4
-    assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3
-    assert worst < 1e-3, (worst_n, worst)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

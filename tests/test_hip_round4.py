@@ -62,3 +62,51 @@ def test_one_tap_gemm_is_bit_identical_to_per_tap_tiles(mb, kind, Kc, Nout, monk
         if name == "Ch" and kind in ("plain", "res", "res_first"):
             continue                                                    # (not written by these kinds)
         assert torch.equal(_bits(a), _bits(b)), name
+
+
+def test_gradient_x8_exponent_adapts_to_saturation_reports(monkeypatch):
+    """ops.GradScale: a backward pass whose 8-bit gradient parts saturate e4m3 reports by how many powers of two
+    (flag bits 2..7 of the backward producers' word); the exponent of the following passes is lowered by that level and
+    the reports stop -- no host synchronisation in between (the flags travel with the scale's event).  Started 10 powers
+    of two too high on purpose."""
+    import numpy as np
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", "f8x")
+    monkeypatch.setenv("RADMMM_F8X_MIN_ROWS", "0")
+    monkeypatch.delenv("RADMMM_CHECK_SATURATION", raising=False)
+    kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,
+              n_energy_avg_dims=1, n_mel_channels=80, n_early_size=2, n_early_every=2, n_group_size=2, scaling_fn="tanh",
+              affine_activation="softplus", use_partial_padding=True, n_conv_layers_per_step=4, n_flows=2)
+    cfg = O.DecoderConfig(**kw)
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in O.procedural_decoder_state(O.decoder_state_shapes(cfg)).items()})
+    dec = dec.to(DEV).train()
+    dec.precision_guard_every = 0
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in O.synthetic_batch(4, 256, cfg, 5, ragged=True).items()}
+    sl = SequenceLength(b["lengths"])
+    crit = RADMMMLoss(n_group_size=2)
+    dec._grad_scale = ops.GradScale()
+    dec._grad_scale.x8_grad_exp = ops.X8_GRAD_EXP + 10
+    exps, grads = [], []
+    for it in range(6):
+        for p in dec.parameters():
+            p.grad = None
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        crit(out, None, sl, 0)["loss_mel"][0].backward()
+        torch.cuda.synchronize()                              # (so that the next pass finds the published flags)
+        exps.append(dec._grad_scale.grad_exp())
+        grads.append(dec.flows[1].coupling_tfn.affine_param_predictor.in_layers[0].conv.weight_v.grad.clone())
+    gs = dec._grad_scale
+    assert exps[0] == ops.X8_GRAD_EXP + 10 and exps[-1] < exps[0], exps
+    assert gs.x8_adaptations >= 1 and gs.x8_saturated_passes >= 1
+    assert exps[-1] == exps[-2] == exps[-3], exps             # settled: the last passes did not saturate any more
+    assert int(gs.flags[1].item()) & 2 == 0
+    # the settled passes agree with each other bit for bit and differ from the saturated first pass only by the lost
+    # cross terms of the clipped elements
+    assert torch.equal(grads[-1], grads[-2])
+    d = float((grads[0] - grads[-1]).abs().max() / grads[-1].abs().max())
+    assert 0.0 <= d < 5e-3, d
