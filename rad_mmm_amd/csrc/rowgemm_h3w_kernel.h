@@ -32,6 +32,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BN = 256, BK = 32, ROWB = 64;
+// operand format of the scaled cross-term MFMA: 0 = FP8 e4m3 (the product), 2 = FP6 e2m3 in a TIMING-ONLY build
+// (-DRADMMM_X_FMT=2: wrong results; what would MXFP6 cross terms buy the K loop?  DESIGN 7)
+#ifndef RADMMM_X_FMT
+#define RADMMM_X_FMT 0
+#endif
 constexpr int OOB = 0x7fffffff;
 
 // -DRADMMM_PHASE_TIMERS (measurement builds only, tools/phase_probe.py): every workgroup records the 100 MHz wall clock

@@ -80,7 +80,7 @@ __device__ __forceinline__ void one_tap_steps(f32x16 (&acc)[MB][2], unsigned cha
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
-    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
+    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], RADMMM_X_FMT, RADMMM_X_FMT, 0, x_sa, 0, x_sb);
   };
 
   // prologue: tiles 0 and 1 (A stages 0 / 1, B stages 0 / 1); tile 0 must have landed everywhere, tile 1 may still fly

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
-    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
+    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], RADMMM_X_FMT, RADMMM_X_FMT, 0, x_sa, 0, x_sb);
   };
   // DMA with the step's position as the instruction's SCALAR offset (no vector add per piece; an out-of-range vector offset
   // stays out of range: the scalar offset takes part in the range check on gfx950)
