@@ -21,6 +21,7 @@
 // 1.08 us of MFMA work).  Every LDS read of the loop is inline asm: the compiler would otherwise order its own reads
 // behind all outstanding LDS-DMA with vmcnt(0).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -63,6 +64,18 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr d
 #endif
 }
 
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, lds_u32_ptr dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+#ifdef RADMMM_WG8_NOMASK                              // TIMING-ONLY build (wrong at utterance boundaries): no row masks on the X pieces
+using WG8Plain = std::true_type;
+#else
+using WG8Plain = std::false_type;
+#endif
+
 struct Frag { i32x2 lo, hi; };
 // Fragment addressing.  All lane-dependent parts of a fragment's LDS address are computed ONCE (round 3, second pass: the K
 // step carried ~270 VALU instructions beside its 48 MFMAs -- more than the MFMA gaps hide -- of which 30 were these address
@@ -93,6 +106,10 @@ __device__ __forceinline__ void frag8_issue(Frag& f, unsigned addr) {      // .l
   asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:4096" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
 }
 // wait until at most N LDS operations issued AFTER these fragments are outstanding (LDS returns in order)
+template <int N>
+__device__ __forceinline__ void frag_wait2(Frag& a, Frag& b) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void frag_wait3(Frag& a, Frag& b, Frag& c) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi) : "n"(N) : "memory");
@@ -239,6 +256,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
     dma16(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo);
   };
+  // the same without any vector work, for a window that lies inside ONE utterance's readable frames with all its shifted
+  // rows (the common case: T / 32 - 1 of T / 32 steps): every row is readable, the step's position goes into the
+  // instruction's scalar offset (an out-of-range lane offset stays out of range: the scalar offset takes part in the check)
+  auto dma_piece_fast = [&](int buf, int w, int rel) __attribute__((always_inline)) {
+    const bool lo8 = w >= 8;
+    const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
+    const int stepb = lo8 ? (isx ? xl_step : gl_step) : (isx ? x_step : g_step);
+    const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
+    dma16s(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), p_off[w], rel * stepb);
+  };
+  auto window_plain = [&]() __attribute__((always_inline)) {     // (scalar) the window being fetched needs no row mask
+    return w_t + BK <= a.T && w_t + shift >= 0 && w_t + shift + BK <= lim0;
+  };
   auto advance_window = [&]() __attribute__((always_inline)) {   // the window moves on by one K step (scalar work)
     w_t += BK;
     if (w_t >= a.T) {
@@ -272,7 +302,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
 #pragma unroll
     for (int w = 0; w < 12; ++w) dma_piece(1, w, 1);
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-    int buf = 0;
     // lane parts of the fragment addresses (stage-relative; arrays: GYh at 0, Xh at HARR, GYl8 at 2 HARR, Xl8 behind it)
     const unsigned sm_base = (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)sm);
     unsigned ah_base[4], a8_base[8], bh_base[2], b8_base[2];
@@ -286,77 +315,156 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
       bh_base[j] = sm_base + HARR + hi_lane_base(u & 3, lane) + (u >> 2) * 256;
       b8_base[j] = sm_base + 2 * HARR + LARR + lo8_lane_base(u, lane);
     }
+    // ---- K loop (round 4).  One wave per SIMD issues everything in order: whatever stands between two MFMAs must fit under
+    // the first one's 32 (f16) / 64 (fp8) cycles, or the matrix pipe idles.  Round 3's loop left the order to the compiler
+    // (runs of 14 VALU instructions and bursts of 6 LDS reads between MFMAs, every row block waiting for its own fragments
+    // and converting them right in front of its MFMAs).  Now a software pipeline three row blocks deep, in SLOTS closed by
+    // sched_barrier(0): while row block i multiplies, the fragments of block i + 2 are read and the FP8 hi halves of block
+    // i + 1 are converted:
+    //     slot 0: MFMA (i, 0, k block 0) | hi fragments of block i + 2, k block 0
+    //     slot 1: MFMA (i, 1, k block 0) | hi fragments ..., k block 1
+    //     slot 2: MFMA (i, 0, k block 1) | lo8 fragments of block i + 2
+    //     slot 3: MFMA (i, 1, k block 1) |
+    //     slot 4: cross MFMA (i, 0)      | one DMA piece of tile s + 2 (blocks 0 .. 5) | 2 conversion pairs of block i + 1
+    //     slot 5: cross MFMA (i, 1)      | one DMA piece                               | 2 conversion pairs
+    // -- a single wave's ISSUE bandwidth is the limit here (48 MFMAs carry ~60 LDS reads, 12 DMA pieces and, in round 3,
+    // ~170 vector instructions per step: more issue cycles than the MFMAs' 2048), so the loop also sheds vector work: DMA
+    // pieces of a window inside one utterance take no row mask and no address arithmetic (dma_piece_fast)
+    // (per accumulator still k block 0, k block 1, cross: the results are bit-identical to round 3's kernel).  The pipeline
+    // runs across the step boundary: blocks 6 / 7 read blocks 0 / 1 of the NEXT tile, so the step's wait (own vmcnt: tile
+    // s + 1 has landed; lgkmcnt(0): every read of tile s is complete) and barrier stand in front of block 6.  The X-side
+    // fragments (this wave's two units) are refreshed IN PLACE under block 7, each right behind the last MFMA that reads the
+    // old one, and their hi8 halves converted under block 7's two cross MFMAs: the first MFMA of a step finds its operands
+    // in registers.
+    Frag ga0[4], ga1[4], ga8[4];                                    // A side (GY): ring of four row blocks (8 blocks per step: slot = i & 3)
+    i32x4 ah8[2];                                                   // converted hi8 halves: slot = i & 1
+    Frag xb0[2], xb1[2], xb8[2];                                    // X side, unit j: fp16 hi fragments of k block 0 / 1, lo8 fragments
+    i32x4 xh8[2];                                                   // ... and their converted hi8 halves
+    i32x8 b8[2];                                                    // FP8 operand [lo8 | hi8] of the step in progress
+    auto read_a = [&](auto ic, unsigned sb) __attribute__((always_inline)) {      // all six fragment reads of row block ic (prologue)
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < 4) {
+        frag_issue<0>(ga0[i & 3], ah_base[i & 3] + sb);
+        frag_issue<8192>(ga1[i & 3], ah_base[i & 3] + sb);
+      } else {
+        frag_issue<256>(ga0[i & 3], ah_base[i & 3] + sb);
+        frag_issue<8192 + 256>(ga1[i & 3], ah_base[i & 3] + sb);
+      }
+      frag8_issue(ga8[i & 3], a8_base[i] + sb);
+    };
+    // pipeline prologue: X fragments of tile 0, row blocks 0 and 1 of tile 0, hi8 of block 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      frag_issue<0>(xb0[j], bh_base[j]);
+      frag_issue<8192>(xb1[j], bh_base[j]);
+      frag8_issue(xb8[j], b8_base[j]);
+    }
+    read_a(std::integral_constant<int, 0>{}, 0u);
+    read_a(std::integral_constant<int, 1>{}, 0u);
+    frag_wait3<12>(xb0[0], xb1[0], xb8[0]);
+    frag_wait3<12>(xb0[1], xb1[1], xb8[1]);
+    xh8[0] = hi8_of(xb0[0], xb1[0], x_inv);
+    xh8[1] = hi8_of(xb0[1], xb1[1], x_inv);
+    frag_wait3<6>(ga0[0], ga1[0], ga8[0]);
+    ah8[0] = hi8_of(ga0[0], ga1[0], g_inv);
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto dma_tile_piece = [&](int bufi, int w, int rel, auto plainc) __attribute__((always_inline)) {
+      const bool isx = w >= 8 ? ((w - 8) >> 1) != 0 : (w >> 2) != 0;
+      if (!isx || decltype(plainc)::value) dma_piece_fast(bufi, w, rel);      // (GY rows are never masked)
+      else dma_piece(bufi, w, rel);
+    };
+    int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
       advance_window();                                            // the window follows the tile being fetched: s + 2
       const int l_rel = s + 2;
       const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
-      const unsigned sb = (unsigned)(buf * STAGE);
-      unsigned ah[4], a8a[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ah[q] = ah_base[q] + sb;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a8a[i] = a8_base[i] + sb;
-      // B side (X, this wave's two 32-channel units): fp16 hi fragments of both k blocks + the FP8 operand [lo8 | hi8]
-      Frag xb0[2], xb1[2], xb8[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        frag_issue<0>(xb0[j], bh_base[j] + sb);
-        frag_issue<8192>(xb1[j], bh_base[j] + sb);
-        frag8_issue(xb8[j], b8_base[j] + sb);
-      }
-      Frag ga0[2], ga1[2], ga8[2];                                  // A side (GY), two slots
-      frag_issue<0>(ga0[0], ah[0]);
-      frag_issue<8192>(ga1[0], ah[0]);
-      frag8_issue(ga8[0], a8a[0]);
-      frag_wait3<12>(xb0[0], xb1[0], xb8[0]);                       // (6 B + 6 A read instructions are younger than B's first unit)
-      frag_wait3<6>(xb0[1], xb1[1], xb8[1]);
-      f16x8 bh0[2], bh1[2];
-      i32x8 b8[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh0[j] = frag_val(xb0[j]);
-        bh1[j] = frag_val(xb1[j]);
-        const i32x4 h8 = hi8_of(xb0[j], xb1[j], x_inv);
-        const i32x4 l8 = __builtin_shufflevector(xb8[j].lo, xb8[j].hi, 0, 1, 2, 3);
-        b8[j] = __builtin_shufflevector(l8, h8, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
+      const int xbuf = buf + 1 < NSTAGE ? buf + 1 : 0;             // stage of tile s + 1
+      const unsigned sb = (unsigned)(buf * STAGE), sbn = (unsigned)(xbuf * STAGE);
+      // this step's X operands were read / converted under the previous step's last block (or in the prologue): the fp16
+      // fragments are older than the four lo8 reads behind them; the lo8 fragments are waited for where the FP8 operand is
+      // put together (slot 3 of block 0: six more reads have been issued by then)
+      frag_wait2<4>(xb0[0], xb1[0]);
+      frag_wait2<4>(xb0[1], xb1[1]);
+      const f16x8 bh0[2] = {frag_val(xb0[0]), frag_val(xb0[1])}, bh1[2] = {frag_val(xb1[0]), frag_val(xb1[1])};
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int sl = i & 1;
-        if (i + 1 < 8) {                                            // next row block's fragments ahead of this one's MFMAs
-          if (i + 1 < 4) {
-            frag_issue<0>(ga0[sl ^ 1], ah[(i + 1) & 3]);
-            frag_issue<8192>(ga1[sl ^ 1], ah[(i + 1) & 3]);
-          } else {
-            frag_issue<256>(ga0[sl ^ 1], ah[(i + 1) & 3]);
-            frag_issue<8192 + 256>(ga1[sl ^ 1], ah[(i + 1) & 3]);
-          }
-          frag8_issue(ga8[sl ^ 1], a8a[i + 1]);
-          frag_wait3<6>(ga0[sl], ga1[sl], ga8[sl]);
-        } else {
-          frag_wait3<0>(ga0[sl], ga1[sl], ga8[sl]);
+        const int cur = i & 3, nx1 = (i + 1) & 3, nx2 = (i + 2) & 3;
+        const int i2 = (i + 2) & 7;                                // row block being read (of this tile, or of the next one)
+        const unsigned sb2 = i + 2 < 8 ? sb : sbn;
+        if (i == 6) {
+          // tile s + 1 has landed as far as this wave fetched it, every read of tile s is complete: publish, and free
+          // tile s's stage for tile s + 3
+          asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
-        const f16x8 ah0 = frag_val(ga0[sl]), ah1 = frag_val(ga1[sl]);
-        const i32x4 h8 = hi8_of(ga0[sl], ga1[sl], g_inv);
-        const i32x4 l8 = __builtin_shufflevector(ga8[sl].lo, ga8[sl].hi, 0, 1, 2, 3);
-        const i32x8 a8 = __builtin_shufflevector(h8, l8, 0, 1, 2, 3, 4, 5, 6, 7);
+        const f16x8 ah0 = frag_val(ga0[cur]), ah1 = frag_val(ga1[cur]);
+        const i32x4 l8c = __builtin_shufflevector(ga8[cur].lo, ga8[cur].hi, 0, 1, 2, 3);
+        const i32x8 a8 = __builtin_shufflevector(ah8[i & 1], l8c, 0, 1, 2, 3, 4, 5, 6, 7);
+        i32x4 h8n;                                                 // hi8 of block i + 1, converted under this block's f16 MFMAs
+        // slot 0
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[0], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        if (i2 < 4) frag_issue<0>(ga0[nx2], ah_base[i2 & 3] + sb2);
+        else frag_issue<256>(ga0[nx2], ah_base[i2 & 3] + sb2);
+        frag_wait3<2>(ga0[nx1], ga1[nx1], ga8[nx1]);               // block i + 1's fragments (read a whole block ago): two younger reads in flight
+        if (i == 7) frag_issue<0>(xb0[0], bh_base[0] + sbn);        // (bh0[0] holds the old value: last read by the MFMA above)
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 1
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[1], acc[i][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        if (i2 < 4) frag_issue<8192>(ga1[nx2], ah_base[i2 & 3] + sb2);
+        else frag_issue<8192 + 256>(ga1[nx2], ah_base[i2 & 3] + sb2);
+        if (i == 7) frag_issue<0>(xb0[1], bh_base[1] + sbn);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 2
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[0], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        frag8_issue(ga8[nx2], a8_base[i2] + sb2);
+        if (i == 7) frag_issue<8192>(xb1[0], bh_base[0] + sbn);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 3
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[1], acc[i][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        if (i == 0) {
+          frag_wait2<6>(xb8[0], xb8[1]);                           // (younger: this block's six A reads)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 0, 0, 0, x_sa, 0, x_sb);
+          for (int j = 0; j < 2; ++j)
+            b8[j] = __builtin_shufflevector(__builtin_shufflevector(xb8[j].lo, xb8[j].hi, 0, 1, 2, 3), xh8[j], 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        if (i < 6) {                                                // two DMA pieces of tile s + 2 per row block
-          dma_piece(nbuf, 2 * i, l_rel);
-          dma_piece(nbuf, 2 * i + 1, l_rel);
+        if (i == 7) frag_issue<8192>(xb1[1], bh_base[1] + sbn);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 4
+        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[0], acc[i][0], 0, 0, 0, x_sa, 0, x_sb);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        if (i < 6) dma_tile_piece(nbuf, 2 * i, l_rel, WG8Plain{});
+        h8n[0] = cvt4_fp8(ga0[nx1].lo[0], ga0[nx1].lo[1], g_inv);
+        h8n[1] = cvt4_fp8(ga0[nx1].hi[0], ga0[nx1].hi[1], g_inv);
+        if (i == 7) {
+          frag8_issue(xb8[0], b8_base[0] + sbn);
+          frag_wait2<4>(xb0[0], xb1[0]);                           // (xb0[0], xb1[0] of the next tile: four younger reads)
+          xh8[0] = hi8_of(xb0[0], xb1[0], x_inv);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 5
+        acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[1], acc[i][1], 0, 0, 0, x_sa, 0, x_sb);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
+        if (i < 6) dma_tile_piece(nbuf, 2 * i + 1, l_rel, WG8Plain{});
+        h8n[2] = cvt4_fp8(ga1[nx1].lo[0], ga1[nx1].lo[1], g_inv);
+        h8n[3] = cvt4_fp8(ga1[nx1].hi[0], ga1[nx1].hi[1], g_inv);
+        ah8[(i + 1) & 1] = h8n;
+        if (i == 7) {
+          frag8_issue(xb8[1], b8_base[1] + sbn);
+          frag_wait2<4>(xb0[1], xb1[1]);                           // (xb0[1], xb1[1]: the two lo8 reads are younger)
+          xh8[1] = hi8_of(xb0[1], xb1[1], x_inv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // all reads of stage `buf` are complete (waited above); tile s + 1 has landed once at most this step's 12 pieces
-      // are outstanding
-      asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-      buf = buf + 1 < NSTAGE ? buf + 1 : 0;
+      buf = xbuf;
     }
-    __syncthreads();                                               // the trailing (out-of-range) pieces, before LDS is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                               // the trailing (out-of-range) pieces and look-ahead reads, before LDS is reused
   }
   float* P = a.P + (long long)split * a.split_stride + (long long)tap * a.Mc * a.ldp;
   const bool vec_ok = (a.ldp % 4 == 0) && radmmm::aligned16(a.P) && (a.split_stride % 4 == 0);
