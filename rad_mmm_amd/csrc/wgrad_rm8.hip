@@ -204,9 +204,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
   // (w_b, w_t) = utterance and frame-in-utterance of its first frame, lim0 / lim1 the readable frames of utterances w_b and
   // w_b + 1 (T >= 32: a window meets at most one boundary) -- and lives in scalar registers: a row is readable iff
   //   k + w_t < T ?  0 <= c + w_t < lim0  :  0 <= c + w_t - T < lim1
-  // (5 vector compares / adds per X piece and step; the mask logic is scalar).  Pieces of steps beyond the split's end go to
-  // stages nobody reads, whatever they fetch.
-  int p_k[12], p_off[12], p_c[12];
+  // Round 4: the test is made ONCE per step for the 32 rows of the window (row_mask: lane l stands for row l & 31, the
+  // ballot is a 32-bit scalar with bit k set when row k is NOT readable); an X piece moves its row's bit to the sign,
+  // spreads it and ORs 0x7fffffff into its lane offset (3 vector instructions instead of 10 per piece: the K loop is bound by
+  // the ONE wave's instruction issue).  The step's position itself is the DMA instruction's scalar offset.  Pieces of steps
+  // beyond the split's end go to stages nobody reads, whatever they fetch.
+  int p_off[12], p_sh[12];
   const int nb = a.R / a.T;
   auto lim_of = [&](int b) __attribute__((always_inline)) {
     if (b >= nb) return 0;
@@ -223,8 +226,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int u = ((lane & 31) >> 2) ^ (k & 3);                  // source 64-byte unit that lands at this lane's LDS unit
     const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
     const int ch = c0 + u * 32 + (lane & 3) * 8;
-    p_k[w] = k;
-    p_c[w] = k + shift;
+    p_sh[w] = 31 - k;
     const int f0 = step_lo * BK + k;                             // GY frame of this row at the split's first step
     p_off[w] = ch < ld ? ((f0 + (isx ? shift : 0)) * ld + ch) * 2 : OOB;
   }
@@ -235,39 +237,36 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     const int u = ((lane >> 1) & 7) ^ (k & 7);                   // source 32-channel unit that lands at this lane's LDS unit
     const int c0 = isx ? n0 : m0, ld = isx ? a.ldx : a.ldg;
     const int ch = c0 + u * 32 + (lane & 1) * 16;
-    p_k[w] = k;
-    p_c[w] = k + shift;
+    p_sh[w] = 31 - k;
     const int f0 = step_lo * BK + k;
     const int pitch = isx ? a.xl_pitch : a.gl_pitch, bs = isx ? a.xl_bstride : a.gl_bstride, bo = isx ? a.xl_boff : a.gl_boff;
     p_off[w] = ch < ld ? (f0 + (isx ? shift : 0)) * pitch + (ch >> 5) * bs + bo + (ch & 31) : OOB;
   }
   const int g_step = BK * a.ldg * 2, x_step = BK * a.ldx * 2, gl_step = BK * a.gl_pitch, xl_step = BK * a.xl_pitch;
-  // piece w of relative step `rel` into stage `buf`; the window state must be that of step `rel` (advance_window)
-  auto dma_piece = [&](int buf, int w, int rel) __attribute__((always_inline)) {
+  // bit k set: row k of the window being fetched (state w_t, lim0, lim1) is not readable through this tap's shift
+  auto row_mask = [&]() __attribute__((always_inline)) {
+    int k = lane & 31;
+    asm volatile("" : "+v"(k));                                  // (pins the computation where it is called: see the K loop's slots)
+    const int x = k + shift + w_t;
+    const bool ok = (k + w_t < a.T) ? ((unsigned)x < (unsigned)lim0) : ((unsigned)(x - a.T) < (unsigned)lim1);
+    return ~(unsigned)__ballot(ok);
+  };
+  // piece w of relative step `rel` into stage `buf`; nmask = row_mask() of that step's window (X pieces only)
+  auto dma_piece = [&](int buf, int w, int rel, unsigned nmask) __attribute__((always_inline)) {
     const bool lo8 = w >= 8;
     const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
     const int stepb = lo8 ? (isx ? xl_step : gl_step) : (isx ? x_step : g_step);
-    int vo = p_off[w] + rel * stepb;                             // (OOB + anything stays beyond 2^31 = out of range)
+    // GY pieces: the step's position is the instruction's scalar offset (their lane offsets are never negative).  X pieces:
+    // with a negative tap shift the lane offset of the split's first rows IS negative until the window has moved on, and the
+    // range check takes the unsigned sum of lane and scalar offset: one vector add, then the mask (OOB | anything and
+    // OOB + the position stay out of range)
+    int vo = p_off[w];
     if (isx) {
-      const int x = p_c[w] + w_t;
-      const bool ok = (p_k[w] + w_t < a.T) ? ((unsigned)x < (unsigned)lim0) : ((unsigned)(x - a.T) < (unsigned)lim1);
-      vo = ok ? vo : OOB;
+      vo += rel * stepb;
+      if (!WG8Plain::value) vo |= ((int)(nmask << p_sh[w]) >> 31) & OOB;
     }
     const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
-    dma16(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo);
-  };
-  // the same without any vector work, for a window that lies inside ONE utterance's readable frames with all its shifted
-  // rows (the common case: T / 32 - 1 of T / 32 steps): every row is readable, the step's position goes into the
-  // instruction's scalar offset (an out-of-range lane offset stays out of range: the scalar offset takes part in the check)
-  auto dma_piece_fast = [&](int buf, int w, int rel) __attribute__((always_inline)) {
-    const bool lo8 = w >= 8;
-    const int isx = lo8 ? (w - 8) >> 1 : w >> 2;
-    const int stepb = lo8 ? (isx ? xl_step : gl_step) : (isx ? x_step : g_step);
-    const int dst = lo8 ? 2 * HARR + isx * LARR + (4 * ((w - 8) & 1) + wave) * 1024 : isx * HARR + (4 * (w & 3) + wave) * 1024;
-    dma16s(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), p_off[w], rel * stepb);
-  };
-  auto window_plain = [&]() __attribute__((always_inline)) {     // (scalar) the window being fetched needs no row mask
-    return w_t + BK <= a.T && w_t + shift >= 0 && w_t + shift + BK <= lim0;
+    dma16s(lo8 ? (isx ? rXl : rGl) : (isx ? rXh : rGh), (lds_u32_ptr)(sm + buf * STAGE + dst), vo, isx ? 0 : rel * stepb);
   };
   auto advance_window = [&]() __attribute__((always_inline)) {   // the window moves on by one K step (scalar work)
     w_t += BK;
@@ -296,11 +295,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
   if (nsteps > 0) {
     // prologue: tiles 0 and 1 (the pieces of a step beyond the split's end are issued all the same, with out-of-range
     // offsets -- zeros into a stage nobody reads -- so that every step issues exactly 12 pieces per wave)
+    {
+      const unsigned nm = row_mask();
 #pragma unroll
-    for (int w = 0; w < 12; ++w) dma_piece(0, w, 0);
+      for (int w = 0; w < 12; ++w) dma_piece(0, w, 0, nm);
+    }
     advance_window();
+    {
+      const unsigned nm = row_mask();
 #pragma unroll
-    for (int w = 0; w < 12; ++w) dma_piece(1, w, 1);
+      for (int w = 0; w < 12; ++w) dma_piece(1, w, 1, nm);
+    }
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     // lane parts of the fragment addresses (stage-relative; arrays: GYh at 0, Xh at HARR, GYl8 at 2 HARR, Xl8 behind it)
     const unsigned sm_base = (unsigned)reinterpret_cast<size_t>((lds_u32_ptr)sm);
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     //     slot 5: cross MFMA (i, 1)      | one DMA piece                               | 2 conversion pairs
     // -- a single wave's ISSUE bandwidth is the limit here (48 MFMAs carry ~60 LDS reads, 12 DMA pieces and, in round 3,
     // ~170 vector instructions per step: more issue cycles than the MFMAs' 2048), so the loop also sheds vector work: DMA
-    // pieces of a window inside one utterance take no row mask and no address arithmetic (dma_piece_fast)
+    // pieces take their row mask from one 32-bit ballot per step and their position from the instruction's scalar offset
     // (per accumulator still k block 0, k block 1, cross: the results are bit-identical to round 3's kernel).  The pipeline
     // runs across the step boundary: blocks 6 / 7 read blocks 0 / 1 of the NEXT tile, so the step's wait (own vmcnt: tile
     // s + 1 has landed; lgkmcnt(0): every read of tile s is complete) and barrier stand in front of block 6.  The X-side
@@ -369,15 +374,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
     ah8[0] = hi8_of(ga0[0], ga1[0], g_inv);
     __builtin_amdgcn_sched_barrier(0);
 
-    auto dma_tile_piece = [&](int bufi, int w, int rel, auto plainc) __attribute__((always_inline)) {
-      const bool isx = w >= 8 ? ((w - 8) >> 1) != 0 : (w >> 2) != 0;
-      if (!isx || decltype(plainc)::value) dma_piece_fast(bufi, w, rel);      // (GY rows are never masked)
-      else dma_piece(bufi, w, rel);
-    };
     int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
       advance_window();                                            // the window follows the tile being fetched: s + 2
       const int l_rel = s + 2;
+      unsigned nmask = 0;
       const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
       const int xbuf = buf + 1 < NSTAGE ? buf + 1 : 0;             // stage of tile s + 1
       const unsigned sb = (unsigned)(buf * STAGE), sbn = (unsigned)(xbuf * STAGE);
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         // slot 4
         acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[0], acc[i][0], 0, 0, 0, x_sa, 0, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i < 6) dma_tile_piece(nbuf, 2 * i, l_rel, WG8Plain{});
+        if (i < 6) dma_piece(nbuf, 2 * i, l_rel, nmask);
+        if (i == 1) nmask = row_mask();                            // (first needed by block 2's pieces)
         h8n[0] = cvt4_fp8(ga0[nx1].lo[0], ga0[nx1].lo[1], g_inv);
         h8n[1] = cvt4_fp8(ga0[nx1].hi[0], ga0[nx1].hi[1], g_inv);
         if (i == 7) {
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         // slot 5
         acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[1], acc[i][1], 0, 0, 0, x_sa, 0, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i < 6) dma_tile_piece(nbuf, 2 * i + 1, l_rel, WG8Plain{});
+        if (i < 6) dma_piece(nbuf, 2 * i + 1, l_rel, nmask);
         h8n[2] = cvt4_fp8(ga1[nx1].lo[0], ga1[nx1].lo[1], g_inv);
         h8n[3] = cvt4_fp8(ga1[nx1].hi[0], ga1[nx1].hi[1], g_inv);
         ah8[(i + 1) & 1] = h8n;
