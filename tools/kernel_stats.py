@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total/avg ms, share) from a rocprofv3 --kernel-trace results .db
 (rocpd sqlite schema), for when the --stats CSVs were not merged back.
-usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps]
+usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps] [--json FILE]
   -> prints a table; with `steps`, also ms per step; with --hist, the launch-duration clusters of the
      kernels whose name contains SUBSTR (one kernel serves several GEMM shapes: the per-shape average is
      what bench.py's roofline leg times, the all-shapes average is what --stats prints); with --gaps, how much of the
@@ -16,6 +16,11 @@ def main():
     gaps = "--gaps" in argv
     if gaps:
         argv.remove("--gaps")
+    jpath = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        jpath = argv[i + 1]
+        del argv[i:i + 2]
     hist = None
     if "--hist" in argv:
         i = argv.index("--hist")
@@ -36,6 +41,12 @@ def main():
             line += f" {t / 1e6 / steps:8.2f}"
         print(line)
     print(f"{'TOTAL':70s} {sum(r[1] for r in rows):7d} {tot / 1e6:10.2f}")
+    if jpath:                                           # machine-readable copy (bench.py quotes it: roofline_hbm)
+        import json
+        with open(jpath, "w") as f:
+            json.dump({"steps": steps, "total_ms": tot / 1e6,
+                       "kernels": {n: {"calls": c, "total_ms": t / 1e6, "avg_us": a / 1e3,
+                                       "ms_per_step": (t / 1e6 / steps) if steps else None} for n, c, t, a in rows}}, f, indent=1)
     if gaps:
         ev = db.execute(f"select d.start, d.end from {kd} d order by d.start").fetchall()
         ev = ev[int(len(ev) * 0.4):]                                  # the timed steps at the end of the run
