@@ -10,8 +10,10 @@ Pinning: the reference has no tests or golden vectors of its own, s
 the oracle is pinned against outputs of the reference itself, imported in the
 build container by `tests/golden/make_golden.py`; the resulting fixtures live in
 `tests/golden/*.npz` and `tests/test_oracle_golden.py` replays them.  One piece
-is "parity unpinned": the Slaney mel filterbank (`mel_filterbank_slaney`), which
-the reference takes from librosa 0.8.0 (absent here) -- see DESIGN.md.
+is pinned one step removed: the Slaney mel filterbank (`mel_filterbank_slaney`), which
+the reference takes from librosa 0.8.0 (absent here): its fixture comes from an
+independent, librosa-validated implementation (Hugging Face transformers'
+audio_utils.mel_filter_bank, tests/golden/make_mel_basis.py) -- see DESIGN.md.
 
 All tensors use the reference's layout: activations [B, C, T], conv weights
 [C_out, C_in, k].  Parameters are passed as a flat dict keyed by the reference's
@@ -630,8 +632,10 @@ def mel_filterbank_slaney(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: O
                           ) -> np.ndarray:
     """Published algorithm of librosa 0.8.0 `filters.mel(sr, n_fft, n_mels, fmin, fmax)`
     with its defaults (htk=False -> Slaney scale, norm='slaney'); call site
-    audio_processing.py:124-125.  PARITY UNPINNED: librosa is absent from the
-    reference tree and from this image; self-checked only (tests/test_oracle_golden.py).
+    audio_processing.py:124-125.  librosa is absent from the reference tree and from this
+    image: pinned (bit-equal in float32) to transformers.audio_utils.mel_filter_bank(norm =
+    mel_scale = "slaney"), an independent implementation that project validates against
+    librosa (tests/golden/mel_basis_hf.npz, tests/test_oracle_golden.py).
     """
     if fmax is None:
         fmax = sr / 2.0

@@ -4,7 +4,8 @@
 mel_fmax).mel_spectrogram(y)` as in the reference, forward only (the reference runs it without
 grad inside DataLoader workers).  The windowed DFT basis is built exactly like the reference's
 conv1d weights; the mel filterbank restates librosa 0.8.0 `filters.mel` (Slaney scale, Slaney
-norm), which the reference imports -- PARITY UNPINNED for that matrix.
+norm), which the reference imports -- pinned to an independent librosa-validated implementation
+(tests/golden/mel_basis_hf.npz: librosa itself is absent from the reference tree and the image).
 """
 from __future__ import annotations
 

@@ -171,8 +171,7 @@ def test_stft_mel(golden):
     mag_r = torch.exp(mel_r).cpu().numpy()
     big = g["mag2"] > 1e-3 * g["mag2"].max()
     assert np.abs(mag_r - g["mag2"])[big].max() < 2e-5 * g["mag2"].max()
-    # full mel path at the real geometry vs the oracle (same restated filterbank: librosa 0.8.0 is absent, the Slaney
-    # basis itself stays "parity unpinned")
+    # full mel path at the real geometry vs the oracle (the Slaney basis itself: tests/golden/mel_basis_hf.npz)
     st = TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0).to(DEV)
     r = np.random.Generator(np.random.PCG64(9))
     audio = np.clip(r.standard_normal((3, 256 * 40)) * 0.3, -1, 1).astype(np.float32)

@@ -204,8 +204,25 @@ def test_stft_magnitude(golden):
     assert rel_err(m2, g["mag2"]) < 5e-6
 
 
+@pytest.mark.parametrize("tag", ["22k", "16k"])
+def test_mel_filterbank_matches_an_independent_implementation(golden, tag):
+    """librosa (the reference's source of the matrix, audio_processing.py:124-125) is absent, so the pin is one step removed:
+    tests/golden/mel_basis_hf.npz holds the Slaney filterbank of Hugging Face transformers' `audio_utils.mel_filter_bank`
+    (norm = mel_scale = "slaney": the function Whisper's feature extractor uses to reproduce librosa's filters) for the two
+    geometries of the reference's data configs (tests/golden/make_mel_basis.py).  The oracle's restatement AND the
+    product's (rad_mmm_amd.audio_processing.mel_filterbank: host-side numpy) must agree with it to float32 rounding."""
+    g = golden("mel_basis_hf.npz")
+    sr, n_fft, n_mels, fmin, fmax = g[f"args_{tag}"]
+    ref = g[f"mel_{tag}"]
+    fb = O.mel_filterbank_slaney(int(sr), int(n_fft), int(n_mels), float(fmin), float(fmax))
+    assert fb.shape == ref.shape and np.abs(fb - ref).max() <= 1e-7 * np.abs(ref).max()
+    from rad_mmm_amd.audio_processing import mel_filterbank
+    fp = mel_filterbank(int(sr), int(n_fft), int(n_mels), float(fmin), float(fmax))
+    assert fp.shape == ref.shape and np.abs(fp - ref).max() <= 1e-7 * np.abs(ref).max()
+
+
 def test_mel_filterbank_selfcheck():
-    """librosa is absent -> PARITY UNPINNED; structural checks only."""
+    """structural checks of the restated filterbank (its values are pinned by the test above)"""
     fb = O.mel_filterbank_slaney(22050, 1024, 80, 0.0, 8000.0)
     assert fb.shape == (80, 513) and (fb >= 0).all()
     freqs = np.linspace(0, 22050 / 2, 513)
@@ -221,7 +238,7 @@ def test_mel_filterbank_selfcheck():
     # The one PUBLISHED value available offline: the example in librosa.filters.mel's docstring (0.8.x),
     # `melfb = librosa.filters.mel(22050, 2048)` -> `array([[ 0.   ,  0.016, ...,  0.   ,  0.   ], ...` (128 mels, fmax = sr/2,
     # Slaney scale and norm), i.e. melfb[0, 0] = 0.000 and melfb[0, 1] = 0.016 to the three decimals printed there.  A
-    # weak pin (two rounded entries) -- the basis stays "parity unpinned" in DESIGN.md -- but it does tie the restated
+    # weak pin (two rounded entries), but it does tie the restated
     # scale, the triangle construction and the Slaney area normalisation to librosa's own numbers.
     doc = O.mel_filterbank_slaney(22050, 2048, 128, 0.0, None)
     assert doc.shape == (128, 1025)
