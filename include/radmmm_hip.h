@@ -297,6 +297,11 @@ int radmmm_fused_add_tanh_sigmoid_multiply(const float* a, const float* b, int l
  * ------------------------------------------------------------------------------------ */
 int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int ldq, float* y, int ldy,
                          float* logj_sum, int rows, int h, int K, radmmm_stream_t stream);
+/* INDEX accounting of the forward bin search (splines.py:300-306 `searchsorted`), for parity tests: bins[r*h + c] = the bin
+ * radmmm_pq_spline_fwd picks for element (r, c), or -1 for an element outside [0, 1) (passed through); edge_l / edge_r = the
+ * two edges of that bin as the search compared them (the kernel's running sum of the softmax widths; 1 for the last bin). */
+int radmmm_pq_spline_bins(const float* x, int ldx, const float* q, int ldq, int32_t* bins, float* edge_l, float* edge_r,
+                          int rows, int h, int K, radmmm_stream_t stream);
 /* inverse direction of the same transform (splines.py:327-339; no log-jacobian): x from y, both in [0,1) units */
 int radmmm_pq_spline_inv(const float* y, int ldy, const float* q, int ldq, float* x, int ldx, int rows, int h, int K,
                          radmmm_stream_t stream);

@@ -167,6 +167,7 @@ def _load() -> C.CDLL:
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, so, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, i, i, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
+        "radmmm_pq_spline_bins": [p, i, p, i, p, p, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],
         "radmmm_attn_fwd": [p, p, p, p, p, p, i, i, i, i, f, p],
         "radmmm_attn_bwd": [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, f, p],

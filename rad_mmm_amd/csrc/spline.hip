@@ -16,6 +16,7 @@ struct SplineCore {
   float A;        // normalising area of the pdf
   int b;          // bin index
   float w_b, w_l, v_b, v_r, c_l, alpha, wbc, y0, L;
+  float edge_r;   // right edge of the chosen bin as the search compared it (running sum of the widths; 1 for the last bin)
 };
 
 // In place: P[0..K) <- w_j (normalised), P[K..2K+1) <- ev_j (un-normalised exp(v-max)+1e-8)
@@ -50,10 +51,12 @@ __device__ __forceinline__ void spline_forward_core(float* P, int K, float x, Sp
       b = j;
       w_l = wl_j;
       c_l = cl_j;
+      o.edge_r = edge;
     }
   }
   if (!found) {  // x > 1 cannot happen for inside elements; keep last bin
     b = K - 1;
+    o.edge_r = 1.f;
   }
   o.A = A;
   o.b = b;
@@ -153,6 +156,38 @@ __global__ __launch_bounds__(SP_THREADS) void pq_spline_inv_kernel(
       xo = fminf(fmaxf(alpha * w_b + w_l, eps), 1.f - eps);
     }
     x[(long long)r * ldx + c] = xo;
+  }
+}
+
+// INDEX accounting (tests): the bin the forward search picks for every element (-1: outside [0, 1), passed through) and the
+// two edges of that bin as the search saw them -- its running sum of the softmax widths, not torch's cumsum
+__global__ __launch_bounds__(SP_THREADS) void pq_spline_bins_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ q,
+                                                                    int* __restrict__ bins, float* __restrict__ edge_l,
+                                                                    float* __restrict__ edge_r, int rows, int h, int K) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nb = 2 * K + 1;
+  const long long total = (long long)rows * h;
+  const long long e0 = (long long)blockIdx.x * SP_THREADS;
+  const int ne = (int)((total - e0) < SP_THREADS ? (total - e0) : SP_THREADS);
+  const float* src = q + e0 * nb;
+  for (int i = threadIdx.x; i < ne * nb; i += SP_THREADS) sm[i] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x < ne) {
+    const long long e = e0 + threadIdx.x;
+    const int r = (int)(e / h), c = (int)(e - (long long)r * h);
+    const float xv = x[(long long)r * ldx + c];
+    int b = -1;
+    float el = 0.f, er = 0.f;
+    if (xv >= 0.f && xv < 1.f) {
+      SplineCore o;
+      spline_forward_core(sm + threadIdx.x * nb, K, xv, o);
+      b = o.b;
+      el = o.w_l;
+      er = o.edge_r;
+    }
+    bins[e] = b;
+    edge_l[e] = el;
+    edge_r[e] = er;
   }
 }
 
@@ -274,6 +309,19 @@ extern "C" int radmmm_pq_spline_fwd(const float* x, int ldx, const float* q, int
   hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0,
                      static_cast<hipStream_t>(stream), logj_elem, logj_sum, rows, h);
   return radmmm::check_launch("pq_spline_fwd");
+}
+
+extern "C" int radmmm_pq_spline_bins(const float* x, int ldx, const float* q, int ldq, int32_t* bins, float* edge_l, float* edge_r,
+                                     int rows, int h, int K, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(x && q && bins && edge_l && edge_r, "pq_spline_bins: null pointer");
+  RADMMM_REQUIRE(rows > 0 && h > 0 && K >= 1 && K <= SP_KMAX, "pq_spline_bins: bad dims");
+  RADMMM_REQUIRE(ldq == h * (2 * K + 1), "pq_spline_bins: q must be dense (ldq == h*(2K+1))");
+  const long long total = (long long)rows * h;
+  const int nblk = (int)((total + SP_THREADS - 1) / SP_THREADS);
+  const size_t smem = (size_t)SP_THREADS * (2 * K + 1) * sizeof(float);
+  hipLaunchKernelGGL(pq_spline_bins_kernel, dim3(nblk), dim3(SP_THREADS), smem, static_cast<hipStream_t>(stream), x, ldx, q, bins,
+                     edge_l, edge_r, rows, h, K);
+  return radmmm::check_launch("pq_spline_bins");
 }
 
 extern "C" int radmmm_pq_spline_inv(const float* y, int ldy, const float* q, int ldq, float* x, int ldx, int rows, int h,

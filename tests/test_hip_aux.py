@@ -97,6 +97,18 @@ def test_mas_full_size_properties():
     print(f"MAS full size: numpy float32 log differs from the correctly rounded one in {changed_logs} of {total_logs} "
           f"elements; alignments changed by that: {changed_items} of {B}")
     assert changed_items <= 1
+    # (4) RADMMM_MAS_LOG=host: the batched product path on the host's numpy log, as the reference takes it -- bit-exact with
+    # the C oracle's reference-style run (numpy log + search) for every item
+    import os
+    os.environ["RADMMM_MAS_LOG"] = "host"
+    try:
+        hard_h = binarize_attention(attn.to(DEV), torch.from_numpy(in_lens).to(DEV), torch.from_numpy(out_lens).to(DEV))
+    finally:
+        del os.environ["RADMMM_MAS_LOG"]
+    hard_h = hard_h.cpu().numpy()[:, 0]
+    for b in range(B):
+        a = attn[b, 0, : out_lens[b], : in_lens[b]].numpy().copy()
+        assert np.array_equal(hard_h[b, : out_lens[b], : in_lens[b]], O.mas_width1_c(a)), b
 
 
 def test_pq_spline_kernel_golden(golden):
