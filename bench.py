@@ -306,13 +306,16 @@ def cpu_baseline(cfg, sd, batch, hip_out, budget_s=25.0):
                       f"1 step = {dt:.1f} s (one utterance alone: {probe:.2f} s)"}, parity
 
 
-def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=5, t_txt=150):
+def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=150):
     """The WHOLE training step the reference's Lightning loop runs per batch (tts_lightning_modules.py:643-750 + clip +
     RAdam, configs/RADMMM_train_config.yaml:7-8): embeddings, text encoder, alignment attention with the beta-binomial
     prior, on-device MAS (binarisation on), context = txt_enc . attn^T, flow decoder, flow NLL + CTC + binarisation losses,
     backward, global-norm clip 1.0, RAdam -- on synthetic text (150 tokens per utterance) and the decoder leg's mel.
+    Gradients land in the flat buckets of a BucketedGradReducer around the whole step (what a data-parallel run uses) and
+    FlatRAdam steps on those buckets; the batch carries the host copies of the lengths the collate function has anyway.
     Reported: ms per step, the share outside the decoder's fwd+bwd, and the host synchronisations one step makes."""
     import warnings
+    from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.data import BetaBinomialInterpolator
     from rad_mmm_amd.encoder import Encoder
     from rad_mmm_amd.loss import RADMMMLoss
@@ -329,14 +332,17 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=5, t_txt=
              "speaker_ids": torch.randint(0, 8, (B,), generator=g).to(dev), "accent_ids": torch.randint(0, 4, (B,), generator=g).to(dev),
              "text": torch.randint(0, 185, (B, t_txt), generator=g).to(dev),
              "input_lengths": torch.tensor(in_lens, device=dev), "output_lengths": gb["lengths"],
+             "input_lengths_host": torch.tensor(in_lens), "output_lengths_host": gb["lengths"].cpu(),
              "attn_prior": BetaBinomialInterpolator(device=dev).batch(in_lens, [T] * B),
              "f0": gb["f0"], "energy_avg": gb["energy"]}
-    opt = FlatRAdam(model.named_parameters(), lr=1e-6, weight_decay=1e-6)       # tiny lr: the loss stays put
+    reducer = BucketedGradReducer(model)
+    opt = FlatRAdam(model.named_parameters(), lr=1e-6, weight_decay=1e-6, reducer=reducer)   # tiny lr: the loss stays put
 
     def step():
-        opt.zero_grad()
+        reducer.prepare()
         loss, losses, _ = model.training_step(batch, global_step=10)
         loss.backward()
+        reducer.finish()
         opt.clip_grad_norm(1.0)
         opt.step()
         return loss
@@ -672,6 +678,7 @@ def main():
                                       "loss_mel": l16, "loss_rel_diff_vs_parity_mode": abs(l16 - loss_val) / abs(loss_val),
                                       "within_parity_bar": False}
         if world == 1 and args.full_step:
+            reducer.detach()                          # the step-wide reducer of that leg takes over the decoder's parameters
             res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms)
         # what the split producers reported over the whole run (ops.GradScale; published without host synchronisation)
         gs = getattr(dec, "_grad_scale", None)

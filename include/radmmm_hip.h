@@ -400,6 +400,19 @@ int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, 
  * per process) when data-parallel runs leave CUs to RCCL's channel kernels (Lightning `strategy: ddp`,
  * configs/RADMMM_train_config.yaml:28; rad_mmm_amd/ddp.py reserve_collective_cus). */
 int radmmm_gemm_cu_slots(void);
+/* ------------------------------------------------------------------------------------
+ * CTC loss of the alignment attention (loss.py:112-141: torch.nn.CTCLoss, blank 0, zero_infinity, with the targets
+ * 1, 2, .., L_b -- every text position once, in order) for a whole batch, value and gradient in one launch.
+ *   lp [B][T][C] log-probabilities (log-softmax outputs, class 0 = blank), lens_txt[b] = L_b <= C - 1, lens_mel[b] = T_b <= T
+ *   nll [B]: -log p(targets | frames 0 .. T_b - 1), or 0 where no alignment exists (T_b < L_b)
+ *   grad [B][T][C]: d nll[b] / d lp as torch's ctc_loss_backward defines it (exp(lp) - exp(log-sum alpha*beta + nll - lp);
+ *   0 for frames >= T_b and for utterances without alignment)
+ *   scratch: radmmm_ctc_monotonic_scratch_floats(B, T, C) floats.  At most 511 text positions.
+ * ------------------------------------------------------------------------------------ */
+int64_t radmmm_ctc_monotonic_scratch_floats(int B, int T, int C);
+int radmmm_ctc_monotonic(const float* lp, const int32_t* lens_txt, const int32_t* lens_mel, float* nll, float* grad,
+                         float* scratch, int B, int T, int C, radmmm_stream_t stream);
+
 /* A HIP stream whose kernels may use only `enabled_cus` of the device's CUs (hipExtStreamCreateWithCUMask); *out receives
  * the hipStream_t (wrap it, e.g. torch.cuda.ExternalStream).  radmmm_stream_destroy releases it. */
 int radmmm_stream_create_masked(int enabled_cus, void** out);

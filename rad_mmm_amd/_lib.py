@@ -162,6 +162,7 @@ def _load() -> C.CDLL:
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_stream_create_masked": [i, C.POINTER(C.c_void_p)],
         "radmmm_stream_destroy": [p],
+        "radmmm_ctc_monotonic": [p, p, p, p, p, p, i, i, i, p],
         "radmmm_lstm_bwd": [p, p, p, p, p, p, p, p, i, i, i, p, p],
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, so, p],
@@ -184,7 +185,7 @@ def _load() -> C.CDLL:
         fn.restype = C.c_int
     for name, args in {"radmmm_colsum_scratch_floats": [i, i], "radmmm_rowgemm_h3_colsum_scratch_floats": [i, i],
                        "radmmm_masked_reduce_scratch_floats": [i, i, i],
-                       "radmmm_mas_scratch_bytes": [i, i, i],
+                       "radmmm_mas_scratch_bytes": [i, i, i], "radmmm_ctc_monotonic_scratch_floats": [i, i, i],
                        "radmmm_film_bwd_scratch_floats": [i, i],
                        "radmmm_stft_mel_scratch_floats": [i, i, i, i, i],
                        "radmmm_lstm_scratch_bytes": [i, i, i], "radmmm_lstm_hseq_bytes": [i, i, i],

@@ -50,7 +50,7 @@ class ConvAttention(nn.Module):
         for i, key in enumerate(sorted(layers.keys(), key=int)):
             c = layers[key].conv
             x = ops.conv_norm(x, c.weight_v, c.weight_g, c.bias, None, B, T, dil=1, partial=False, mask_out=False,
-                              act="relu" if i < n - 1 else "none")
+                              act="relu" if i < n - 1 else "none", scale_box=ops.module_scale_box(self))
         return x
 
     @fp32_region
@@ -62,6 +62,7 @@ class ConvAttention(nn.Module):
             raise RuntimeError("rad_mmm_amd.attention.ConvAttention runs on an MI355X only (no CPU path)")
         B, _, T1 = queries.shape
         T2 = keys.shape[2]
+        ops.module_scale_box(self, new_forward_on=queries.device)
         k = self._proj(self.key_proj, self._cl(keys), B, T2)
         q = self._proj(self.query_proj, self._cl(queries), B, T1)
         Ca = self.query_proj["4"].conv.weight_v.shape[0]

@@ -21,9 +21,11 @@ from . import ops
 from ._lib import ACT, SCALE, debug_env
 
 
-def get_mask_from_lengths(lengths: torch.Tensor) -> torch.Tensor:
-    """bool [B, max_len]; reference common.py:105-116."""
-    max_len = int(torch.max(lengths).item())
+def get_mask_from_lengths(lengths: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
+    """bool [B, max_len]; reference common.py:105-116.  max_len: the largest length when the caller holds it on the host
+    (without it one device -> host read)."""
+    if max_len is None:
+        max_len = int(torch.max(lengths).item())
     ids = torch.arange(0, max_len, device=lengths.device)
     return ids < lengths.unsqueeze(1)
 
@@ -32,9 +34,11 @@ class SequenceLength:
     """Sequence lengths + mask (reference common.py:123-128).  Also keeps a host copy of the
     lengths so later stages do not need another device->host sync."""
 
-    def __init__(self, lengths: torch.Tensor):
+    def __init__(self, lengths: torch.Tensor, lengths_host: Optional[torch.Tensor] = None):
+        """lengths_host: the same lengths as a CPU tensor when the caller has them (the collate function builds them on the
+        host before the batch is moved): saves the device -> host read, i.e. a synchronisation per step."""
         self.lengths = lengths.long()
-        self.lengths_host = self.lengths.cpu()
+        self.lengths_host = self.lengths.cpu() if lengths_host is None else lengths_host.long().cpu()
         max_len = int(self.lengths_host.max())
         ids = torch.arange(0, max_len, device=lengths.device)
         self.mask = ids < self.lengths.unsqueeze(1)
@@ -99,6 +103,7 @@ class DataInitializedInvertible1x1Conv(nn.Module):
         self.upper_diag = nn.Parameter(torch.diag(upper).clone())
         self.upper = nn.Parameter(torch.triu(upper, 1))
         self.cache_inverse = cache_inverse
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.__dict__.pop("_init_seen", None))
 
     @torch.no_grad()
     def initialize(self, z_cl: torch.Tensor, lens: SequenceLength, T: int):

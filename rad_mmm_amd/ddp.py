@@ -90,6 +90,7 @@ class BucketedGradReducer:
                 groups.setdefault(bucket_key(name), []).append((bool(direct(name)) and p.is_cuda, p))
         self.buckets: List[Dict] = []
         self._by_param: Dict[int, Dict] = {}
+        self._hook_handles: List = []
         self._views: Dict[int, torch.Tensor] = {}
         self._direct: Dict[int, bool] = {}
         for key, tagged in groups.items():
@@ -109,7 +110,7 @@ class BucketedGradReducer:
             self.buckets.append(b)
             for p in params:
                 self._by_param[id(p)] = b
-                p.register_post_accumulate_grad_hook(self._make_hook(b))
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
         self.total_bytes = sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
         # Collectives are issued in ONE fixed, rank-independent order: the reverse of the registration order, which is the
         # order backward completes the buckets in (last flow first, the context LSTM / everything upstream last).  A
@@ -213,6 +214,14 @@ class BucketedGradReducer:
         self._sink_keys = []
         if self._grads_final in ops.GRAD_FINAL_HOOKS:
             ops.GRAD_FINAL_HOOKS.remove(self._grads_final)
+
+    def detach(self) -> None:
+        """Remove this reducer's hooks and sinks from the module (another reducer, e.g. one around a parent module, can
+        then be built over the same parameters); the parameters keep their last .grad views."""
+        self._drop_sinks()
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
 
     def finish(self) -> None:
         """Wait for the outstanding reductions and turn sums into means (call after backward)."""

@@ -74,9 +74,13 @@ class FlowStep(nn.Module):
     def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
                    scale_box=None):
         conv = self.invtbl_conv
-        if isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not bool(conv.initialized):
-            conv.initialize(z_cl[:, col_offset:], seq_lens, T)
-            print("initialized invertible conv")
+        # (`initialized` is a device buffer: it is read once -- a host synchronisation -- and remembered; loading a state_dict
+        #  forgets the answer)
+        if (isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not conv.__dict__.get("_init_seen", False)):
+            if not bool(conv.initialized):
+                conv.initialize(z_cl[:, col_offset:], seq_lens, T)
+                print("initialized invertible conv")
+            conv.__dict__["_init_seen"] = True
         if isinstance(conv, Invertible1x1ConvLUS):
             W_eff, log_det_W = conv.weight_and_log_det(ZLD, col_offset)
             b_eff = self._zero_bias(W_eff)

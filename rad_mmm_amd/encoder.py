@@ -81,22 +81,24 @@ class Encoder(nn.Module):
             hook(self.lstm, ())
 
     @fp32_region
-    def forward(self, x, in_lens):
-        """x [B, C, L] padded text embeddings, in_lens [B] -> [B, max(in_lens), C]."""
+    def forward(self, x, in_lens, max_len=None):
+        """x [B, C, L] padded text embeddings, in_lens [B] -> [B, max(in_lens), C].  max_len = max(in_lens) when the caller
+        holds it on the host (otherwise one device -> host read)."""
         if not x.is_cuda:
             raise RuntimeError("rad_mmm_amd.encoder.Encoder runs on an MI355X only (no CPU path)")
         B, C, L = x.shape
         lens32 = in_lens.to(device=x.device, dtype=torch.int32).contiguous()
+        ops.module_scale_box(self, new_forward_on=x.device)
         h = x.float().permute(0, 2, 1).reshape(B * L, C).contiguous()
         for holder, inorm in self.convolutions:
             c = holder.conv
             h = ops.conv_norm(h, c.weight_v, c.weight_g, c.bias, lens32, B, L, dil=1, partial=True, mask_out=True,
-                              act="none")
+                              act="none", scale_box=ops.module_scale_box(self))
             h = InstanceNormReluFn.apply(h, inorm.weight, inorm.bias, lens32, B, L, C, True)
             h = F.dropout(h, 0.5, self.training)
         self._lstm_weights_ready()
         y = bilstm(self.lstm, h.view(B, L, C), lens32)
-        return y[:, : int(in_lens.max())]
+        return y[:, : (int(in_lens.max()) if max_len is None else int(max_len))]
 
     @fp32_region
     def infer(self, x):

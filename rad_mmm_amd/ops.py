@@ -623,6 +623,31 @@ def mas_width1_batch(logp: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.
     return hard
 
 
+class CTCMonotonicFn(torch.autograd.Function):
+    """nll [B] of torch's CTC loss (blank 0, zero_infinity) for the targets 1 .. L_b, from log-probabilities lp [B, T, C]
+    (class 0 = blank); value and gradient come out of ONE launch (radmmm_ctc_monotonic: a wave per utterance, no host
+    synchronisation), the backward scales the stored gradient."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, lp, lens_txt, lens_mel):
+        B, T, C = lp.shape
+        lp = f32c(lp)
+        nll = _empty(B, like=lp)
+        grad = torch.empty_like(lp)
+        scratch = _empty(int(lib.radmmm_ctc_monotonic_scratch_floats(B, T, C)), like=lp)
+        check(lib.radmmm_ctc_monotonic(ptr(lp), ptr(lens_txt), ptr(lens_mel), ptr(nll), ptr(grad), ptr(scratch), B, T, C,
+                                       stream()), "ctc_monotonic")
+        ctx.save_for_backward(grad)
+        return nll
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.reshape(-1, 1, 1), None, None
+
+
 def stft_mel(audio: torch.Tensor, basis: torch.Tensor, mel_basis: torch.Tensor, n_fft: int, hop: int,
              clip: float = 1e-5) -> torch.Tensor:
     """audio [B,S] -> log-mel [B, n_mel, 1+S//hop] (audio_processing.py:137-154)."""
@@ -1053,6 +1078,18 @@ class GradScale:
             if (f_fwd | f_bwd) & 1:
                 raise FloatingPointError("split-f16 gradient saturated: a gradient element exceeds 2^12 x the first gradient's "
                                          "maximum of this backward pass and was clamped")
+
+
+def module_scale_box(module, new_forward_on=None) -> "GradScale":
+    """The GradScale a module outside the decoder (text encoder, alignment attention) keeps for its stand-alone conv_norm
+    calls: with a throw-away dict every conv's backward reads its gradient's maximum on the host -- a synchronisation per
+    conv and step.  new_forward_on = device: mark the start of a training forward (publishes the previous pass's stats)."""
+    box = module.__dict__.get("_scale_box")
+    if box is None:
+        box = module.__dict__["_scale_box"] = GradScale()
+    if new_forward_on is not None and torch.is_grad_enabled():
+        box.new_forward(new_forward_on)
+    return box
 
 
 def grad_scale(box, g: torch.Tensor) -> float:

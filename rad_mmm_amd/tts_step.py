@@ -67,17 +67,21 @@ class TTSTrainingStep(nn.Module):
     def encode_accent(self, accent_ids):
         return self.accent_embeddings(accent_ids)
 
-    def encode_text(self, text, in_lens, accent_vecs=None):
+    def encode_text(self, text, in_lens, accent_vecs=None, max_len=None):
         emb = self.text_embeddings(text).transpose(1, 2)
         x = emb
         if accent_vecs is not None:
             x = torch.cat((emb, accent_vecs[..., None].expand(-1, -1, emb.shape[-1])), 1)
-        enc = self.text_encoder.infer(x) if in_lens is None else self.text_encoder(x, in_lens)
+        from .encoder import Encoder as _HipEncoder
+        enc = self.text_encoder.infer(x) if in_lens is None else (
+            self.text_encoder(x, in_lens, max_len) if (max_len is not None and isinstance(self.text_encoder, _HipEncoder))
+            else self.text_encoder(x, in_lens))
         return enc.transpose(1, 2), emb
 
     # ---- tts_lightning_modules.py:440-475 ------------------------------------------------------
-    def compute_attention(self, mel, txt_emb, spk_vecs, accent_vecs, out_lens, in_lens, attn_prior, binarize=False):
-        attn_mask = get_mask_from_lengths(in_lens)[..., None] == 0
+    def compute_attention(self, mel, txt_emb, spk_vecs, accent_vecs, out_lens, in_lens, attn_prior, binarize=False,
+                          max_in_len=None):
+        attn_mask = get_mask_from_lengths(in_lens, max_in_len)[..., None] == 0
         keys = txt_emb
         if self.use_accent_emb_for_alignment:
             keys = torch.cat((keys, accent_vecs[:, :, None].expand(-1, -1, txt_emb.shape[2]).detach()), 1)
@@ -99,15 +103,18 @@ class TTSTrainingStep(nn.Module):
         input_lengths, output_lengths, attn_prior, f0, energy_avg (+ voiced_mask, speaker_f0_mean/std when
         the attribute predictors are attached).  Returns (loss, {name: (value, weight)}, outputs)."""
         binarize = self.binarize = global_step >= self.binarization_start_iter
-        in_lens = SequenceLength(batch["input_lengths"])
-        out_lens = SequenceLength(batch["output_lengths"])
+        # (the batch may carry host copies of the lengths -- the collate function has them before the batch moves to the
+        #  device -- as "input_lengths_host" / "output_lengths_host": no device -> host read, i.e. no synchronisation, then)
+        in_lens = SequenceLength(batch["input_lengths"], batch.get("input_lengths_host"))
+        out_lens = SequenceLength(batch["output_lengths"], batch.get("output_lengths_host"))
+        max_in = int(in_lens.lengths_host.max())
         mel = self.mel_scale(batch["mel"])
         spk_vecs = self.encode_speaker(batch["speaker_ids"])
         accent_vecs = self.encode_accent(batch["accent_ids"]) if self.use_accent else None
         txt_enc, txt_emb = self.encode_text(batch["text"], in_lens.lengths,
-                                            accent_vecs if self.use_accent_emb_for_encoder else None)
+                                            accent_vecs if self.use_accent_emb_for_encoder else None, max_in)
         attn, attn_soft, _, attn_logprob = self.compute_attention(
-            mel, txt_emb, spk_vecs, accent_vecs, out_lens.lengths, in_lens.lengths, batch["attn_prior"], binarize)
+            mel, txt_emb, spk_vecs, accent_vecs, out_lens.lengths, in_lens.lengths, batch["attn_prior"], binarize, max_in)
         context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
         f0, energy_avg = batch.get("f0"), batch.get("energy_avg")
         outputs = self.decoder(mel, spk_vecs, context, out_lens, f0=f0, energy_avg=energy_avg, accent_vecs=accent_vecs)
@@ -156,15 +163,18 @@ class TTSTrainingStep(nn.Module):
         """tts_lightning_modules.py:752-860: the same pass without gradients; the decoder criterion is evaluated
         at step 100000 (all loss terms on), alignments are binarized when training last was (`self.binarize`),
         and the predictors see the un-detached context.  `global_step` only reaches the predictor losses."""
-        in_lens = SequenceLength(batch["input_lengths"])
-        out_lens = SequenceLength(batch["output_lengths"])
+        # (the batch may carry host copies of the lengths -- the collate function has them before the batch moves to the
+        #  device -- as "input_lengths_host" / "output_lengths_host": no device -> host read, i.e. no synchronisation, then)
+        in_lens = SequenceLength(batch["input_lengths"], batch.get("input_lengths_host"))
+        out_lens = SequenceLength(batch["output_lengths"], batch.get("output_lengths_host"))
+        max_in = int(in_lens.lengths_host.max())
         mel = self.mel_scale(batch["mel"])
         spk_vecs = self.encode_speaker(batch["speaker_ids"])
         accent_vecs = self.encode_accent(batch["accent_ids"]) if self.use_accent else None
         txt_enc, txt_emb = self.encode_text(batch["text"], in_lens.lengths,
-                                            accent_vecs if self.use_accent_emb_for_encoder else None)
+                                            accent_vecs if self.use_accent_emb_for_encoder else None, max_in)
         attn, attn_soft, _, attn_logprob = self.compute_attention(
-            mel, txt_emb, spk_vecs, accent_vecs, out_lens.lengths, in_lens.lengths, batch["attn_prior"], self.binarize)
+            mel, txt_emb, spk_vecs, accent_vecs, out_lens.lengths, in_lens.lengths, batch["attn_prior"], self.binarize, max_in)
         context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
         f0, energy_avg = batch.get("f0"), batch.get("energy_avg")
         outputs = self.decoder(mel, spk_vecs, context, out_lens, f0=f0, energy_avg=energy_avg, accent_vecs=accent_vecs)

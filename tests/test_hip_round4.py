@@ -205,3 +205,56 @@ def test_spline_bin_search_index_accounting_at_config5_size():
         tie_q = mism[sub].unsqueeze(-1).expand_as(gqo)
         worst_tie = float((gqh - gqo)[tie_q].abs().max()) / scale
         print(f"  parameter gradient at the tie elements differs by up to {worst_tie:.2e} of the tensor max (the other one-sided derivative)")
+
+
+@pytest.mark.parametrize("B,T,Lmax,case", [(6, 97, 23, "ragged"), (32, 800, 150, "bench"), (4, 640, 511, "longest"),
+                                           (3, 40, 9, "impossible"), (2, 33, 1, "one_symbol")])
+def test_ctc_monotonic_matches_torch_ctc(B, T, Lmax, case):
+    """radmmm_ctc_monotonic (csrc/ctc.hip: targets 1 .. L_b, one wave per utterance, value + gradient in one launch) against
+    torch's CTC on the CPU in float64 for the value and float32 for the gradient formula (reference: common.py:441-464 feeds
+    nn.CTCLoss(zero_infinity=True) one utterance at a time).  Ragged text and mel lengths, the longest text the kernel takes
+    (511 symbols: 1023 states, 16 per lane), an utterance whose mel is shorter than its text (infinite loss -> 0 and a zero
+    gradient, zero_infinity) and a one-symbol text."""
+    import torch.nn.functional as F
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T + Lmax)
+    C = Lmax + 1
+    lt = torch.randint(max(1, Lmax // 2), Lmax + 1, (B,), generator=g)
+    lm = torch.randint(max(int(lt.max()), T // 2), T + 1, (B,), generator=g)
+    lt[0], lm[0] = Lmax, T
+    if case == "impossible":
+        lm[1] = int(lt[1]) - 1                                          # fewer frames than symbols
+    if case == "longest":
+        lm[1] = int(lt[1])                                              # exactly one alignment: no blanks at all
+    logits = torch.randn(B, T, C, generator=g) * 2.0
+    cls = torch.arange(C)
+    logits = logits.masked_fill(cls[None, None, :] > lt[:, None, None], -1e4)
+    lp0 = torch.log_softmax(logits, -1)
+    lp_d = lp0.to(DEV).requires_grad_(True)
+    nll = ops.CTCMonotonicFn.apply(lp_d, lt.to(DEV, torch.int32), lm.to(DEV, torch.int32))
+    wgt = torch.rand(B, generator=g) + 0.5
+    (nll * wgt.to(DEV)).sum().backward()
+    targets = cls[1:][None].expand(B, -1)
+    lp64 = lp0.double().requires_grad_(True)
+    ref64 = F.ctc_loss(lp64.transpose(0, 1), targets, lm, lt, blank=0, reduction="none", zero_infinity=True)
+    (ref64 * wgt.double()).sum().backward()
+    lp32 = lp0.clone().requires_grad_(True)
+    ref32 = F.ctc_loss(lp32.transpose(0, 1), targets, lm, lt, blank=0, reduction="none", zero_infinity=True)
+    (ref32 * wgt).sum().backward()
+    got, gg = nll.detach().cpu(), lp_d.grad.cpu()
+    if case == "impossible":
+        assert float(got[1]) == 0.0 and float(ref32[1].detach()) == 0.0
+        assert float(gg[1].abs().max()) == 0.0
+    err_hip = float(((got.double() - ref64.detach()).abs() / ref64.detach().abs().clamp_min(1.0)).max())
+    err_t32 = float(((ref32.detach().double() - ref64.detach()).abs() / ref64.detach().abs().clamp_min(1.0)).max())
+    print(f"ctc {case}: nll rel. error vs float64  hip {err_hip:.2e}   torch float32 {err_t32:.2e}")
+    assert err_hip < max(4 * err_t32, 2e-6)
+    # gradient: torch's float32 formula is exp(lp) - exp(log(alpha beta sum) + nll - lp); compare both with float64
+    scale = float(lp64.grad.abs().max())
+    e_hip = float((gg.double() - lp64.grad).abs().max()) / scale
+    e_t32 = float((lp32.grad.double() - lp64.grad).abs().max()) / scale
+    print(f"      gradient max abs error / max vs float64  hip {e_hip:.2e}   torch float32 {e_t32:.2e}")
+    assert e_hip < max(4 * e_t32, 1e-5)
+    # frames beyond each utterance's mel length carry exactly zero gradient (torch's rule)
+    for b in range(B):
+        assert float(gg[b, int(lm[b]):].abs().max() if int(lm[b]) < T else 0.0) == 0.0
