@@ -363,7 +363,8 @@ int radmmm_mas_width1(const float* logp, const int32_t* in_lens, const int32_t* 
                       float* hard, void* scratch, int B, int T1, int T2, radmmm_stream_t stream);
 /* Same search on PROBABILITIES attn [B, T1, T2] (TTSModel.binarize_attention, tts_lightning_modules.py:270-284,
  * hands alignment.py:31 the soft attention and the log is taken inside, alignment.py:36): the kernel takes the log
- * itself, correctly rounded to fp32, so no log tensor is materialised. */
+ * itself, correctly rounded to fp32 (a first launch over the whole chip, into `scratch`; the search itself is a chain
+ * of T1 dependent steps per utterance and keeps nothing but an LDS row exchange and a ballot in each). */
 int radmmm_mas_width1_prob(const float* attn, const int32_t* in_lens, const int32_t* out_lens,
                            float* hard, void* scratch, int B, int T1, int T2, radmmm_stream_t stream);
 int64_t radmmm_mas_scratch_bytes(int B, int T1, int T2);
@@ -402,7 +403,7 @@ int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, 
 int radmmm_gemm_cu_slots(void);
 /* ------------------------------------------------------------------------------------
  * CTC loss of the alignment attention (loss.py:112-141: torch.nn.CTCLoss, blank 0, zero_infinity, with the targets
- * 1, 2, .., L_b -- every text position once, in order) for a whole batch, value and gradient in one launch.
+ * 1, 2, .., L_b -- every text position once, in order) for a whole batch, value and gradient in one call (two launches, no host read).
  *   lp [B][T][C] log-probabilities (log-softmax outputs, class 0 = blank), lens_txt[b] = L_b <= C - 1, lens_mel[b] = T_b <= T
  *   nll [B]: -log p(targets | frames 0 .. T_b - 1), or 0 where no alignment exists (T_b < L_b)
  *   grad [B][T][C]: d nll[b] / d lp as torch's ctc_loss_backward defines it (exp(lp) - exp(log-sum alpha*beta + nll - lp);

@@ -561,9 +561,10 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act],
                 scale_box=scale_box if scale_box is not None else {})
     Cout, Cin, taps = v.shape
-    # split-f16 path for the frame-rate convs (FiLM stacks: N = B*T' rows); text-rate convs (encoder,
-    # attention projections: a few thousand rows, negligible cost) stay on the fp32-MFMA kernels
-    min_rows = int(debug_env("RADMMM_CONVNORM_H3_MIN_ROWS", "8192"))
+    # split-f16 path (three f16 products: 2e-6 of fp32) for the frame-rate convs (FiLM stacks: N = B*T' rows) and, since
+    # round 4, the text-rate ones of a batch (text encoder, key projection: B * T_txt = 4800 rows at the benchmark batch --
+    # on the fp32-MFMA kernels they were 2.2 ms of the full step, 0.9 ms more than here); single utterances stay on fp32 MFMA
+    min_rows = int(debug_env("RADMMM_CONVNORM_H3_MIN_ROWS", "1024"))
     prec = os.environ.get("RADMMM_PRECISION", "f8x")
     # "f8x" (FP8 cross terms) is for the WN stack of the affine flows; the FiLM convs of the spline flows keep the three
     # f16 products: the piecewise-quadratic transform's log-Jacobian amplifies errors of its 65 parameters per element
@@ -625,8 +626,8 @@ def mas_width1_batch(logp: torch.Tensor, in_lens: torch.Tensor, out_lens: torch.
 
 class CTCMonotonicFn(torch.autograd.Function):
     """nll [B] of torch's CTC loss (blank 0, zero_infinity) for the targets 1 .. L_b, from log-probabilities lp [B, T, C]
-    (class 0 = blank); value and gradient come out of ONE launch (radmmm_ctc_monotonic: a wave per utterance, no host
-    synchronisation), the backward scales the stored gradient."""
+    (class 0 = blank); value and gradient come out of one call (radmmm_ctc_monotonic: the alpha and beta chains side by
+    side, then an elementwise gradient launch; no host synchronisation), the backward scales the stored gradient."""
 
     @staticmethod
     @amp_fwd

@@ -48,20 +48,27 @@ def main():
                        "kernels": {n: {"calls": c, "total_ms": t / 1e6, "avg_us": a / 1e3,
                                        "ms_per_step": (t / 1e6 / steps) if steps else None} for n, c, t, a in rows}}, f, indent=1)
     if gaps:
-        ev = db.execute(f"select d.start, d.end from {kd} d order by d.start").fetchall()
+        ev = db.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
         ev = ev[int(len(ev) * 0.4):]                                  # the timed steps at the end of the run
         span = ev[-1][1] - ev[0][0]
-        busy, idle, cur_end = 0, [], ev[0][0]
-        for s0, e0 in ev:
+        busy, idle, cur_end, big, prev_name = 0, [], ev[0][0], [], ""
+        for s0, e0, name in ev:
             if s0 > cur_end:
                 idle.append(s0 - cur_end)
+                if s0 - cur_end > 1e5:
+                    big.append((s0 - cur_end, prev_name, name))
             busy += max(0, e0 - max(s0, cur_end))
+            if e0 >= cur_end:
+                prev_name = name
             cur_end = max(cur_end, e0)
         print(f"\nlast {len(ev)} dispatches: span {span / 1e6:.2f} ms, some kernel running {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %), "
               f"idle {sum(idle) / 1e6:.2f} ms in {len(idle)} gaps")
         for lo, hi in ((0, 2e3), (2e3, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e12)):
             g = [x for x in idle if lo <= x < hi]
             print(f"  gaps {lo / 1e3:6.0f} .. {hi / 1e3 if hi < 1e12 else float('inf'):6.0f} us: {len(g):6d}  total {sum(g) / 1e6:7.3f} ms")
+        short = lambda n: n.replace("_ZN12_GLOBAL__N_1", "").replace("_ZN2at6native", "at:")[:48]
+        for g, a, b in sorted(big, reverse=True)[:40]:
+            print(f"    {g / 1e3:8.0f} us   after {short(a):48s} before {short(b)}")
     if hist:
         durs = [r[0] / 1e3 for r in db.execute(
             f"select d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id where s.kernel_name like ?",
