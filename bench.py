@@ -367,12 +367,66 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=
     finally:
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
+    # where the step's time goes: HIP events at the section boundaries of one more step (forward sections by wrapping the
+    # step's own methods; the backward is cut where the gradient of `context` -- the last thing the decoder's backward
+    # produces -- is handed to the attention / text-encoder part)
+    marks = {}
+
+    def ev(name):
+        marks[name] = torch.cuda.Event(enable_timing=True)
+        marks[name].record()
+
+    class _Mark(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            ev("bwd_context_grad")
+            return g
+
+    def wrap(obj, name, before, after):
+        fn = getattr(obj, name)
+
+        def inner(*a, **k):
+            ev(before)
+            out = fn(*a, **k)
+            ev(after)
+            return out
+        setattr(obj, name, inner)
+        return lambda: delattr(obj, name) if name in obj.__dict__ else None
+    undo = [wrap(model, "encode_text", "enc0", "enc1"), wrap(model, "compute_attention", "att0", "att1")]
+    h1 = model.decoder.register_forward_pre_hook(
+        lambda m, a, k: (ev("dec0"), ((a[0], a[1], _Mark.apply(a[2])) + tuple(a[3:]), k))[1], with_kwargs=True)
+    h2 = model.decoder.register_forward_hook(lambda m, a, o: ev("dec1"))
+    ev("t0")
+    reducer.prepare()
+    loss, _, _ = model.training_step(batch, global_step=10)
+    ev("fwd_end")
+    loss.backward()
+    reducer.finish()
+    ev("bwd_end")
+    opt.clip_grad_norm(1.0)
+    opt.step()
+    ev("opt_end")
+    torch.cuda.synchronize()
+    for u in undo:
+        u()
+    h1.remove()
+    h2.remove()
+    dt_ = lambda a, b: round(marks[a].elapsed_time(marks[b]), 3)
+    split = {"forward_text_encoder_ms": dt_("enc0", "enc1"), "forward_attention_mas_ms": dt_("att0", "att1"),
+             "forward_decoder_ms": dt_("dec0", "dec1"), "forward_losses_nll_ctc_binarisation_ms": dt_("dec1", "fwd_end"),
+             "backward_losses_and_decoder_ms": dt_("fwd_end", "bwd_context_grad"),
+             "backward_attention_text_encoder_ms": dt_("bwd_context_grad", "bwd_end"),
+             "clip_and_radam_ms": dt_("bwd_end", "opt_end"), "whole_instrumented_step_ms": dt_("t0", "opt_end")}
     return {"what": "TTSTrainingStep.training_step (text encoder + attention + on-device MAS + decoder + NLL/CTC/binarisation "
                     "losses) + backward + clip 1.0 + FlatRAdam; tts_lightning_modules.py:643-750",
             "batch": B, "frames": T, "text_tokens": t_txt, "steps": steps, "statistic": "median", "ms_per_step": ms,
             "value": B * T / (ms * 1e-3), "unit": "mel-frames/s", "loss": float(lv.detach()),
             "decoder_fwd_bwd_ms": decoder_only_ms, "ms_outside_decoder_fwd_bwd": ms - decoder_only_ms,
-            "share_outside_decoder": (ms - decoder_only_ms) / ms, "host_syncs_per_step": n_sync}
+            "share_outside_decoder": (ms - decoder_only_ms) / ms, "host_syncs_per_step": n_sync, "split": split}
 
 
 def main():

@@ -1,2 +1,6 @@
-python -m pytest tests/test_hip_aux.py tests/test_tts_step.py tests/test_hip_edge.py -x -q -m gpu 2>&1 | tail -2
-GRIDS="rowgemm_h3d wgrad_h3 wgrad_rm_ rowgemm16 wgrad_f32 wgrad16 rowgemm_h3_kernel" bash tools/prof_full_step.sh r04_g 2>&1 | tail -1 | cut -c 200-330
+python bench.py --full-step --no-cpu-baseline --no-throughput-mode 2>&1 | tail -1 > gpurun_out/full_h.json
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/full_h.json').read())
+print(d['ms_per_step_median']); print(json.dumps(d['full_step'],indent=1))
+PY
