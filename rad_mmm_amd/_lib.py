@@ -243,8 +243,25 @@ _H3_KEYS = {"Ah", "Al", "lda_h", "Bh", "Bl", "ldb_h", "b_tap_stride_h", "acc_sca
             "extra_a_rows"}
 
 
+# Measurement hook (bench.py's roofline leg): LAUNCH_TIMER(kw) -> True brackets that rowgemm_h3 launch with a pair of HIP
+# events on the stream it is launched on; the pairs collect in LAUNCH_EVENTS.  None (the default) costs one comparison.
+LAUNCH_TIMER = None
+LAUNCH_EVENTS: list = []
+
+
 def rowgemm_h3(**kw) -> None:
     """split-f16 row GEMM: keys of RowGemmDesc (epilogue, shapes) + the split operands."""
+    if LAUNCH_TIMER is not None and LAUNCH_TIMER(kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _rowgemm_h3(kw)
+        e1.record()
+        LAUNCH_EVENTS.append((e0, e1))
+        return
+    _rowgemm_h3(kw)
+
+
+def _rowgemm_h3(kw) -> None:
     d = RowGemmH3Desc()
     d.base.sign = 1
     d.base.taps = 1
