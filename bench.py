@@ -451,7 +451,7 @@ def main():
                          "+ global-norm clip + RAdam on synthetic text/mel, reported under `full_step`")
     ap.add_argument("--rccl-channels", type=int, default=None,
                     help="N > 1: pin RCCL to this many channels (NCCL_MIN/MAX_NCHANNELS) and size the GEMM grids for the "
-                         "remaining CUs; default 8 (rad_mmm_amd.ddp.reserve_collective_cus)")
+                         "remaining CUs; default 16 (rad_mmm_amd.ddp.reserve_collective_cus)")
     ap.add_argument("--step-only", action="store_true",
                     help="profiling aid (tools/prof_step.sh): run warm-up + timed steps, print ms per step and exit -- no roofline "
                          "leg, no extra legs, so that a kernel trace holds nothing but the steps")
@@ -610,6 +610,40 @@ def main():
                          exposed_comm_ms_per_bucket_mean_rank0=([x / len(per_step) for x in per_bucket] if per_bucket else None),
                          bucket_order=[reducer.buckets[i]["key"] for i in reducer._order],
                          bucket_mbytes=[round(reducer.buckets[i]["flat"].numel() * 4 / 1e6, 1) for i in reducer._order])
+        # what the pinned channels deliver: every bucket all-reduced on its own (nothing else running), three times each
+        # -- algorithm bandwidth = bytes / time, bus bandwidth = 2 (n - 1) / n of that (the ring's per-link load)
+        bw = []
+        scratch = {}
+        for i in reducer._order:
+            flat = reducer.buckets[i]["flat"]
+            buf = scratch.setdefault(flat.numel(), torch.empty_like(flat))
+            buf.copy_(flat)
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 3.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gbs = flat.numel() * 4 / (float(t) * 1e-3) / 1e9
+            bw.append({"bucket": reducer.buckets[i]["key"], "ms": round(float(t), 3), "algbw_gbs": round(gbs, 1),
+                       "busbw_gbs": round(gbs * 2 * (world - 1) / max(world, 1), 1)})
+        del scratch
+        exposed_share = float(worst) / median_ms if median_ms else 0.0
+        dist_info.update(allreduce_alone_per_bucket=bw, exposed_comm_share_of_step=exposed_share)
+        if world > 1 and exposed_share > 0.05:
+            note = (f"exposed gradient communication is {100 * exposed_share:.1f} % of the step (> 5 %): the "
+                    f"{os.environ.get('NCCL_MAX_NCHANNELS', 'default')} RCCL channels this run is pinned to (rad_mmm_amd/ddp.py "
+                    "reserve_collective_cus) under-deliver for these buckets, see allreduce_alone_per_bucket.  RCCL fixes its "
+                    "channel count at the first communicator of a process, so the run cannot switch by itself: rerun with "
+                    "--rccl-channels 32 (GEMM grids sized for 224 CUs) or with NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS unset "
+                    "and RADMMM_GEMM_CUS=256 for RCCL's own choice")
+            dist_info["rccl_channel_note"] = note
+            if rank == 0:
+                print("[bench] " + note, file=sys.stderr)
 
     if args.step_only:
         if rank == 0:

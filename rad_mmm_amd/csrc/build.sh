@@ -27,4 +27,14 @@ for p in "${pids[@]:-}"; do
 done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT.tmp"      # only objects of sources that still exist
 mv "$OUT.tmp" "$OUT"
+# housekeeping: objects of sources that no longer exist, and the object caches of other flag sets (each ~3 MB that would
+# travel to the GPU box with every run); RADMMM_KEEP_BUILDS=1 keeps the latter (A/B builds with extra -D flags)
+for o in "$OBJ"/*.o; do
+  [[ -f "$HERE/$(basename "${o%.o}")" ]] || rm -f "$o"
+done
+if [[ "${RADMMM_KEEP_BUILDS:-0}" != "1" ]]; then
+  for d in "$HERE"/build/*/; do
+    [[ "$(basename "$d")" == "$KEY" ]] || rm -rf "$d"
+  done
+fi
 echo "built $OUT"

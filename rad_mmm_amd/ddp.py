@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 
-RCCL_CUS = 8     # CUs left to RCCL's channel kernels in data-parallel runs (see reserve_collective_cus)
+RCCL_CUS = 16    # CUs left to RCCL's channel kernels in data-parallel runs (see reserve_collective_cus)
 
 
 def reserve_collective_cus(n: int = RCCL_CUS, total_cus: int = 256) -> None:
@@ -29,10 +29,14 @@ def reserve_collective_cus(n: int = RCCL_CUS, total_cus: int = 256) -> None:
     The GEMM kernels of this package run ONE workgroup per CU and size their grids to fill whole rounds of the CUs (232 of
     256 for the dominant launch, weight-gradient split-K factors chosen to fill all 256): an all-reduce whose channel
     kernels land during such a launch would push part of the grid into a second round -- up to 2x on that launch.  So the
-    collective gets its own CUs: RCCL is pinned to `n` channels (one workgroup = one CU each; a 106 MB bucket hidden under
-    ~5 ms of one flow step's backward needs ~25 GB/s, far below what 8 channels move over xGMI), and the GEMM grids are
-    sized for `total_cus - n` workgroup slots (RADMMM_GEMM_CUS, read once by libradmmm_hip.so).  Explicit settings of
-    either variable in the environment win."""
+    collective gets its own CUs: RCCL is pinned to `n` channels (one workgroup = one CU each), and the GEMM grids are
+    sized for `total_cus - n` workgroup slots (RADMMM_GEMM_CUS, read once by libradmmm_hip.so).  n = 16 since round 4:
+    the big launches fill 232 - 240 workgroups anyway, so a budget of 240 slots costs the same step time as 248 (measured
+    at one GPU: 44.40 vs 44.39 ms; 232 slots: 46.6 ms) and RCCL gets twice the channels -- a 53 MB bucket hidden under ~3 ms
+    of backward needs ~30 GB/s of algorithm bandwidth, the ~80 MB that can still be in flight when backward returns is
+    exposed at whatever the channels deliver.  Explicit settings of either variable in the environment win.  The channel
+    count cannot be changed once a communicator exists (RCCL reads NCCL_*_NCHANNELS once per process): bench.py reports the
+    measured all-reduce bandwidth per bucket and says so when the exposed communication exceeds 5 % of the step."""
     import os
     os.environ.setdefault("NCCL_MIN_NCHANNELS", str(n))
     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))

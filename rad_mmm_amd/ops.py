@@ -859,6 +859,15 @@ def wgrad_rm8_slabs(gy_pair, g8_exp, x_pair, x8_exp, B, T, Mc, Nc, taps, dil, ac
     return P
 
 
+def _all_reduce_or(flags: torch.Tensor) -> torch.Tensor:
+    """bitwise OR of small non-negative int32 flag words over the ranks of the default process group.  RCCL / NCCL have no
+    BOR reduction (torch raises "Cannot use ReduceOp.BOR with NCCL"): the low 16 bits go out as 0/1 words under MAX."""
+    sh = torch.arange(16, device=flags.device, dtype=flags.dtype)
+    bits = (flags.reshape(-1, 1) >> sh) & 1
+    torch.distributed.all_reduce(bits, op=torch.distributed.ReduceOp.MAX)
+    return (bits << sh).sum(1).to(flags.dtype).reshape(flags.shape)
+
+
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
     a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), the exponent of
@@ -1029,8 +1038,7 @@ class GradScale:
             # publish the stats of the backward that followed the previous forward, then re-arm the flags
             fl = self.flags
             if sync_ranks:
-                fl = self.flags.clone()
-                torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.BOR)          # every rank raises together
+                fl = _all_reduce_or(self.flags)                                              # every rank raises together
             self._host[0:1].copy_(self.amax, non_blocking=True)
             self._host[1:3].copy_(fl.float(), non_blocking=True)
             self._event.record()
@@ -1070,8 +1078,7 @@ class GradScale:
         if self.flags is not None:
             fl = self.flags
             if self._distributed():
-                fl = self.flags.clone()
-                torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.BOR)
+                fl = _all_reduce_or(self.flags)
             f_fwd, f_bwd = (int(v) for v in fl.tolist())
             if f_fwd | f_bwd:
                 self.flags.zero_()

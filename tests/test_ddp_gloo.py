@@ -87,6 +87,11 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    # the saturation flag words travel as a bitwise OR (GradScale, strict + distributed) -- through MAX over 0/1 words,
+    # because RCCL has no BOR reduction
+    from rad_mmm_amd.ops import _all_reduce_or
+    fl = torch.tensor([[1, 4], [2, 4 | 128]][rank], dtype=torch.int32)
+    ok = ok and _all_reduce_or(fl).tolist() == [3, 132] and fl.tolist() == [[1, 4], [2, 132]][rank]
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -131,4 +136,4 @@ def test_collective_cu_reservation_reaches_the_library():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     mx, mn, cus, slots, n = out.stdout.split()[-5:]
-    assert mx == mn == n == "8" and cus == "248" and slots == "248"
+    assert mx == mn == n == "16" and cus == "240" and slots == "240"

@@ -1,6 +1,8 @@
-python bench.py --no-cpu-baseline --no-throughput-mode 2>&1 | tail -1 > gpurun_out/bench_i.json
+RADMMM_BENCH_SPAWN=1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-throughput-mode 2>gpurun_out/spawn_err.txt | tail -1 > gpurun_out/spawn.json
+tail -3 gpurun_out/spawn_err.txt
 python - <<PY
 import json
-d=json.loads(open('gpurun_out/bench_i.json').read())
-print(d['ms_per_step_median']); r=d['roofline']; print({k:r[k] for k in ('achieved','frac','frac_executed','avg_launch_ms','avg_launch_measured','avg_launch_ms_back_to_back')})
+d=json.loads(open('gpurun_out/spawn.json').read())
+print(d['ms_per_step_median']); print(json.dumps(d['distributed'])[:1800])
 PY
+python -m pytest tests/test_ddp_nccl.py -x -q 2>&1 | tail -2
