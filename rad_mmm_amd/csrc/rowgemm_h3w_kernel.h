@@ -17,6 +17,13 @@
 //     rounds of the 256 CUs: 12 800 frames x 1024 channels -> MB = 7 -> 58 x 4 = 232 workgroups
 //     in one round (89 % of the MFMA slots useful; 128-row tiles: 78 %).
 #pragma once
+// timing-only build switches (results wrong): -DRADMMM_EPI_NOSTORE removes the epilogue's stores (its arithmetic stays),
+// -DRADMMM_EPI_NONE the whole epilogue of the window kernel -- what the launch costs without them (tools/epi_cost.sh)
+#ifdef RADMMM_EPI_NOSTORE
+#define RADMMM_EPI_STORE(...) ((void)0)
+#else
+#define RADMMM_EPI_STORE(...) __VA_ARGS__
+#endif
 #include <stdlib.h>
 
 #include "common.h"
@@ -168,21 +175,21 @@ __device__ __forceinline__ float store_pair_split(__amdgpu_buffer_rsrc_t rH, __a
   const float r0 = t0 - (float)h0, r1 = t1 - (float)h1;
   f16x2 hp;
   hp[0] = h0; hp[1] = h1;
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hp), rH, vH, sH, 0);
+  RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hp), rH, vH, sH, 0));
   if constexpr (!X8) {
     f16x2 lp;
     lp[0] = (_Float16)r0; lp[1] = (_Float16)r1;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rL, vH, sH, 0);
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rL, vH, sH, 0));
   } else {
     const float lm = x8_mul * 2048.f;
     const int w8h = __builtin_amdgcn_cvt_pk_fp8_f32(radmmm::clamp_e4m3(t0 * x8_mul), radmmm::clamp_e4m3(t1 * x8_mul), 0, false);
     const int w8l = __builtin_amdgcn_cvt_pk_fp8_f32(radmmm::clamp_e4m3(r0 * lm), radmmm::clamp_e4m3(r1 * lm), 0, false);
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8h, rL, vXh, sH, 0);
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8l, rL, vXl, sH, 0);
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8h, rL, vXh, sH, 0));
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8l, rL, vXl, sH, 0));
     if (has_lo16) {
       f16x2 lp;
       lp[0] = (_Float16)r0; lp[1] = (_Float16)r1;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rLo16, vH, sH, 0);
+      RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rLo16, vH, sH, 0));
     }
   }
   return amax;
@@ -286,11 +293,11 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
       x1 = actf(x1 * rf.z);
       f32x2 y;
       y[0] = x0; y[1] = x1;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0);
+      RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0));
       if constexpr (C2M) {
         f32x2 c2;
         c2[0] = side[e][0] + x0; c2[1] = side[e][1] + x1;          // (side reads as zero when not accumulating)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0);
+        RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0));
         if (c2split)
           sat = fmaxf(sat, store_pair_split<X8>(rH, rL, rLo16, false, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, c2[0], c2[1]));
       }

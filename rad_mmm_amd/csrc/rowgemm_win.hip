@@ -328,8 +328,19 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     rowf4[tid] = make_float4(q.acc_scale * pre, post, rsc, 0.f);
   }
   __syncthreads();
+#ifdef RADMMM_EPI_NONE
+  {                                                                    // (timing only: keep the accumulators alive)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[i][0][e] + acc[i][1][e];
+    if (s == 1.2345e-30f) p.C[0] = s;
+  }
+#else
   direct_epilogue<MB, EK, true>(acc, rowf4, p, m0, n0, lane, wave, sat);
   radmmm::raise_sat_flag(p.sat_flag, sat, (p.Ch && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, p.ch_x8_exp) : 0.f);
+#endif
 }
 
 template <int MB, int EK, bool XT>
