@@ -2,6 +2,7 @@
   * the one-tap GEMM kernel (csrc/rowgemm_one.hip, rowgemm_onetap.h: three A stages, wave-private B, slot-pinned K loop)
     against the per-tap-tile kernel (rowgemm_h3d) -- same operands, same MFMAs in the same order per accumulator: the
     outputs must be IDENTICAL bit for bit, for every epilogue kind, tile height and a ragged batch with masked input rows."""
+import numpy as np
 import pytest
 import torch
 
@@ -258,3 +259,38 @@ def test_ctc_monotonic_matches_torch_ctc(B, T, Lmax, case):
     # frames beyond each utterance's mel length carry exactly zero gradient (torch's rule)
     for b in range(B):
         assert float(gg[b, int(lm[b]):].abs().max() if int(lm[b]) < T else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("B,T1,T2,case", [(5, 64, 1, "one_text_position"), (4, 1, 7, "one_frame"), (6, 333, 65, "wave_boundary"),
+                                          (3, 257, 640, "ten_waves"), (2, 90, 1030, "wider_than_a_workgroup"),
+                                          (2, 3000, 500, "bits_exceed_lds"), (4, 40, 64, "text_longer_than_mel")])
+def test_mas_chain_kernel_edge_shapes_are_bit_exact(B, T1, T2, case):
+    """INDEX WORK (alignment.py:31-59).  The round-4 search (csrc/attention.hip: log pass + chain kernel with the scores
+    fetched ahead, LDS row exchange, ballot-packed moves in LDS) against the C oracle on the same log array, bit for bit,
+    on the shapes that bend it: one text position, one frame, a text that ends exactly behind a wave boundary, ten waves,
+    a text wider than a workgroup and a map whose move bits exceed LDS (both fall back to the round-1 kernel), more text
+    positions than frames (the reference's loop then ends away from column 0 and opt[0, 0] is still forced to 1), ragged
+    lengths.  Both entry points: caller's log (radmmm_mas_width1) and probabilities (…_prob: correctly rounded log inside)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops
+    r = np.random.Generator(np.random.PCG64(B * 7 + T1 + T2))
+    in_lens = r.integers(max(1, T2 // 2), T2 + 1, B)
+    out_lens = r.integers(max(1, T1 // 2), T1 + 1, B)
+    in_lens[0], out_lens[0] = T2, T1
+    if case == "text_longer_than_mel":
+        out_lens[1], in_lens[1] = 5, 64
+    attn = torch.softmax(torch.from_numpy(r.standard_normal((B, T1, T2)).astype(np.float32) * 3), 2)
+    il = torch.from_numpy(in_lens).to(DEV, torch.int32)
+    ol = torch.from_numpy(out_lens).to(DEV, torch.int32)
+    with np.errstate(divide="ignore"):
+        lp_np = np.log(attn.numpy())
+    hard_lp = ops.mas_width1_batch(torch.from_numpy(lp_np).to(DEV), il, ol).cpu().numpy()
+    hard_pr = ops.mas_width1_batch(attn.to(DEV), il, ol, prob=True).cpu().numpy()
+    for b in range(B):
+        n1, n2 = int(out_lens[b]), int(in_lens[b])
+        a = attn[b, :n1, :n2].numpy().copy()
+        assert np.array_equal(hard_lp[b, :n1, :n2], O.mas_width1_c(a, logp=lp_np[b, :n1, :n2].copy())), (case, b)
+        lp_rn = np.log(a.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(hard_pr[b, :n1, :n2], O.mas_width1_c(a, logp=lp_rn)), (case, b)
+        for h in (hard_lp, hard_pr):                                    # zero outside the utterance's corner
+            assert h[b, n1:].sum() == 0 and h[b, :, n2:].sum() == 0
