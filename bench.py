@@ -787,6 +787,18 @@ def main():
                                       "ms_per_step": dt16 * 1e3, "statistic": "median", "value": B * T / dt16, "unit": "mel-frames/s",
                                       "loss_mel": l16, "loss_rel_diff_vs_parity_mode": abs(l16 - loss_val) / abs(loss_val),
                                       "within_parity_bar": False}
+        hip_out = None
+        if world == 1 and not args.no_cpu_baseline:
+            # the decoder's outputs on the bench batch for `parity_vs_cpu`, taken BEFORE any leg that updates the weights
+            # (the full-step leg and --optimizer run RAdam on them; the oracle runs on the initial state)
+            if opt is not None:
+                dec.load_state_dict(sd)
+            with torch.no_grad():                     # (training mode, default scheme: the step's forward once more, outputs kept)
+                hip_out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+            hip_out = {k: (v.detach().clone() if torch.is_tensor(v) else
+                           [t.detach().clone() if torch.is_tensor(t) else t for t in v] if isinstance(v, (list, tuple)) else v)
+                       for k, v in hip_out.items()}
+            torch.cuda.synchronize()
         if world == 1 and args.full_step:
             reducer.detach()                          # the step-wide reducer of that leg takes over the decoder's parameters
             res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms)
@@ -802,10 +814,7 @@ def main():
                                  "x8_adaptations": gs.x8_adaptations, "x8_grad_exp": gs.x8_grad_exp,
                                  "nonfinite_passes": gs.nonfinite_passes}
         res["roofline_hbm"] = hbm_rooflines(dec, cfg, B, T)
-        if world == 1 and not args.no_cpu_baseline:
-            with torch.no_grad():                     # (training mode, default scheme: the step's forward once more, outputs kept)
-                hip_out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
-            torch.cuda.synchronize()
+        if hip_out is not None:
             res["cpu_baseline"], res["parity_vs_cpu"] = cpu_baseline(cfg, sd, batch, hip_out)
     if use_dist:
         dist.barrier()

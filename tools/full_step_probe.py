@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Only bench.py's full-step leg (TTSTrainingStep.training_step + backward + clip + FlatRAdam on the benchmark batch), for a
-kernel trace of the WHOLE training step (3 warm-up + `steps` timed + 1 sync-counting step = steps + 4 steps in the trace):
+kernel trace of the WHOLE training step (3 warm-up + `steps` timed + 1 sync-counting + 1 section-timing step = steps + 5 steps in the trace):
     rocprofv3 --kernel-trace --stats -d out -- python tools/full_step_probe.py [--steps 7]"""
 import argparse
 import json

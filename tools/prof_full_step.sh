@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -- python "$ROOT/tools/full_step_probe.py" --steps 7 > "$OUT/bench.log" 2>&1
 DB=$(find "$OUT" -name "*.db" | head -1)
 cd "$ROOT"
-python tools/kernel_stats.py "$DB" 11 --gaps --json "gpurun_out/${TAG}_full_step_kernel_stats.json" > "gpurun_out/${TAG}_full_step_kernel_stats.txt" 2>&1
+python tools/kernel_stats.py "$DB" 12 --gaps --json "gpurun_out/${TAG}_full_step_kernel_stats.json" > "gpurun_out/${TAG}_full_step_kernel_stats.txt" 2>&1
 python tools/kernel_grids.py "$DB" ${GRIDS:-rowgemm_h3d_kernelILi8ELi3ELi1 rowgemm16 wgrad_f32 wgrad16} > "gpurun_out/${TAG}_full_step_grids.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 grep -a what "$OUT/bench.log" | cut -c1-600
