@@ -506,6 +506,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test-only: RADMMM_BENCH_SHARE_GPU=1 puts every rank on device 0 and RADMMM_BENCH_BACKEND=gloo reduces through the host,
+    # so that the control flow of an N > 1 run (who issues which collective when) can be exercised on a one-GPU box --
+    # RCCL refuses two ranks on one device (tests/test_ddp_nccl.py)
+    if os.environ.get("RADMMM_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("RADMMM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("RADMMM_FORCE_DIST") == "1"   # the latter: RCCL smoke test on 1 GPU
@@ -517,7 +523,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import rad_mmm_amd  # noqa: F401  (loads libradmmm_hip.so; no fallback)
     from rad_mmm_amd.common import SequenceLength
@@ -650,6 +656,34 @@ def main():
             print(json.dumps({"step_only": True, "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "steps": args.steps,
                               "warmup": args.warmup, "loss": loss_val}))
         return
+    # the dominant kernel's launches INSIDE the training step, each bracketed by HIP events on its stream, over three more
+    # steps -- on EVERY rank (a step issues the gradient all-reduces: rank 0 must not run one alone); rank 0 reports its own
+    in_step = []
+    if dec.gemm_precision in ("h3", "f8x"):
+        from rad_mmm_amd import _lib as L
+        Nrows = B * (T // cfg.n_group_size)
+        L.LAUNCH_EVENTS.clear()
+        L.LAUNCH_TIMER = lambda kw: (kw.get("taps") == 5 and kw.get("N") == 1024 and kw.get("K") == 1024 and kw.get("M") == Nrows
+                                     and kw.get("Ch") is not None and kw.get("dact") is None and "act" in kw)
+        for _ in range(3):
+            step()
+        L.LAUNCH_TIMER = None
+        torch.cuda.synchronize()
+        in_step = [a.elapsed_time(b) * 1e-3 for a, b in L.LAUNCH_EVENTS]
+        L.LAUNCH_EVENTS.clear()
+
+    def saturation_report():
+        gs = getattr(dec, "_grad_scale", None)
+        if gs is None:
+            return None
+        torch.cuda.synchronize()
+        try:
+            gs.check()                                # (consumes what is still in flight; under a process group it
+        except FloatingPointError:                    #  all-reduces the flag words: every rank has to call it)
+            pass
+        return {"saturated_passes": gs.saturated_passes, "x8_saturated_passes": gs.x8_saturated_passes,
+                "x8_adaptations": gs.x8_adaptations, "x8_grad_exp": gs.x8_grad_exp, "nonfinite_passes": gs.nonfinite_passes}
+    sat_report = saturation_report() if use_dist else None      # (one GPU: taken at the end, after the side legs)
     if rank == 0:
         N = B * (T // cfg.n_group_size)
         h3 = dec.gemm_precision in ("h3", "f8x")
@@ -664,16 +698,6 @@ def main():
             # chip's power limit (MFMA at full tilt throttles the clock); in the step it alternates with memory-bound
             # kernels.  The in-step average is what rocprofv3's kernel trace of the step shows for this kernel
             # (profiles/r04_kernel_stats.json) and what `achieved` is priced on; the back-to-back figure stays beside it.
-            from rad_mmm_amd import _lib as L
-            L.LAUNCH_EVENTS.clear()
-            L.LAUNCH_TIMER = lambda kw: (kw.get("taps") == 5 and kw.get("N") == 1024 and kw.get("K") == 1024 and kw.get("M") == N
-                                         and kw.get("Ch") is not None and kw.get("dact") is None and "act" in kw)
-            for _ in range(3):
-                step()
-            L.LAUNCH_TIMER = None
-            torch.cuda.synchronize()
-            in_step = [a.elapsed_time(b) * 1e-3 for a, b in L.LAUNCH_EVENTS]
-            L.LAUNCH_EVENTS.clear()
             kdur = float(np.mean(in_step)) if in_step else kdur_iso
             n_in_step = len(in_step)
             # executed MFMA work in f16-equivalent products: 3 f16 products, or 1 f16 + 2 FP8 products at twice the rate
@@ -803,16 +827,7 @@ def main():
             reducer.detach()                          # the step-wide reducer of that leg takes over the decoder's parameters
             res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms)
         # what the split producers reported over the whole run (ops.GradScale; published without host synchronisation)
-        gs = getattr(dec, "_grad_scale", None)
-        if gs is not None:
-            torch.cuda.synchronize()
-            try:
-                gs.check()                            # (consumes what is still in flight)
-            except FloatingPointError:
-                pass
-            res["saturation"] = {"saturated_passes": gs.saturated_passes, "x8_saturated_passes": gs.x8_saturated_passes,
-                                 "x8_adaptations": gs.x8_adaptations, "x8_grad_exp": gs.x8_grad_exp,
-                                 "nonfinite_passes": gs.nonfinite_passes}
+        res["saturation"] = sat_report if sat_report is not None else saturation_report()
         res["roofline_hbm"] = hbm_rooflines(dec, cfg, B, T)
         if hip_out is not None:
             res["cpu_baseline"], res["parity_vs_cpu"] = cpu_baseline(cfg, sd, batch, hip_out)

@@ -37,3 +37,23 @@ def test_bench_starts_its_own_ranks():
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["value"] > 0
     assert res["config"]["parallelism"] == "dp1" and res["distributed"]["backend"] == "nccl"
+
+
+def test_bench_control_flow_at_world_size_two_on_one_gpu():
+    """The driver's N > 1 runs are the first time two ranks meet, and a collective that only rank 0 issues (an extra
+    measured step, a flag all-reduce inside a rank-0 block) hangs them: round 4 found two by reading.  This runs the
+    benchmark's whole N = 2 control flow on ONE GPU -- both ranks on device 0, gradients reduced by gloo through the host
+    (RCCL refuses two ranks on a device) -- under a timeout: timed loop, exposed-communication report, per-bucket all-reduce
+    timing, in-step launch timing, saturation report, JSON line from rank 0."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "8", "--frames", "400"], capture_output=True, text=True, timeout=600,
+                       env=_env(RADMMM_BENCH_SHARE_GPU="1", RADMMM_BENCH_BACKEND="gloo", RADMMM_CHECK_SATURATION="1"), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 16
+    d = res["distributed"]
+    assert d["backend"] == "gloo" and d["rccl_world_size"] == 2 and d["rccl_allreduce_of_ones"] == 2.0
+    assert len(d["allreduce_alone_per_bucket"]) == d["gradient_buckets"] and res["saturation"]["nonfinite_passes"] == 0
+    assert res["roofline"]["avg_launch_ms"] > 0
