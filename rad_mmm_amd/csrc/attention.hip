@@ -142,6 +142,55 @@ __global__ __launch_bounds__(128) void attn_bwd_keys_kernel(
   }
 }
 
+// the same sums, tiled (round 4): a workgroup owns 4 text positions x all channels of one utterance and walks the frames in
+// chunks of 32 through LDS (the kernel above re-read Q once per text position and fetched g_d one broadcast word at a time:
+// 0.43 ms at B = 32, 800 x 150, Ca = 80).  Every output keeps the SAME fmaf chain over t in ascending order: identical bits.
+constexpr int ABK_S = 4, ABK_T = 32, ABK_MAXJ = 2;       // Ca <= 128; small tiles: several workgroups per CU hide the LDS latency
+__global__ __launch_bounds__(256) void attn_bwd_keys_tiled_kernel(
+    const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ gd,
+    float* __restrict__ gK, int B, int T1, int T2, int Ca, float temp) {
+  extern __shared__ float abk_sm[];                      // [ABK_T][ABK_S + 1] of g_d, then [ABK_T][Ca] of Q
+  float* sg = abk_sm;
+  float* sq = abk_sm + ABK_T * (ABK_S + 1);
+  const int b = blockIdx.y, s0 = blockIdx.x * ABK_S, tid = threadIdx.x;
+  const int nout = ABK_S * Ca;
+  int os[ABK_MAXJ], oc[ABK_MAXJ];
+  float kv[ABK_MAXJ], acc[ABK_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ABK_MAXJ; ++j) {
+    const int idx = tid + j * 256;
+    const bool on = idx < nout;
+    os[j] = on ? idx / Ca : 0;
+    oc[j] = on ? idx - os[j] * Ca : 0;
+    const bool live = on && s0 + os[j] < T2;
+    kv[j] = live ? Kx[((long long)b * T2 + s0 + os[j]) * Ca + oc[j]] : 0.f;
+    acc[j] = 0.f;
+  }
+  for (int t0 = 0; t0 < T1; t0 += ABK_T) {
+    for (int i = tid; i < ABK_T * ABK_S; i += 256) {
+      const int tt = i / ABK_S, ss = i - tt * ABK_S;
+      const bool ok = t0 + tt < T1 && s0 + ss < T2;
+      sg[tt * (ABK_S + 1) + ss] = ok ? gd[((long long)b * T1 + t0 + tt) * T2 + s0 + ss] : 0.f;
+    }
+    const int nq = min(ABK_T, T1 - t0) * Ca;
+    const float* qsrc = Q + ((long long)b * T1 + t0) * Ca;
+    for (int i = tid; i < ABK_T * Ca; i += 256) sq[i] = i < nq ? qsrc[i] : 0.f;
+    __syncthreads();
+#pragma unroll 4
+    for (int tt = 0; tt < ABK_T; ++tt) {
+#pragma unroll
+      for (int j = 0; j < ABK_MAXJ; ++j)
+        if (j * 256 < nout) acc[j] = fmaf(sg[tt * (ABK_S + 1) + os[j]], sq[tt * Ca + oc[j]] - kv[j], acc[j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < ABK_MAXJ; ++j) {
+    const int idx = tid + j * 256;
+    if (idx < nout && s0 + os[j] < T2) gK[((long long)b * T2 + s0 + os[j]) * Ca + oc[j]] = 2.f * temp * acc[j];
+  }
+}
+
 // ------------------------------------------------------------------ MAS
 // PROB: the input holds probabilities and the log is taken here, correctly rounded to fp32 (double log, then one
 // rounding): a device-independent definition of the reference's `np.log(attn)` (alignment.py:36), whose own float32
@@ -325,8 +374,12 @@ extern "C" int radmmm_attn_bwd(const float* Q, const float* Kx, const float* pri
   hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3((unsigned)((rows + AT_WAVES - 1) / AT_WAVES)), dim3(256),
                      smem, s, Q, Kx, prior, in_lens, attn, logprob, gattn, glogprob, gQ, gd_scratch, B, T1,
                      T2, Ca, temp);
-  hipLaunchKernelGGL(attn_bwd_keys_kernel, dim3((unsigned)((long long)B * T2)), dim3(128), 0, s, Q, Kx,
-                     gd_scratch, gK, B, T1, T2, Ca, temp);
+  if (ABK_S * Ca <= 256 * ABK_MAXJ)       // (ABK_S positions x Ca outputs over 256 threads: at most ABK_MAXJ each)
+    hipLaunchKernelGGL(attn_bwd_keys_tiled_kernel, dim3((unsigned)((T2 + ABK_S - 1) / ABK_S), (unsigned)B), dim3(256),
+                       (size_t)(ABK_T * (ABK_S + 1) + ABK_T * Ca) * sizeof(float), s, Q, Kx, gd_scratch, gK, B, T1, T2, Ca, temp);
+  else
+    hipLaunchKernelGGL(attn_bwd_keys_kernel, dim3((unsigned)((long long)B * T2)), dim3(128), 0, s, Q, Kx,
+                       gd_scratch, gK, B, T1, T2, Ca, temp);
   return radmmm::check_launch("attn_bwd");
 }
 

@@ -294,3 +294,37 @@ def test_mas_chain_kernel_edge_shapes_are_bit_exact(B, T1, T2, case):
         assert np.array_equal(hard_pr[b, :n1, :n2], O.mas_width1_c(a, logp=lp_rn)), (case, b)
         for h in (hard_lp, hard_pr):                                    # zero outside the utterance's corner
             assert h[b, n1:].sum() == 0 and h[b, :, n2:].sum() == 0
+
+
+@pytest.mark.parametrize("B,T1,T2,Ca", [(3, 77, 37, 80), (2, 33, 16, 20), (2, 64, 150, 128), (2, 40, 19, 160)])
+def test_attention_core_gradients_on_odd_shapes(B, T1, T2, Ca):
+    """radmmm_attn_fwd / _bwd (common.py:1262-1277: squared distance, log-softmax + log prior, masked softmax) against the
+    oracle's formula in float64 -- outputs and the gradients of queries and keys, on shapes that are no multiple of the tiled
+    key-gradient kernel's 4 text positions x 32 frames (round 4), at its channel limit (128) and beyond it (160: the
+    per-position kernel), ragged text lengths."""
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T1 + T2 + Ca)
+    q0 = torch.randn(B, T1, Ca, generator=g) * 3
+    k0 = torch.randn(B, T2, Ca, generator=g) * 3
+    prior = torch.rand(B, T1, T2, generator=g) + 0.05
+    in_lens = torch.randint(max(1, T2 // 2), T2 + 1, (B,), generator=g)
+    in_lens[0] = T2
+    w1, w2 = torch.randn(B, T1, T2, generator=g), torch.randn(B, T1, T2, generator=g) * 0.1
+    valid = (torch.arange(T2)[None] < in_lens[:, None])[:, None, :]                   # [B, 1, T2]
+    w2 = w2 * valid                                                                   # (log-probabilities of padded keys: unused downstream)
+
+    def ref(q, k):
+        d = ((q[:, :, None, :] - k[:, None, :, :]) ** 2).sum(-1)
+        a = torch.log_softmax(-0.0005 * d, 2) + torch.log(prior.to(q.dtype) + 1e-8)
+        return torch.softmax(a.masked_fill(~valid, -float("inf")), 2), a
+    q64, k64 = q0.double().requires_grad_(True), k0.double().requires_grad_(True)
+    a64, l64 = ref(q64, k64)
+    ((a64 * w1.double()).sum() + (l64 * w2.double()).sum()).backward()
+    qd, kd = q0.to(DEV).requires_grad_(True), k0.to(DEV).requires_grad_(True)
+    attn, lp = ops.AttentionCoreFn.apply(qd, kd, prior.to(DEV), in_lens.to(DEV, torch.int32), 0.0005)
+    ((attn * w1.to(DEV)).sum() + (lp * w2.to(DEV)).sum()).backward()
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(attn.detach(), a64.detach()) < 2e-5
+    assert float(((lp.detach().double().cpu() - l64.detach()) * valid).abs().max()) < 2e-4 * float(l64.detach().abs().max())
+    assert rel(qd.grad, q64.grad) < 2e-4, rel(qd.grad, q64.grad)
+    assert rel(kd.grad, k64.grad) < 2e-4, rel(kd.grad, k64.grad)

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -- python "$ROOT/bench.py" --steps 5 --warmup 2 --step-only "$@" > "$OUT/bench.log" 2>&1
 DB=$(find "$OUT" -name "*.db" | head -1)
 cd "$ROOT"
-python tools/kernel_stats.py "$DB" 7 --hist rowgemm_win_kernelILi7ELi2 --json "gpurun_out/${TAG}_kernel_stats.json" > "gpurun_out/${TAG}_kernel_stats.txt" 2>&1
+python tools/kernel_stats.py "$DB" 7 --gaps --hist rowgemm_win_kernelILi7ELi2 --json "gpurun_out/${TAG}_kernel_stats.json" > "gpurun_out/${TAG}_kernel_stats.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 tail -1 "$OUT/bench.log" | cut -c1-300
 head -45 "gpurun_out/${TAG}_kernel_stats.txt"
