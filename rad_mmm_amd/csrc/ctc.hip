@@ -33,6 +33,16 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   if (m == -INFINITY) return -INFINITY;
   return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
+// the chain's version on the hardware's exp2 / log2 (v_exp_f32 / v_log_f32, 1 ulp): the arguments are <= 0, the sum lies in
+// [1, 3], so the absolute error per step is ~1e-7 like the library functions' -- at 15 instead of ~60 instructions on the
+// critical path of a T-step recurrence (0.29 -> 0.2 ms at T = 800).  A term below 2^-126 flushes to 0 as in expf.
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  if (m == -INFINITY) return -INFINITY;
+  constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+  const float s = __builtin_amdgcn_exp2f((a - m) * L2E) + __builtin_amdgcn_exp2f((b - m) * L2E) + __builtin_amdgcn_exp2f((c - m) * L2E);
+  return fmaf(__builtin_amdgcn_logf(s), LN2, m);
+}
 
 // launch 1.  lp [B][T][C] log-probabilities; lens_txt[b] = L_b targets (1 .. L_b), lens_mel[b] = T_b frames;
 // tab [2][B][T][SP]: alpha rows (direction 0) and beta rows (direction 1), SP = blockDim.x = S rounded up to 64
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(1024) void ctc_chain_kernel(const float* __restrict
           } else {
             const float* r = row[(t - 1) & 1] + 2 + s;
             const float p1 = r[-1], p2 = odd ? r[-2] : -INFINITY;
-            v = live ? lse3(cur, p1, p2) + e[i] : -INFINITY;
+            v = live ? lse3_fast(cur, p1, p2) + e[i] : -INFINITY;
           }
           cur = v;
           row[t & 1][2 + s] = v;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(1024) void ctc_chain_kernel(const float* __restrict
           } else {
             const float* r = row[(t + 1) & 1] + 2 + s;
             const float n1 = s + 1 < S ? r[1] : -INFINITY, n2 = (odd && s + 2 < S) ? r[2] : -INFINITY;
-            v = live ? lse3(cur, n1, n2) + e[i] : -INFINITY;
+            v = live ? lse3_fast(cur, n1, n2) + e[i] : -INFINITY;
           }
           cur = v;
           row[t & 1][2 + s] = v;
