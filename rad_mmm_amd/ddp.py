@@ -43,6 +43,14 @@ def reserve_collective_cus(n: int = RCCL_CUS, total_cus: int = 256) -> None:
     os.environ.setdefault("RADMMM_GEMM_CUS", str(total_cus - n))
 
 
+def slot_numel(p) -> int:
+    """elements a parameter occupies in a flat bucket: its size rounded up to 4 (16 bytes).  Every slice -- the gradient
+    sinks the kernels write with 16-byte stores, the parameter views RAdam streams over -- then starts 16-byte aligned
+    whatever odd-sized tensor precedes it (a start conv with 1127 input channels misaligned everything behind it: half of
+    the weight-norm backward launches fell back to their scalar path).  The pad elements stay zero."""
+    return (p.numel() + 3) & ~3
+
+
 def default_bucket_key(name: str) -> str:
     """flows.3.coupling_tfn... -> 'flows.3.lo' / 'flows.3.hi', also below a parent module (decoder.flows.3... ->
     'decoder.flows.3.lo': the reducer wrapped around the whole training step); everything else (LSTM, embeddings, text
@@ -100,8 +108,8 @@ class BucketedGradReducer:
         for key, tagged in groups.items():
             tagged = [t for t in tagged if t[0]] + [t for t in tagged if not t[0]]   # direct ones first: one fill covers the rest
             params = [t[1] for t in tagged]
-            n = sum(p.numel() for p in params)
-            n_direct = sum(p.numel() for d_, p in tagged if d_)
+            n = sum(slot_numel(p) for p in params)
+            n_direct = sum(slot_numel(p) for d_, p in tagged if d_)
             flat = torch.zeros(n, device=params[0].device, dtype=params[0].dtype)
             off = 0
             for d_, p in tagged:
@@ -109,7 +117,7 @@ class BucketedGradReducer:
                 p.grad = view
                 self._views[id(p)] = view
                 self._direct[id(p)] = d_
-                off += p.numel()
+                off += slot_numel(p)
             b = dict(key=key, params=params, flat=flat, pending=len(params), handle=None, n_direct=n_direct, ready=False)
             self.buckets.append(b)
             for p in params:

@@ -17,7 +17,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Tuple
 import torch
 
 from ._lib import lib, check, ptr, stream
-from .ddp import default_bucket_key
+from .ddp import default_bucket_key, slot_numel
 
 
 class FlatRAdam:
@@ -53,13 +53,13 @@ class FlatRAdam:
                 assert sorted(id(q) for q in rb["params"]) == sorted(id(q) for q in params), "bucket contents differ"
                 params = list(rb["params"])             # the reducer's order (direct-write parameters first)
                 gflat = rb["flat"]
-            n = sum(p.numel() for p in params)
-            flat = torch.empty(n, device=params[0].device, dtype=torch.float32)
+            n = sum(slot_numel(p) for p in params)           # 16-byte aligned slots: the reducer's layout (ddp.slot_numel)
+            flat = torch.zeros(n, device=params[0].device, dtype=torch.float32)
             off = 0
             for p in params:
                 flat[off: off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat[off: off + p.numel()].view_as(p)          # parameter becomes a view of the flat buffer
-                off += p.numel()
+                off += slot_numel(p)
             self.buckets.append(dict(key=key, params=params, flat=flat, gflat=gflat, own_g=gflat is None,
                                      m=torch.zeros_like(flat), v=torch.zeros_like(flat)))
         self._slot = {}                                    # id(param) -> (bucket, offset)
@@ -67,7 +67,7 @@ class FlatRAdam:
             off = 0
             for p in b["params"]:
                 self._slot[id(p)] = (b, off)
-                off += p.numel()
+                off += slot_numel(p)
         dev = self.buckets[0]["flat"].device
         self._part = torch.empty(len(self.buckets), int(lib.radmmm_sumsq_scratch_floats()), device=dev)
         self._clip = torch.ones(1, device=dev)
@@ -85,7 +85,7 @@ class FlatRAdam:
                     b["gflat"][off: off + p.numel()].copy_(p.grad.reshape(-1))
                 else:
                     b["gflat"][off: off + p.numel()].zero_()
-                off += p.numel()
+                off += slot_numel(p)
 
     def clip_grad_norm(self, max_norm: float) -> torch.Tensor:
         """Global 2-norm of all gradients (device scalar, returned) and the clip coefficient

@@ -80,8 +80,8 @@ def _worker(rank, world, port, q):
         for b in red.buckets:
             off = 0
             for p in b["params"]:
-                ok = ok and p.grad.data_ptr() == b["flat"].data_ptr() + 4 * off
-                off += p.numel()
+                ok = ok and p.grad.data_ptr() == b["flat"].data_ptr() + 4 * off and off % 4 == 0
+                off += (p.numel() + 3) & ~3                      # 16-byte aligned slots (ddp.slot_numel)
     # identical parameters on every rank after broadcast
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
