@@ -295,3 +295,56 @@ def test_training_step_under_autocast_runs_in_fp32_where_it_matters(monkeypatch)
         a, b = float(losses32[k][0]), float(losses16[k][0])
         assert abs(a - b) <= 3e-2 * max(abs(a), 1e-2), (k, a, b)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_training_step_with_host_lengths_never_synchronises():
+    """Round 4: with the host copies of the lengths in the batch (`input_lengths_host` /
+    `output_lengths_host`, what the collate function has before the batch moves to the device) a whole training step --
+    text encoder, attention, on-device MAS (binarisation on), decoder, flow + CTC + binarisation losses, backward through the
+    step-wide gradient reducer, global-norm clip, FlatRAdam -- makes NO blocking device -> host read: torch's sync debug mode
+    is set to "error" around the third step.  Same loss as the step without the host copies (which reads the two length
+    tensors once)."""
+    from rad_mmm_amd import synthetic as S
+    from rad_mmm_amd.ddp import BucketedGradReducer
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.optim import FlatRAdam
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=0),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=0)
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion")]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+    model = model.to(dev).train()
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    with torch.no_grad():
+        loss_plain = float(model.training_step(batch, global_step=10)[0])       # (dropout off the record: eval of the same glue)
+    batch["input_lengths_host"] = batch["input_lengths"].cpu()
+    batch["output_lengths_host"] = batch["output_lengths"].cpu()
+    red = BucketedGradReducer(model)
+    opt = FlatRAdam(model.named_parameters(), lr=1e-6, weight_decay=1e-6, reducer=red)
+
+    def step():
+        red.prepare()
+        loss, _, _ = model.training_step(batch, global_step=10)
+        loss.backward()
+        red.finish()
+        opt.clip_grad_norm(1.0)
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss.detach())) and loss_plain > 0
