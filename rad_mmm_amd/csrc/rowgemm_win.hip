@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   };
   auto read_lo = [&](int t, auto tapc, auto parc) __attribute__((always_inline)) {
     constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
+#ifdef RADMMM_SKIP_LO_READS                 // TIMING-ONLY build (wrong results): the cross-term MFMAs run on the hi fragments -- what do
+    fal[t] = fah[t];                        // the 14 lo-fragment LDS reads per wave and K step cost a power-bound launch?
+#else
     fal[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1][tap] + par * G::W_BYTES + G::W_PLANE);
+#endif
   };
   auto read_b1 = [&](int set, int stage, int kb, int j) __attribute__((always_inline)) {
     const int fo = kb ? bad1 : bad0;
