@@ -235,9 +235,9 @@ def hbm_rooflines(dec, cfg, B, T):
         wn_elems += wn.end.weight.numel()
     C = 160
     rows = {
-        "weightnorm_fwd_h3_kernel": ("weight norm + scale + split of every conv weight (fp32 v read, fp16 hi + 8-bit cross written)", wn_elems * 8.0),
+        "weightnorm_fwd_h3": ("weight norm + scale + split of every conv weight, one launch per flow step (fp32 v read, fp16 hi + 8-bit cross written)", wn_elems * 8.0),
         "weightnorm_bwd": ("weight-norm backward over the split-K slabs of the weight gradients", bwd_bytes),
-        "transpose_pair_x8_kernel": ("transposed copies of the split weights for the data-gradient GEMMs", tr_bytes),
+        "transpose_pair_x8": ("transposed copies of the split weights, one launch per flow step for the data-gradient GEMMs", tr_bytes),
         "dact_transposed_kernel": ("gQ = gOUT * softplus'(R): two fp32 reads, split pair written (4 layers x flows)", N * 1024 * (4 + 4 + 4.0) * 4 * len(dec.flows)),
         "affine_coupling_fwd_kernel": ("affine coupling forward (O, z1 read; z, log s written)", N * (C + C + C + C / 2) * 4.0 * len(dec.flows)),
         "affine_coupling_bwd_kernel": ("affine coupling backward", N * (C * 5 + C / 2) * 4.0 * len(dec.flows)),

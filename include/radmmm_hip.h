@@ -397,6 +397,28 @@ int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl,
 int radmmm_transpose_f16_pair(const void* src_h, const void* src_l, int ld_src, int64_t src_batch,
                               void* dst_h, void* dst_l, int ld_dst, int64_t dst_batch, int batches,
                               int rows, int cols, int fmt, int x8_exp, radmmm_stream_t stream);
+/* The two above for up to 16 tensors in ONE launch each: the weights of a flow step are mostly 4 - 9 MB, where a launch of its
+ * own is two memory round trips long rather than bandwidth-bound.  Same arithmetic per tensor, same results. */
+typedef struct radmmm_wn_item {
+  const float* v;
+  const float* g;       /* NULL: plain weights */
+  void* Wh;
+  void* Wl;
+  float* inv_norm;      /* may be NULL when g is NULL */
+  int Cout, Cin, taps, ldk, perm_split, off_lo, off_hi;
+} radmmm_wn_item;
+int radmmm_weightnorm_fwd_h3_multi(const radmmm_wn_item* items, int n, float scale, const radmmm_split_opts* so,
+                                   radmmm_stream_t stream);
+typedef struct radmmm_tp_item {
+  const void* src_h;
+  const void* src_l;
+  void* dst_h;
+  void* dst_l;
+  int64_t src_batch, dst_batch;
+  int ld_src, ld_dst, batches, rows, cols;
+} radmmm_tp_item;
+/* (8-bit B-role pairs only: fmt RADMMM_SPLIT_X8B) */
+int radmmm_transpose_f16_pair_multi(const radmmm_tp_item* items, int n, int fmt, int x8_exp, radmmm_stream_t stream);
 /* Workgroup slots the GEMM grids are sized for: the device's CU count, or RADMMM_GEMM_CUS (32 .. CUs; read once
  * per process) when data-parallel runs leave CUs to RCCL's channel kernels (Lightning `strategy: ddp`,
  * configs/RADMMM_train_config.yaml:28; rad_mmm_amd/ddp.py reserve_collective_cus). */

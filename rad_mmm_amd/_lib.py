@@ -91,6 +91,20 @@ class RowGemmH3Desc(C.Structure):
     ]
 
 
+class WnItem(C.Structure):
+    """radmmm_wn_item: one tensor of radmmm_weightnorm_fwd_h3_multi"""
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("Wh", C.c_void_p), ("Wl", C.c_void_p), ("inv_norm", C.c_void_p),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("ldk", C.c_int), ("perm_split", C.c_int),
+                ("off_lo", C.c_int), ("off_hi", C.c_int)]
+
+
+class TpItem(C.Structure):
+    """radmmm_tp_item: one pair of radmmm_transpose_f16_pair_multi"""
+    _fields_ = [("src_h", C.c_void_p), ("src_l", C.c_void_p), ("dst_h", C.c_void_p), ("dst_l", C.c_void_p),
+                ("src_batch", C.c_int64), ("dst_batch", C.c_int64), ("ld_src", C.c_int), ("ld_dst", C.c_int),
+                ("batches", C.c_int), ("rows", C.c_int), ("cols", C.c_int)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("GY", C.c_void_p), ("ldgy", C.c_int),
@@ -167,6 +181,7 @@ def _load() -> C.CDLL:
         "radmmm_wgrad_h3": [p, p, p, p, p, p, i, i, i, p, i, i64, i, i, i, i, i, f, i, p],
         "radmmm_weightnorm_fwd_h3": [p, p, p, p, p, i, i, i, i, i, i, i, f, so, p],
         "radmmm_transpose_f16_pair": [p, p, i, i64, p, p, i, i64, i, i, i, i, i, p],
+        "radmmm_weightnorm_fwd_h3_multi": [p, i, f, so, p], "radmmm_transpose_f16_pair_multi": [p, i, i, i, p],
         "radmmm_pq_spline_fwd": [p, i, p, i, p, i, p, i, i, i, p],
         "radmmm_pq_spline_bins": [p, i, p, i, p, p, p, i, i, i, p],
         "radmmm_pq_spline_bwd": [p, i, p, i, p, i, p, p, i, p, i, i, i, i, p],

@@ -17,13 +17,10 @@ using radmmm::block_sum;
 // each tap plane is then written as whole 4-column groups (8-byte fp16 stores, 4-byte stores of the 8-bit parts) with
 // consecutive lanes on consecutive columns.  (The first version wrote element by element in [ci][tap] order: adjacent
 // lanes hit different tap planes, 2-byte scattered stores -- 1.7 ms per step for 849 MB of weights.)
-__global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
+__device__ __forceinline__ void weightnorm_fwd_h3_row(
     const float* __restrict__ v, const float* __restrict__ g, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
     float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi,
-    float scale, int fmt, float x8_mul, int vec_ok) {
-  extern __shared__ float row[];        // [Cin * taps]
-  __shared__ float sh[17];
-  const int co = blockIdx.x;
+    float scale, int fmt, float x8_mul, int vec_ok, int co, float* row, float* sh) {
   const int n = Cin * taps;
   const float* vr = v + (long long)co * n;
   float ss = 0.f;
@@ -57,6 +54,37 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
+    float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi,
+    float scale, int fmt, float x8_mul, int vec_ok) {
+  extern __shared__ float row[];        // [Cin * taps]
+  __shared__ float sh[17];
+  weightnorm_fwd_h3_row(v, g, Wh, Wl, inv_norm, Cout, Cin, taps, ldk, perm_split, off_lo, off_hi, scale, fmt, x8_mul, vec_ok,
+                        blockIdx.x, row, sh);
+}
+
+// Several weight tensors in ONE launch (round 4): a flow step prepares ten conv weights, most of them 4 - 9 MB -- at that
+// size a launch is two dependent memory round trips long, not bandwidth-bound (8.5 us for 8 MB).  The items travel as a
+// kernel argument (no device-side table to upload); workgroup b belongs to the item whose [start, start + Cout) holds b.
+constexpr int WN_MULTI_MAX = 16;
+struct WnMulti {
+  radmmm_wn_item it[WN_MULTI_MAX];
+  int start[WN_MULTI_MAX + 1];
+  int vec_ok[WN_MULTI_MAX];
+  int n, fmt;
+  float scale, x8_mul;
+};
+__global__ __launch_bounds__(256) void weightnorm_fwd_h3_multi_kernel(const WnMulti m) {
+  extern __shared__ float row[];
+  __shared__ float sh[17];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.start[k + 1]) ++k;
+  const radmmm_wn_item& t = m.it[k];
+  weightnorm_fwd_h3_row(t.v, t.g, static_cast<_Float16*>(t.Wh), static_cast<_Float16*>(t.Wl), t.inv_norm, t.Cout, t.Cin, t.taps,
+                        t.ldk, t.perm_split, t.off_lo, t.off_hi, m.scale, m.fmt, m.x8_mul, m.vec_ok[k], blockIdx.x - m.start[k], row, sh);
 }
 
 // hi/lo [rows][ldh] split of scale * x (zero padded to ldh), any split format
@@ -105,14 +133,12 @@ __global__ __launch_bounds__(256) void transpose_pair_kernel(const _Float16* __r
 // the same for a B-role 8-bit pair (hi f16 + cross array [lo8 | hi8] per 32 columns): the 8-bit lo parts move with the
 // transposition, the 8-bit hi parts are re-derived from the fp16 hi (what the producer did: e4m3(hi * 2^e) of the value
 // already rounded to fp16 differs from e4m3(t * 2^e) only in double-rounding ties; both are valid 8-bit images of hi)
-__global__ __launch_bounds__(256) void transpose_pair_x8_kernel(const _Float16* __restrict__ sh_, const unsigned char* __restrict__ sx,
-                                                                int ld_src, long long src_batch, _Float16* __restrict__ dh,
-                                                                unsigned char* __restrict__ dx, int ld_dst, long long dst_batch,
-                                                                int rows, int cols, int fmt, float x8_mul) {
-  __shared__ _Float16 th[32][34];
-  __shared__ unsigned char tl[32][36];
-  const int b = blockIdx.z;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+__device__ __forceinline__ void transpose_pair_x8_tile(const _Float16* __restrict__ sh_, const unsigned char* __restrict__ sx,
+                                                       int ld_src, long long src_batch, _Float16* __restrict__ dh,
+                                                       unsigned char* __restrict__ dx, int ld_dst, long long dst_batch,
+                                                       int rows, int cols, int fmt, float x8_mul, int bx, int by, int b,
+                                                       _Float16 (*th)[34], unsigned char (*tl)[36]) {
+  const int r0 = by * 32, c0 = bx * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
@@ -133,7 +159,97 @@ __global__ __launch_bounds__(256) void transpose_pair_x8_kernel(const _Float16* 
   }
 }
 
+__global__ __launch_bounds__(256) void transpose_pair_x8_kernel(const _Float16* __restrict__ sh_, const unsigned char* __restrict__ sx,
+                                                                int ld_src, long long src_batch, _Float16* __restrict__ dh,
+                                                                unsigned char* __restrict__ dx, int ld_dst, long long dst_batch,
+                                                                int rows, int cols, int fmt, float x8_mul) {
+  __shared__ _Float16 th[32][34];
+  __shared__ unsigned char tl[32][36];
+  transpose_pair_x8_tile(sh_, sx, ld_src, src_batch, dh, dx, ld_dst, dst_batch, rows, cols, fmt, x8_mul, blockIdx.x, blockIdx.y,
+                         blockIdx.z, th, tl);
+}
+
+// several pairs in one launch (see weightnorm_fwd_h3_multi_kernel): workgroup b -> item, then (tile column, tile row, batch)
+constexpr int TP_MULTI_MAX = 16;
+struct TpMulti {
+  radmmm_tp_item it[TP_MULTI_MAX];
+  int start[TP_MULTI_MAX + 1];
+  int nbx[TP_MULTI_MAX], nby[TP_MULTI_MAX];
+  int n, fmt;
+  float x8_mul;
+};
+__global__ __launch_bounds__(256) void transpose_pair_x8_multi_kernel(const TpMulti m) {
+  __shared__ _Float16 th[32][34];
+  __shared__ unsigned char tl[32][36];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.start[k + 1]) ++k;
+  const radmmm_tp_item& t = m.it[k];
+  int r = blockIdx.x - m.start[k];
+  const int bx = r % m.nbx[k];
+  r /= m.nbx[k];
+  const int by = r % m.nby[k], b = r / m.nby[k];
+  transpose_pair_x8_tile(static_cast<const _Float16*>(t.src_h), static_cast<const unsigned char*>(t.src_l), t.ld_src,
+                         (long long)t.src_batch, static_cast<_Float16*>(t.dst_h), static_cast<unsigned char*>(t.dst_l), t.ld_dst,
+                         (long long)t.dst_batch, t.rows, t.cols, m.fmt, m.x8_mul, bx, by, b, th, tl);
+}
+
 }  // namespace
+
+extern "C" int radmmm_weightnorm_fwd_h3_multi(const radmmm_wn_item* items, int n, float scale, const radmmm_split_opts* so,
+                                              radmmm_stream_t stream) {
+  RADMMM_REQUIRE(items && n >= 1 && n <= WN_MULTI_MAX, "weightnorm_fwd_h3_multi: 1 .. %d items", WN_MULTI_MAX);
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  WnMulti m;
+  m.n = n;
+  m.fmt = fmt;
+  m.scale = scale;
+  m.x8_mul = ldexpf(1.f, so ? so->x8_exp : 0);
+  size_t smem = 0;
+  int blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const radmmm_wn_item& t = items[k];
+    RADMMM_REQUIRE(t.v && t.Wh && t.Wl && (t.inv_norm || !t.g), "weightnorm_fwd_h3_multi: null pointer in item %d", k);
+    RADMMM_REQUIRE(t.Cout > 0 && t.Cin > 0 && t.taps > 0 && t.ldk >= t.Cin && t.ldk % 8 == 0, "weightnorm_fwd_h3_multi: bad dims in item %d", k);
+    RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || (t.ldk % 32 == 0 && abs(so->x8_exp) <= 16),
+                   "weightnorm_fwd_h3_multi: 8-bit format needs ldk %% 32 == 0");
+    const size_t sm = (size_t)t.Cin * t.taps * sizeof(float);
+    RADMMM_REQUIRE(sm <= 60 * 1024, "weightnorm_fwd_h3_multi: Cin*taps=%d too large for the row buffer", t.Cin * t.taps);
+    smem = sm > smem ? sm : smem;
+    m.it[k] = t;
+    m.start[k] = blocks;
+    blocks += t.Cout;
+    m.vec_ok[k] = (t.Cin % 4 == 0 && t.perm_split % 4 == 0 && t.off_lo % 4 == 0 && t.off_hi % 4 == 0 && t.ldk % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(t.Wh) & 7) == 0 && (reinterpret_cast<uintptr_t>(t.Wl) & 7) == 0) ? 1 : 0;
+  }
+  m.start[n] = blocks;
+  hipLaunchKernelGGL(weightnorm_fwd_h3_multi_kernel, dim3(blocks), dim3(256), smem, static_cast<hipStream_t>(stream), m);
+  return radmmm::check_launch("weightnorm_fwd_h3_multi");
+}
+
+extern "C" int radmmm_transpose_f16_pair_multi(const radmmm_tp_item* items, int n, int fmt, int x8_exp, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(items && n >= 1 && n <= TP_MULTI_MAX, "transpose_f16_pair_multi: 1 .. %d items", TP_MULTI_MAX);
+  RADMMM_REQUIRE(fmt != RADMMM_SPLIT_F16 && abs(x8_exp) <= 16, "transpose_f16_pair_multi: 8-bit B-role pairs only (|x8_exp| <= 16)");
+  TpMulti m;
+  m.n = n;
+  m.fmt = fmt;
+  m.x8_mul = ldexpf(1.f, x8_exp);
+  long long blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const radmmm_tp_item& t = items[k];
+    RADMMM_REQUIRE(t.src_h && t.src_l && t.dst_h && t.dst_l, "transpose_f16_pair_multi: null pointer in item %d", k);
+    RADMMM_REQUIRE(t.batches > 0 && t.rows > 0 && t.cols > 0 && t.ld_src >= t.cols && t.ld_dst >= t.rows && t.ld_src % 32 == 0 &&
+                       t.ld_dst % 32 == 0, "transpose_f16_pair_multi: bad dims in item %d (ld %% 32 == 0)", k);
+    m.it[k] = t;
+    m.nbx[k] = (t.cols + 31) / 32;
+    m.nby[k] = (t.rows + 31) / 32;
+    m.start[k] = (int)blocks;
+    blocks += (long long)m.nbx[k] * m.nby[k] * t.batches;
+    RADMMM_REQUIRE(blocks < 0x7fffffffLL, "transpose_f16_pair_multi: too many tiles");
+  }
+  m.start[n] = (int)blocks;
+  hipLaunchKernelGGL(transpose_pair_x8_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), m);
+  return radmmm::check_launch("transpose_f16_pair_multi");
+}
 
 extern "C" int radmmm_weightnorm_fwd_h3(const float* v, const float* g, void* Wh, void* Wl, float* inv_norm, int Cout,
                                         int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi, float scale,

@@ -710,6 +710,50 @@ def split_weight(v, g, ldk, perm=(0, 0, 0), nprod=3):
     return Wh, Wl, inv
 
 
+def split_weights(specs, nprod=3):
+    """split_weight for several tensors -- specs: [(v, g or None, ldk, perm or None), ...] -> [(Wh, Wl, inv_norm), ...].
+    Up to 16 per launch go through radmmm_weightnorm_fwd_h3_multi (a flow step's ten conv weights in ONE launch: most are
+    4 - 9 MB, where a launch of their own is latency- rather than bandwidth-bound); same arithmetic, same results."""
+    from ._lib import WnItem
+    out, items = [], []
+    for v, g, ldk, perm in specs:
+        perm = perm or (0, 0, 0)
+        Cout, Cin, taps = v.shape
+        Wh, Wl = _halves(taps, Cout, ldk, like=v, zero=(ldk != Cin or perm != (0, 0, 0)))
+        inv = _empty(Cout, like=v) if g is not None else None
+        out.append((Wh, Wl, inv))
+        items.append(WnItem(ptr(v), ptr(g), ptr(Wh), ptr(Wl), ptr(inv), Cout, Cin, taps, ldk, perm[0], perm[1], perm[2]))
+    for k in range(0, len(items), 16):
+        chunk = items[k: k + 16]
+        arr = (WnItem * len(chunk))(*chunk)
+        check(lib.radmmm_weightnorm_fwd_h3_multi(arr, len(chunk), W_SCALE, split_opts(fmt_b(nprod), X8_W_EXP), stream()),
+              "weightnorm_fwd_h3_multi")
+    return out
+
+
+def transpose_splits(specs, nprod=2):
+    """transpose_split for several B-role 8-bit pairs (FP8-cross scheme) in one launch -- specs: [(Wh, Wl, rows, cols, ld_dst,
+    out or None), ...] -> [(Th, Tl), ...] with Th [taps][cols][ld_dst]; out = (Th, Tl) views to write into (slices of a
+    larger tap stack)."""
+    from ._lib import TpItem
+    assert nprod == 2
+    res, items = [], []
+    for Wh, Wl, rows, cols, ld_dst, out in specs:
+        taps = Wh.shape[0]
+        if out is not None:
+            Th, Tl = out
+            assert Th.shape == (taps, cols, ld_dst) and Th.is_contiguous() and ld_dst == rows
+        else:
+            Th, Tl = _halves(taps, cols, ld_dst, like=Wh, zero=(ld_dst != rows))
+        res.append((Th, Tl))
+        items.append(TpItem(ptr(Wh), ptr(Wl), ptr(Th), ptr(Tl), Wh.stride(0), Th.stride(0), Wh.shape[2], ld_dst, taps, rows, cols))
+    for k in range(0, len(items), 16):
+        chunk = items[k: k + 16]
+        arr = (TpItem * len(chunk))(*chunk)
+        check(lib.radmmm_transpose_f16_pair_multi(arr, len(chunk), fmt_b(nprod), X8_W_EXP, stream()), "transpose_f16_pair_multi")
+    return res
+
+
 def transpose_split(Wh, Wl, rows, cols, ld_dst, nprod=3, out=None):
     """[taps][rows][ld] pair -> [taps][cols][ld_dst] (zero padded), i.e. the K-contiguous operand of the
     data-gradient GEMM.  out = (Th, Tl): write into these [taps][cols][ld_dst] views (slices of a larger tap stack)."""
@@ -1181,14 +1225,17 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l),
                                       split_opts(fa, X8_ACT_EXP, None, X0lo), stream()), "wn_input_fwd")
         perm = (h, D, 0)
-        Wsh, Wsl, inv_s = split_weight(start_v, start_g, Kp, perm, NPR)
-        Wih, Wil, inv_i, Wrh, Wrl, inv_r = [], [], [], [], [], []
+        # all conv weights of the flow step in one launch (round 4)
+        specs = [(start_v, start_g, Kp, perm)]
         for j in range(nl):
-            a, b, iv = split_weight(in_p[3 * j], in_p[3 * j + 1], Wc, nprod=NPR)
-            Wih.append(a); Wil.append(b); inv_i.append(iv)
-            a, b, iv = split_weight(res_p[3 * j], res_p[3 * j + 1], Wc, nprod=NPR)
-            Wrh.append(a); Wrl.append(b); inv_r.append(iv)
-        Weh, Wel, _ = split_weight(end_w, None, Wc, nprod=NPR)
+            specs.append((in_p[3 * j], in_p[3 * j + 1], Wc, None))
+            specs.append((res_p[3 * j], res_p[3 * j + 1], Wc, None))
+        specs.append((end_w, None, Wc, None))
+        sw = split_weights(specs, NPR)
+        Wsh, Wsl, inv_s = sw[0]
+        Wih, Wil, inv_i = [sw[1 + 2 * j][0] for j in range(nl)], [sw[1 + 2 * j][1] for j in range(nl)], [sw[1 + 2 * j][2] for j in range(nl)]
+        Wrh, Wrl, inv_r = [sw[2 + 2 * j][0] for j in range(nl)], [sw[2 + 2 * j][1] for j in range(nl)], [sw[2 + 2 * j][2] for j in range(nl)]
+        Weh, Wel, _ = sw[-1]
 
         H = [_empty(N, Wc, like=z_in)]
         Hh, Hl = _halves(N, Wc, like=z_in)
@@ -1292,7 +1339,35 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_end_w = grad_out(end_w)
         torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
         gOh, gOl = split_f16(gO, ZLD, SG, ZLD, NPR, GE, flag)
-        WeTh, WeTl = transpose_split(Weh, Wel, C, Wc, ZLD, NPR)                    # [1][Wc][ZLD]
+        # the transposed weights of the whole flow step in ONE launch (round 4; FP8-cross scheme): end conv, per layer the
+        # in_layer stack (with the free slot of the fused data gradient filled by res_skip j-1's weights) and the start conv
+        fuse = debug_env("RADMMM_FUSED_DGRAD", "1") != "0"
+        pre = None
+        if NPR == 2 and debug_env("RADMMM_MULTI_TRANSPOSE", "1") != "0":
+            specs, slot = [(Weh, Wel, C, Wc, ZLD, None)], {"end": 0}
+            stacks = {}
+            for j in range(nl - 1, -1, -1):
+                kt_j = in_p[3 * j].shape[2]
+                if fuse and j > 0:                       # keep_pair below: in_layer j's stack with one free slot
+                    stacks[j] = _halves(kt_j + 1, Wc, Wc, like=z_in)
+                    slot[("in", j)] = len(specs)
+                    specs.append((Wih[j], Wil[j], Wc, Wc, Wc, (stacks[j][0][:kt_j], stacks[j][1][:kt_j])))
+                else:
+                    slot[("in", j)] = len(specs)
+                    specs.append((Wih[j], Wil[j], Wc, Wc, Wc, None))
+            for j in range(nl - 1, -1, -1):
+                slot[("res", j)] = len(specs)
+                if fuse and j + 1 < nl:                  # fused below: into the stack of in_layer j + 1
+                    kt_n = in_p[3 * (j + 1)].shape[2]
+                    specs.append((Wrh[j], Wrl[j], Wc, Wc, Wc, (stacks[j + 1][0][kt_n:], stacks[j + 1][1][kt_n:])))
+                else:
+                    specs.append((Wrh[j], Wrl[j], Wc, Wc, Wc, None))
+            slot["start"] = len(specs)
+            specs.append((Wsh, Wsl, Wc, Kp, Wc, None))
+            done = transpose_splits(specs, NPR)
+            pre = {k: done[i] for k, i in slot.items()}
+            pre["stacks"] = stacks
+        WeTh, WeTl = pre["end"] if pre else transpose_split(Weh, Wel, C, Wc, ZLD, NPR)      # [1][Wc][ZLD]
         gOUT = _empty(N, Wc, like=z_in)
         rowgemm_h3(Ah=gOh, Al=gOl, lda_h=ZLD, Bh=WeTh, Bl=WeTl, ldb_h=ZLD, C=gOUT, ldc=Wc, M=N, N=Wc, K=ZLD, **gin)
         g_in: List[Optional[torch.Tensor]] = [None] * (3 * nl)
@@ -1304,7 +1379,6 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # extra_tap) -- and dL/dH_{j+1} itself never exists in memory.  For that the split copies of g_conv_{j+1} and of
         # gQ_j live in one [2N, Wc] pair (rows [0, N) / [N, 2N)) and the transposed weights of in_layer j+1 and res_skip j
         # in one [taps + 1] tap stack.  RADMMM_FUSED_DGRAD=0 keeps the two-launch arrangement (A/B runs).
-        fuse = debug_env("RADMMM_FUSED_DGRAD", "1") != "0"
         # bias gradients of the in_layer convs and of the start conv: column sums of the data-gradient GEMMs' values before
         # their row scale, taken from the accumulators in the epilogue (radmmm_rowgemm_desc.colsum_out) instead of a pass
         # over the 52 MB output each.  RADMMM_FUSED_COLSUM=0: the separate radmmm_colsum launches (A/B runs).
@@ -1350,11 +1424,12 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             gb, cs = cs_args(in_p[3 * j + 2]) if cs_here else (None, {})
             if fused:
                 WTh, WTl, ktn, dn = WT_prev
-                transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
+                if pre is None:
+                    transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
                 rowgemm_h3(Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=WTh, Bl=WTl, ldb_h=Wc, b_tap_stride_h=WTh.stride(0), taps=ktn,
                            dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout, **cs)
             else:
-                WrTh, WrTl = transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
+                WrTh, WrTl = pre[("res", j)] if pre else transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
                 rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout, **cs)
             if use_rm:
                 g_in[3 * j + 2] = gb if cs_here else colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d,
@@ -1379,13 +1454,16 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             if keep_pair:
                 # in_layer j's data gradient is deferred into layer j-1's fused launch: transposed weights into a tap
                 # stack with one free slot for res_skip j-1's
-                WTh, WTl = _halves(kt + 1, Wc, Wc, like=z_in)
-                transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR, out=(WTh[:kt], WTl[:kt]))
+                if pre is not None:
+                    WTh, WTl = pre["stacks"][j]
+                else:
+                    WTh, WTl = _halves(kt + 1, Wc, Wc, like=z_in)
+                    transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR, out=(WTh[:kt], WTl[:kt]))
                 WT_prev = (WTh, WTl, kt, d)
                 pair_h, pair_l = nh, nlo
                 G = None
             else:
-                WiTh, WiTl = transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)            # [taps][ci][co]
+                WiTh, WiTl = pre[("in", j)] if pre else transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)   # [taps][ci][co]
                 G = _empty(N, Wc, like=z_in)
                 if j == 0:
                     Gh, Gl = _halves(N, Wc, like=z_in)
@@ -1412,7 +1490,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             x_t = transpose_split_act(X0, Kp, B, T, None, 0, 1.0, "x0")
             slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Kp, Kp, 1, 1, 1.0 / SG, WPR)
         g_start_v, g_start_g = weightnorm_bwd(start_v, start_g, inv_s, slabs, Kp, perm, poison=poison)
-        WsTh, WsTl = transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)                      # [1][Kp][Wc]
+        WsTh, WsTl = pre["start"] if pre else transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)
         rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc, **gin)
         g_cond = _empty(N, D, like=z_in)

@@ -328,3 +328,33 @@ def test_attention_core_gradients_on_odd_shapes(B, T1, T2, Ca):
     assert float(((lp.detach().double().cpu() - l64.detach()) * valid).abs().max()) < 2e-4 * float(l64.detach().abs().max())
     assert rel(qd.grad, q64.grad) < 2e-4, rel(qd.grad, q64.grad)
     assert rel(kd.grad, k64.grad) < 2e-4, rel(kd.grad, k64.grad)
+
+
+@pytest.mark.parametrize("nprod", [2, 3])
+def test_multi_tensor_weight_preparation_is_bit_identical(nprod):
+    """radmmm_weightnorm_fwd_h3_multi / radmmm_transpose_f16_pair_multi (one launch for a flow step's conv weights) against
+    one launch per tensor: identical bytes, for 5-tap and 1x1 weights, a plain (no weight norm) weight, a start conv with a
+    column permutation and an input width that is no multiple of 4 (scalar store path), more than 16 items (two chunks);
+    transposes into fresh tensors and into slices of a larger tap stack."""
+    from rad_mmm_amd import ops
+    g = torch.Generator().manual_seed(17 + nprod)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.05).to(DEV)
+    specs = [(mk(96, 150, 1), mk(96, 1, 1).abs() + 0.5, 160, (77, 80, 0)),      # start conv: 77 | 73 columns -> offsets 80, 0
+             (mk(64, 64, 5), mk(64, 1, 1).abs() + 0.5, 64, None), (mk(64, 64, 1), mk(64, 1, 1).abs() + 0.5, 64, None),
+             (mk(160, 64, 1), None, 64, None), (mk(32, 96, 3), mk(32, 1, 1).abs() + 0.5, 96, None)]
+    specs = specs + [(mk(64, 64, 1), mk(64, 1, 1).abs() + 0.5, 64, None) for _ in range(14)]          # 19 items: two chunks
+    multi = ops.split_weights(specs, nprod)
+    for (v, gg, ldk, perm), (Wh, Wl, inv) in zip(specs, multi):
+        Wh1, Wl1, inv1 = ops.split_weight(v, gg, ldk, perm or (0, 0, 0), nprod)
+        assert torch.equal(Wh.view(torch.int16), Wh1.view(torch.int16)) and torch.equal(Wl.view(torch.int16), Wl1.view(torch.int16))
+        assert (inv is None and inv1 is None) or torch.equal(inv, inv1)
+    if nprod == 2:
+        Wh5, Wl5, _ = multi[1]
+        Wh1_, Wl1_, _ = multi[2]
+        stack = ops._halves(6, 64, 64, like=specs[1][0])
+        done = ops.transpose_splits([(Wh5, Wl5, 64, 64, 64, (stack[0][:5], stack[1][:5])), (Wh1_, Wl1_, 64, 64, 64, (stack[0][5:], stack[1][5:])),
+                                     (multi[3][0], multi[3][1], 160, 64, 160, None), (multi[4][0], multi[4][1], 32, 96, 32, None)], 2)
+        refs = [ops.transpose_split(Wh5, Wl5, 64, 64, 64, 2), ops.transpose_split(Wh1_, Wl1_, 64, 64, 64, 2),
+                ops.transpose_split(multi[3][0], multi[3][1], 160, 64, 160, 2), ops.transpose_split(multi[4][0], multi[4][1], 32, 96, 32, 2)]
+        for (Th, Tl), (Rh, Rl) in zip(done, refs):
+            assert torch.equal(Th.view(torch.int16), Rh.view(torch.int16)) and torch.equal(Tl.view(torch.int16), Rl.view(torch.int16))
