@@ -39,29 +39,26 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         step()
         torch.cuda.synchronize()
-    agg = defaultdict(lambda: [0, 0.0])
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):
-            continue
-        dt = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
-        if not ev.kernels:
+    rows = prof.key_averages(group_by_stack_n=8)
+    out = []
+    for r in rows:
+        if not r.key.startswith("aten::") or r.device_time_total <= 0 or r.self_device_time_total <= 0:
             continue
         where = "?"
-        for fr in ev.stack or []:
-            if "rad_mmm_amd" in fr or "bench.py" in fr or "aten_ops_probe" in fr:
-                where = fr.split("rad_mmm_amd/")[-1][:70]
+        for fr in r.stack or []:
+            if "rad_mmm_amd" in fr or "aten_ops_probe" in fr:
+                where = fr.split("rad_mmm_amd/")[-1].split("/root/repo/")[-1][:80]
                 break
-        k = (ev.name, where)
-        agg[k][0] += 1
-        agg[k][1] += dt
-    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-    tot = sum(v[1] for _, v in rows)
-    print(f"stock torch kernels in one decoder step: {sum(v[0] for _, v in rows)} launches, {tot / 1e3:.2f} ms of device time")
-    for (name, where), (n, dt) in rows[:45]:
-        print(f"  {name:28s} {n:4d} x  {dt / 1e3:7.3f} ms   {where}")
+        out.append((r.self_device_time_total, r.count, r.key, where))
+    out.sort(reverse=True)
+    tot = sum(o[0] for o in out)
+    print(f"stock torch kernels in one decoder step: {sum(o[1] for o in out)} calls, {tot / 1e3:.2f} ms of device time")
+    for dt, n, name, where in out[:50]:
+        print(f"  {name:24s} {n:4d} x  {dt / 1e3:7.3f} ms   {where}")
 
 
 if __name__ == "__main__":
