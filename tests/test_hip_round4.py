@@ -208,6 +208,91 @@ def test_spline_bin_search_index_accounting_at_config5_size():
         print(f"  parameter gradient at the tie elements differs by up to {worst_tie:.2e} of the tensor max (the other one-sided derivative)")
 
 
+@pytest.mark.parametrize("K,rows,h", [(32, 1003, 80), (8, 517, 79), (32, 3, 5), (5, 200, 80)])
+def test_spline_register_kernels_match_the_lds_walk_and_the_oracle(K, rows, h, monkeypatch):
+    """csrc/spline.hip: the shipped bin counts (K = 32 decoders.py:51-61, K = 8 common.py:1014) run register-resident kernels
+    (parameters read once from LDS, loops unrolled over the compile-time K, hardware exp2 / reciprocal with residual
+    corrections); every other K keeps the runtime-K LDS walk.  On identical inputs -- element counts that are not a multiple
+    of the 128-element block, elements outside [0, 1) -- the two must pick the same bin except at last-bit ties of an edge,
+    and agree in y / log-Jacobian / gradients to a few ulp amplified by the conditioning of narrow bins; both against the
+    oracle's autograd (splines.py:241-326).  K = 5 has no register kernel: the switch must be a no-op there."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd._lib import lib, check, ptr, stream
+    nb = 2 * K + 1
+    g = torch.Generator().manual_seed(K * 1000 + rows)
+    x = torch.rand(rows, h, generator=g)
+    x[::7, ::3] = -0.25
+    x[1::11, 1::5] = 1.0
+    q = torch.randn(rows, h * nb, generator=g) * 1.5
+    gy = torch.randn(rows, h, generator=g)
+    glj = torch.randn(rows, generator=g)
+    xd, qd, gyd, gljd = x.to(DEV), q.to(DEV), gy.to(DEV), glj.to(DEV)
+    res = {}
+    for mode in ("generic", "reg"):
+        if mode == "generic":
+            monkeypatch.setenv("RADMMM_SPLINE", "generic")
+        else:
+            monkeypatch.delenv("RADMMM_SPLINE", raising=False)
+        y = torch.full((rows, h), 7.0, device=DEV)
+        lj = torch.full((rows + rows * h,), 7.0, device=DEV)
+        gx = torch.full((rows, h), 7.0, device=DEV)
+        gq = torch.full_like(qd, 7.0)
+        bins = torch.empty(rows * h, dtype=torch.int32, device=DEV)
+        el, er = torch.empty(rows * h, device=DEV), torch.empty(rows * h, device=DEV)
+        check(lib.radmmm_pq_spline_fwd(ptr(xd), h, ptr(qd), h * nb, ptr(y), h, ptr(lj), rows, h, K, stream()), "fwd")
+        check(lib.radmmm_pq_spline_bwd(ptr(xd), h, ptr(qd), h * nb, ptr(gyd), h, ptr(gljd), ptr(gx), h, ptr(gq), h * nb, rows, h, K,
+                                       stream()), "bwd")
+        check(lib.radmmm_pq_spline_bins(ptr(xd), h, ptr(qd), h * nb, ptr(bins), ptr(el), ptr(er), rows, h, K, stream()), "bins")
+        torch.cuda.synchronize()
+        res[mode] = dict(y=y.cpu(), lj=lj.cpu(), gx=gx.cpu(), gq=gq.cpu(), bins=bins.cpu().view(rows, h), el=el.cpu().view(rows, h),
+                         er=er.cpu().view(rows, h))
+    a, b = res["generic"], res["reg"]
+    inside = (x >= 0) & (x < 1)
+    assert bool((b["bins"][~inside] == -1).all()) and bool((b["bins"][inside] >= 0).all())
+    if K not in (8, 32):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        return
+    mism = a["bins"] != b["bins"]
+    assert int(mism.sum()) <= 2, int(mism.sum())                      # last-bit ties only (none at these sizes, normally)
+    ok = ~mism
+    # outside elements pass through, their parameter gradients are zero
+    assert torch.equal(b["y"][~inside], x[~inside]) and torch.equal(b["gx"][~inside], gy[~inside])
+    assert float(b["gq"].view(rows, h, nb)[~inside].abs().max()) == 0.0
+    assert float((a["el"] - b["el"])[ok].abs().max()) < 1e-6 and float((a["er"] - b["er"])[ok].abs().max()) < 1e-6   # <= 8 ulp of 1: 32 roundings each
+    assert float((a["y"] - b["y"])[ok].abs().max()) < 1e-5          # the cdf at the left edge: 32-term sums in two different orders
+    # oracle: values and the gradient of sum(y gy) + sum_r glj_r sum_c logj
+    xo = x.clone().requires_grad_(True)
+    qo = q.clone().requires_grad_(True)
+    qv = qo.view(rows, h, nb)
+    yo, ljo = O.unbounded_piecewise_quadratic_transform(xo, qv[..., :K], qv[..., K:])
+    ((yo * gy).sum() + (ljo.sum(1) * glj).sum()).backward()
+    idx = torch.searchsorted(torch.cumsum(torch.softmax(qv[..., :K].detach(), -1), -1).index_fill(-1, torch.tensor([K - 1]), 1.0),
+                             torch.where(inside, x, torch.full_like(x, 0.5)).unsqueeze(-1)).squeeze(-1)
+    same = ok & inside & (b["bins"].long() == idx)
+    assert float(same.sum()) > 0.999 * float(inside.sum())
+    # y inherits an edge's last-bit difference times the pdf height v_b (up to ~1 / narrowest width): a few 1e-6 at K = 32
+    ey_new, ey_old = float((b["y"] - yo.detach())[same].abs().max()), float((a["y"] - yo.detach())[same].abs().max())
+    assert ey_new < 3e-5 and ey_new <= 2.0 * ey_old + 5e-6, (ey_new, ey_old)
+    # the log-Jacobian and the gradients inherit the edges' last-bit differences amplified by 1 / width in narrow bins
+    # (test_spline_bin_search_index_accounting_at_config5_size has the bound): the bulk tight, the tail bounded
+    lje = b["lj"][rows:].view(rows, h)
+    dlj = (lje - ljo.detach())[same].abs()
+    assert float(torch.quantile(dlj, 0.95)) < 1e-5 and float(dlj.max()) < 2e-3
+    dlj_ab = (a["lj"][rows:].view(rows, h) - lje)[ok].abs()
+    assert float(torch.quantile(dlj_ab, 0.95)) < 1e-5 and float(dlj_ab.max()) < 2e-3
+    assert float((b["lj"][:rows] - lje.sum(1)).abs().max()) < 1e-4 * max(1.0, float(lje.sum(1).abs().max()))
+    for name, new, old, ref in (("gx", b["gx"], a["gx"], xo.grad), ("gq", b["gq"], a["gq"], qo.grad)):
+        sel = same if name == "gx" else same.unsqueeze(-1).expand(rows, h, nb).reshape(rows, h * nb)
+        scale = float(ref.abs().max())
+        d_or = (new - ref)[sel].abs()
+        d_old = (new - old)[sel].abs()
+        assert float(torch.quantile(d_or[:: max(1, d_or.numel() // 2000000)], 0.99)) < 2e-5 * scale, name
+        assert float(d_or.max()) < 5e-3 * scale and float(d_old.max()) < 5e-3 * scale, (name, float(d_or.max()) / scale)
+        # and never worse than the walk it replaces against the oracle (beyond noise)
+        assert float(d_or.max()) <= 2.0 * float((old - ref)[sel].abs().max()) + 1e-5 * scale, name
+
+
 @pytest.mark.parametrize("B,T,Lmax,case", [(6, 97, 23, "ragged"), (32, 800, 150, "bench"), (4, 640, 511, "longest"),
                                            (3, 40, 9, "impossible"), (2, 33, 1, "one_symbol")])
 def test_ctc_monotonic_matches_torch_ctc(B, T, Lmax, case):
