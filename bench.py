@@ -251,9 +251,29 @@ def hbm_rooflines(dec, cfg, B, T):
         gbs = bytes_step / (ms * 1e-3) / 1e9
         out.append({"kernel": sub, "what": what, "algorithmic_gb_per_step": bytes_step / 1e9, "ms_per_step": ms,
                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
-    return {"bound": "hbm", "durations_static": True,
-            "durations_source": "profiles/r04_kernel_stats.json (rocprofv3 --kernel-trace over `bench.py --step-only`, tools/prof_step.sh)",
-            "kernels": out}
+    res = {"bound": "hbm", "durations_static": True,
+           "durations_source": "profiles/r04_kernel_stats.json (rocprofv3 --kernel-trace over `bench.py --step-only`, tools/prof_step.sh)",
+           "kernels": out}
+    n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
+    if n_spl and (B, T) == (32, 2000):
+        # BASELINE configs[4] (`--config radmmm_splines --frames 2000`): the piecewise-quadratic transform, HBM-bound on the
+        # predicted parameters q (2K+1 = 65 floats per element each way); durations from the trace of THAT workload
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_c5_kernel_stats.json")) as f:
+                k5 = json.load(f)["kernels"]
+        except Exception:
+            k5 = {}
+        h, K = dec.flows[0].coupling_tfn.half_mel_channels, dec.flows[0].coupling_tfn.K
+        qb = N * h * (2 * K + 1) * 4.0
+        for sub, what, byt in (("pq_spline_fwd", "spline forward: q read; x read, y + log-Jacobian written", qb + N * h * 12.0),
+                               ("pq_spline_bwd", "spline backward: q read, dq written; x, gy read, gx written", 2 * qb + N * h * 12.0)):
+            ms = sum(v["ms_per_step"] for k, v in k5.items() if sub in k and v.get("ms_per_step"))
+            if ms > 0:
+                gbs = byt * n_spl / (ms * 1e-3) / 1e9
+                out.append({"kernel": sub, "what": what, "algorithmic_gb_per_step": byt * n_spl / 1e9, "ms_per_step": ms,
+                            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                            "durations_source": "profiles/r04_c5_kernel_stats.json"})
+    return res
 
 
 def cpu_baseline(cfg, sd, batch, hip_out, budget_s=25.0):
