@@ -172,6 +172,78 @@ def test_precision_guard_measures_and_switches(monkeypatch):
         fwd()
 
 
+def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
+    """BASELINE configs[4]: configs/RADMMM_16khz_model_config.yaml dims + n_splines = 2 (decoders.py:94,132), 8 flows, masked
+    batch-norm in the FiLM predictors (training mode: statistics over the whole batch), B = 32, T = 2000 ragged -- the
+    launches no other test reaches (M = 32 000 tiles, split-K weight gradients over 32 000 frames, FiLM convs at 32 000
+    rows, the register-resident spline kernels on 666 MB of parameters per flow).  The batch-norm couples the utterances, so
+    the CPU oracle runs the WHOLE batch (forward + NLL + backward, ~1-2 min on the GPU box's host cores; session-cached,
+    tests/_oracle_cache.py): z, log-det, log_s sums and NLL at 1e-4; d loss / d mel at 2e-3 (L2) / 5e-3 (max) and the
+    parameter-gradient norms at 1e-3.  Why not 5e-4: the spline's bin search.  With 2.56 M spline elements per flow a
+    handful land within a few fp32 ulp of a bin edge, where the kernel's running sum of the softmax widths and torch-CPU's
+    cumsum differ in the last bits and `searchsorted` picks neighbouring bins.  The transform and its log-Jacobian are
+    continuous there (outputs agree to 1e-5), but the log-Jacobian's parameter gradient has a kink at every knot, so those
+    elements get the OTHER one-sided gradient -- O(1) relative on the element, 1e-3 of the tensor in L2.  The index
+    accounting itself (every differing bin a neighbour within 4 ulp of the shared edge, counted) is
+    tests/test_hip_round4.py::test_spline_bin_search_index_accounting_at_config5_size; the kernels against the LDS walk
+    they replaced and the oracle: test_spline_register_kernels_match_the_lds_walk_and_the_oracle."""
+    import os
+    from _oracle_cache import oracle_decoder_run, drop
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", os.environ.get("RADMMM_TEST_C5_PRECISION", "f8x"))
+    kw = dict(KW2, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
+    B, Tn = 32, 2000
+    ref = oracle_decoder_run(kw, B, Tn, 2024, ragged=True)
+    try:
+        dec = RADMMMFlow(use_accent=True, **kw)
+        dec.load_state_dict(ref["sd"])
+        dec = dec.to(DEV).train()
+        dec.precision_guard_every = 0
+        b = ref["batch"]
+        gb = {k: v.to(DEV) for k, v in b.items()}
+        sl = SequenceLength(gb["lengths"])
+        mel = gb["mel"].clone().requires_grad_(True)
+        torch.cuda.reset_peak_memory_stats()
+        out = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+        lm = RADMMMLoss(n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
+        lm.backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        assert torch.isfinite(out["z_mel"]).all() and torch.isfinite(lm) and torch.isfinite(mel.grad).all()
+        m = ref["mask"]
+        zerr = rel_err(out["z_mel"].detach().cpu() * m, ref["z_mel"] * m)
+        lerr = abs(float(lm.detach()) - ref["loss"]) / abs(ref["loss"])
+        lserr = 0.0
+        for a, sc in zip(out["log_s_list"], ref["log_s_sums"]):
+            sa = float((a.detach().cpu() * m).sum())
+            lserr = max(lserr, abs(sa - sc) / max(1.0, abs(sc)))
+        for a, c in zip(out["log_det_W_list"], ref["log_det_W_list"]):
+            assert abs(float(a) - c) < 1e-4 * max(1.0, abs(c))
+        og = ref["g_mel"]
+        gerr = rel_err(mel.grad.cpu(), og)
+        gd = (mel.grad.cpu() - og).abs()
+        gl2 = float(gd.norm() / og.norm())
+        gfrac = float((gd > 5e-4 * og.abs().max()).float().mean())
+        worst, worst_n = 0.0, ""
+        for n, q in dec.named_parameters():
+            assert q.grad is not None and torch.isfinite(q.grad).all(), n
+            go = ref["grads"][n]
+            gn, mine = float(go.norm()), float(q.grad.norm())
+            r = abs(mine - gn) / (gn + 1e-6)
+            if r > worst and gn > 1e-7:
+                worst, worst_n = r, n
+        print(f"configs[4] at B=32, T=2000: z rel {zerr:.2e}, log_s sums rel {lserr:.2e}, NLL rel {lerr:.2e}, d/d mel max-rel {gerr:.2e} / "
+              f"L2-rel {gl2:.2e} / fraction of elements off by > 5e-4 of the max {gfrac:.2e}, worst grad-norm rel {worst:.2e} ({worst_n}); "
+              f"peak device memory {peak:.1f} GiB")
+        assert zerr < 1e-4 and lserr < 1e-4 and lerr < 1e-4
+        assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3
+        assert worst < 1e-3, (worst_n, worst)
+    finally:
+        drop(kw, B, Tn, 2024, ragged=True)                       # ~2 GB of host memory
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Shared-window 5-tap GEMM (csrc/rowgemm_win.hip): the A rows of a k slice are fetched once for all five taps.  Same
 # operands, same MFMAs in the same order as the per-tap-tile kernel (rowgemm_h3d): the outputs must be IDENTICAL, bit for
