@@ -208,7 +208,16 @@ def hbm_rooflines(dec, cfg, B, T):
     from inside the process (they are per-kernel sums over a step) and are QUOTED from the committed rocprofv3 kernel trace of
     this very workload, profiles/r04_kernel_stats.json (tools/prof_step.sh), labelled static."""
     import math
-    path = os.path.join(ROOT, "profiles", "r04_kernel_stats.json")
+    # a trace belongs to ONE workload: the default bench line's (RADTTS, B = 32, T = 800) or BASELINE configs[4]'s
+    # (`--config radmmm_splines --frames 2000`); any other shape has no committed trace and gets no static figures
+    n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
+    if (B, T) == (32, 800) and not n_spl and cfg.cond_dims == 1048:
+        trace = "r04_kernel_stats.json"
+    elif (B, T) == (32, 2000) and n_spl == 2:
+        trace = "r04_c5_kernel_stats.json"
+    else:
+        return None
+    path = os.path.join(ROOT, "profiles", trace)
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
@@ -238,10 +247,10 @@ def hbm_rooflines(dec, cfg, B, T):
         "weightnorm_fwd_h3": ("weight norm + scale + split of every conv weight, one launch per flow step (fp32 v read, fp16 hi + 8-bit cross written)", wn_elems * 8.0),
         "weightnorm_bwd": ("weight-norm backward over the split-K slabs of the weight gradients", bwd_bytes),
         "transpose_pair_x8": ("transposed copies of the split weights, one launch per flow step for the data-gradient GEMMs", tr_bytes),
-        "dact_transposed_kernel": ("gQ = gOUT * softplus'(R): two fp32 reads, split pair written (4 layers x flows)", N * 1024 * (4 + 4 + 4.0) * 4 * len(dec.flows)),
-        "affine_coupling_fwd_kernel": ("affine coupling forward (O, z1 read; z, log s written)", N * (C + C + C + C / 2) * 4.0 * len(dec.flows)),
-        "affine_coupling_bwd_kernel": ("affine coupling backward", N * (C * 5 + C / 2) * 4.0 * len(dec.flows)),
-        "wn_input_fwd4_kernel": ("WN input assembly [context | z half] + split copy", N * (1048 + 80 + 1152 + 1152) * 4.0 * len(dec.flows)),
+        "dact_transposed_kernel": ("gQ = gOUT * softplus'(R): two fp32 reads, split pair written (4 layers x flows)", N * 1024 * (4 + 4 + 4.0) * 4 * (len(dec.flows) - n_spl)),
+        "affine_coupling_fwd_kernel": ("affine coupling forward (O, z1 read; z, log s written)", N * (C + C + C + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
+        "affine_coupling_bwd_kernel": ("affine coupling backward", N * (C * 5 + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
+        "wn_input_fwd4_kernel": ("WN input assembly [context | z half] + split copy", N * (1048 + 80 + 1152 + 1152) * 4.0 * (len(dec.flows) - n_spl)),
     }
     out = []
     for sub, (what, bytes_step) in rows.items():
@@ -252,17 +261,12 @@ def hbm_rooflines(dec, cfg, B, T):
         out.append({"kernel": sub, "what": what, "algorithmic_gb_per_step": bytes_step / 1e9, "ms_per_step": ms,
                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     res = {"bound": "hbm", "durations_static": True,
-           "durations_source": "profiles/r04_kernel_stats.json (rocprofv3 --kernel-trace over `bench.py --step-only`, tools/prof_step.sh)",
+           "durations_source": f"profiles/{trace} (rocprofv3 --kernel-trace over `bench.py --step-only` of this workload, tools/prof_step.sh)",
            "kernels": out}
-    n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
-    if n_spl and (B, T) == (32, 2000):
-        # BASELINE configs[4] (`--config radmmm_splines --frames 2000`): the piecewise-quadratic transform, HBM-bound on the
-        # predicted parameters q (2K+1 = 65 floats per element each way); durations from the trace of THAT workload
-        try:
-            with open(os.path.join(ROOT, "profiles", "r04_c5_kernel_stats.json")) as f:
-                k5 = json.load(f)["kernels"]
-        except Exception:
-            k5 = {}
+    if n_spl:
+        # BASELINE configs[4]: the piecewise-quadratic transform, HBM-bound on the predicted parameters q (2K+1 = 65 floats
+        # per element each way)
+        k5 = ks
         h, K = dec.flows[0].coupling_tfn.half_mel_channels, dec.flows[0].coupling_tfn.K
         qb = N * h * (2 * K + 1) * 4.0
         for sub, what, byt in (("pq_spline_fwd", "spline forward: q read; x read, y + log-Jacobian written", qb + N * h * 12.0),
@@ -271,8 +275,7 @@ def hbm_rooflines(dec, cfg, B, T):
             if ms > 0:
                 gbs = byt * n_spl / (ms * 1e-3) / 1e9
                 out.append({"kernel": sub, "what": what, "algorithmic_gb_per_step": byt * n_spl / 1e9, "ms_per_step": ms,
-                            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                            "durations_source": "profiles/r04_c5_kernel_stats.json"})
+                            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     return res
 
 
