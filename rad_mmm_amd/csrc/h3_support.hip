@@ -24,10 +24,21 @@ __device__ __forceinline__ void weightnorm_fwd_h3_row(
   const int n = Cin * taps;
   const float* vr = v + (long long)co * n;
   float ss = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float x = vr[i];
-    row[i] = x;
-    ss = fmaf(x, x, ss);
+  if ((n & 3) == 0 && radmmm::aligned16(vr)) {          // 16 bytes per lane: a 20 KB row in 5 instructions per thread, not 20
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+      const float4 x = *reinterpret_cast<const float4*>(vr + i);
+      *reinterpret_cast<float4*>(row + i) = x;
+      ss = fmaf(x.x, x.x, ss);
+      ss = fmaf(x.y, x.y, ss);
+      ss = fmaf(x.z, x.z, ss);
+      ss = fmaf(x.w, x.w, ss);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float x = vr[i];
+      row[i] = x;
+      ss = fmaf(x, x, ss);
+    }
   }
   float wn = 1.f;                      // g / ||v||  (1 for plain weights)
   if (g) {
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_h3_kernel(
     const float* __restrict__ v, const float* __restrict__ g, _Float16* __restrict__ Wh, _Float16* __restrict__ Wl,
     float* __restrict__ inv_norm, int Cout, int Cin, int taps, int ldk, int perm_split, int off_lo, int off_hi,
     float scale, int fmt, float x8_mul, int vec_ok) {
-  extern __shared__ float row[];        // [Cin * taps]
+  extern __shared__ __attribute__((aligned(16))) float row[];        // [Cin * taps]
   __shared__ float sh[17];
   weightnorm_fwd_h3_row(v, g, Wh, Wl, inv_norm, Cout, Cin, taps, ldk, perm_split, off_lo, off_hi, scale, fmt, x8_mul, vec_ok,
                         blockIdx.x, row, sh);
@@ -78,7 +89,7 @@ struct WnMulti {
   float scale, x8_mul;
 };
 __global__ __launch_bounds__(256) void weightnorm_fwd_h3_multi_kernel(const WnMulti m) {
-  extern __shared__ float row[];
+  extern __shared__ __attribute__((aligned(16))) float row[];
   __shared__ float sh[17];
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.start[k + 1]) ++k;
@@ -169,18 +180,69 @@ __global__ __launch_bounds__(256) void transpose_pair_x8_kernel(const _Float16* 
                          blockIdx.z, th, tl);
 }
 
+// 64 x 64 tile of the same transposition with wide accesses (rows, cols multiples of 4; hi arrays 8-byte, cross arrays
+// 4-byte aligned rows): a source row of the tile is 128 B of fp16 hi + 2 x 32 B of lo8, a destination row 128 B of hi and
+// 128 B of cross array ([lo8 | hi8] of two 32-column groups are adjacent) -- whole cache lines both ways, where the 32 x 32
+// tile above moves 64-byte rows of halves and single bytes (2.9 TB/s on a flow step's weights).  Same bytes out.
+__device__ __forceinline__ void transpose_pair_x8_tile64(const _Float16* __restrict__ sh_, const unsigned char* __restrict__ sx,
+                                                         int ld_src, long long src_batch, _Float16* __restrict__ dh,
+                                                         unsigned char* __restrict__ dx, int ld_dst, long long dst_batch,
+                                                         int rows, int cols, int fmt, float x8_mul, int bx, int by, int b,
+                                                         _Float16 (*th)[66], unsigned char (*tl)[68]) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int r0 = by * 64, c0 = bx * 64;
+  const int q = threadIdx.x & 15, p = threadIdx.x >> 4;       // 16 groups of 4 columns x 16 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int rl = pass * 16 + p, r = r0 + rl, c = c0 + 4 * q;
+    h4 hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    unsigned lv = 0;
+    if (r < rows && c < cols) {
+      const long long base = b * src_batch + (long long)r * ld_src;
+      hv = *reinterpret_cast<const h4*>(sh_ + base + c);
+      lv = *reinterpret_cast<const unsigned*>(sx + 2 * base + radmmm::x8_lo_off(c, fmt));
+    }
+    // LDS rows of 33 / 17 words: the transposed reads below (word stride 4 x 33 / 4 x 17 across the column groups) hit 16
+    // different banks; a row start is only 4-byte aligned, so the four halves go in as two words
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<h2*>(&th[rl][4 * q]) = h2{hv[0], hv[1]};
+    *reinterpret_cast<h2*>(&th[rl][4 * q + 2]) = h2{hv[2], hv[3]};
+    *reinterpret_cast<unsigned*>(&tl[rl][4 * q]) = lv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int cl = pass * 16 + p, c = c0 + cl, r = r0 + 4 * q;  // destination row c, destination columns r .. r + 3
+    if (c < cols && r < rows) {
+      h4 hv;
+      unsigned lv = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hv[e] = th[4 * q + e][cl];
+        lv |= (unsigned)tl[4 * q + e][cl] << (8 * e);
+      }
+      const long long base = b * dst_batch + (long long)c * ld_dst;
+      *reinterpret_cast<h4*>(dh + base + r) = hv;
+      unsigned char* row = dx + 2 * base;
+      *reinterpret_cast<unsigned*>(row + radmmm::x8_hi_off(r, fmt)) =
+          radmmm::pack_e4m3x4((float)hv[0] * x8_mul, (float)hv[1] * x8_mul, (float)hv[2] * x8_mul, (float)hv[3] * x8_mul);
+      *reinterpret_cast<unsigned*>(row + radmmm::x8_lo_off(r, fmt)) = lv;
+    }
+  }
+}
+
 // several pairs in one launch (see weightnorm_fwd_h3_multi_kernel): workgroup b -> item, then (tile column, tile row, batch)
 constexpr int TP_MULTI_MAX = 16;
 struct TpMulti {
   radmmm_tp_item it[TP_MULTI_MAX];
   int start[TP_MULTI_MAX + 1];
-  int nbx[TP_MULTI_MAX], nby[TP_MULTI_MAX];
+  int nbx[TP_MULTI_MAX], nby[TP_MULTI_MAX], wide[TP_MULTI_MAX];
   int n, fmt;
   float x8_mul;
 };
 __global__ __launch_bounds__(256) void transpose_pair_x8_multi_kernel(const TpMulti m) {
-  __shared__ _Float16 th[32][34];
-  __shared__ unsigned char tl[32][36];
+  __shared__ __attribute__((aligned(16))) _Float16 th[64][66];
+  __shared__ __attribute__((aligned(16))) unsigned char tl[64][68];
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.start[k + 1]) ++k;
   const radmmm_tp_item& t = m.it[k];
@@ -188,9 +250,15 @@ __global__ __launch_bounds__(256) void transpose_pair_x8_multi_kernel(const TpMu
   const int bx = r % m.nbx[k];
   r /= m.nbx[k];
   const int by = r % m.nby[k], b = r / m.nby[k];
-  transpose_pair_x8_tile(static_cast<const _Float16*>(t.src_h), static_cast<const unsigned char*>(t.src_l), t.ld_src,
-                         (long long)t.src_batch, static_cast<_Float16*>(t.dst_h), static_cast<unsigned char*>(t.dst_l), t.ld_dst,
-                         (long long)t.dst_batch, t.rows, t.cols, m.fmt, m.x8_mul, bx, by, b, th, tl);
+  if (m.wide[k])
+    transpose_pair_x8_tile64(static_cast<const _Float16*>(t.src_h), static_cast<const unsigned char*>(t.src_l), t.ld_src,
+                             (long long)t.src_batch, static_cast<_Float16*>(t.dst_h), static_cast<unsigned char*>(t.dst_l), t.ld_dst,
+                             (long long)t.dst_batch, t.rows, t.cols, m.fmt, m.x8_mul, bx, by, b, th, tl);
+  else
+    transpose_pair_x8_tile(static_cast<const _Float16*>(t.src_h), static_cast<const unsigned char*>(t.src_l), t.ld_src,
+                           (long long)t.src_batch, static_cast<_Float16*>(t.dst_h), static_cast<unsigned char*>(t.dst_l), t.ld_dst,
+                           (long long)t.dst_batch, t.rows, t.cols, m.fmt, m.x8_mul, bx, by, b,
+                           reinterpret_cast<_Float16(*)[34]>(&th[0][0]), reinterpret_cast<unsigned char(*)[36]>(&tl[0][0]));
 }
 
 }  // namespace
@@ -240,8 +308,15 @@ extern "C" int radmmm_transpose_f16_pair_multi(const radmmm_tp_item* items, int 
     RADMMM_REQUIRE(t.batches > 0 && t.rows > 0 && t.cols > 0 && t.ld_src >= t.cols && t.ld_dst >= t.rows && t.ld_src % 32 == 0 &&
                        t.ld_dst % 32 == 0, "transpose_f16_pair_multi: bad dims in item %d (ld %% 32 == 0)", k);
     m.it[k] = t;
-    m.nbx[k] = (t.cols + 31) / 32;
-    m.nby[k] = (t.rows + 31) / 32;
+    // the 64 x 64 tile's 4-element accesses: whole groups inside the tensor, aligned rows and batches
+    const bool wide = t.rows % 4 == 0 && t.cols % 4 == 0 && t.src_batch % 4 == 0 && t.dst_batch % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(t.src_h) & 7) == 0 && (reinterpret_cast<uintptr_t>(t.dst_h) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(t.src_l) & 3) == 0 && (reinterpret_cast<uintptr_t>(t.dst_l) & 3) == 0 &&
+                      !radmmm::debug_env("RADMMM_TP_NARROW");
+    const int tile = wide ? 64 : 32;
+    m.wide[k] = wide ? 1 : 0;
+    m.nbx[k] = (t.cols + tile - 1) / tile;
+    m.nby[k] = (t.rows + tile - 1) / tile;
     m.start[k] = (int)blocks;
     blocks += (long long)m.nbx[k] * m.nby[k] * t.batches;
     RADMMM_REQUIRE(blocks < 0x7fffffffLL, "transpose_f16_pair_multi: too many tiles");

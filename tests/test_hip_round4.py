@@ -443,3 +443,22 @@ def test_multi_tensor_weight_preparation_is_bit_identical(nprod):
                 ops.transpose_split(multi[3][0], multi[3][1], 160, 64, 160, 2), ops.transpose_split(multi[4][0], multi[4][1], 32, 96, 32, 2)]
         for (Th, Tl), (Rh, Rl) in zip(done, refs):
             assert torch.equal(Th.view(torch.int16), Rh.view(torch.int16)) and torch.equal(Tl.view(torch.int16), Rl.view(torch.int16))
+        # the multi launch moves 64 x 64 tiles with 8- / 4-byte accesses where rows and cols are multiples of 4, the
+        # per-tensor launch 32 x 32 tiles of halves and bytes: shapes that are no multiples of either tile, a shape that
+        # must take the narrow tile inside the multi launch (cols % 4 != 0), untouched padding (the outputs start as 0x7777)
+        odd = [(100, 36, 3), (260, 1152, 1), (64, 130, 2), (1024, 96, 1)]
+        pairs = [ops.split_weight(mk(co, ci, k), mk(co, 1, 1).abs() + 0.5, ops.round_up(ci, 32), (0, 0, 0), 2)[:2] for co, ci, k in odd]
+        fresh = lambda k, ci, ld: tuple(torch.full((k, ci, ld), 0x7777, dtype=torch.int16, device=DEV).view(torch.float16) for _ in range(2))
+        outs_m = [fresh(k, ci, ops.round_up(co, 32)) for co, ci, k in odd]
+        outs_s = [fresh(k, ci, ops.round_up(co, 32)) for co, ci, k in odd]
+        from rad_mmm_amd._lib import lib, check, ptr, stream, TpItem
+        items = [TpItem(ptr(Wh), ptr(Wl), ptr(o[0]), ptr(o[1]), Wh.stride(0), o[0].stride(0), Wh.shape[2], o[0].shape[2], k, co, ci)
+                 for (co, ci, k), (Wh, Wl), o in zip(odd, pairs, outs_m)]
+        check(lib.radmmm_transpose_f16_pair_multi((TpItem * len(items))(*items), len(items), ops.fmt_b(2), ops.X8_W_EXP, stream()), "multi")
+        for (co, ci, k), (Wh, Wl), o in zip(odd, pairs, outs_s):
+            check(lib.radmmm_transpose_f16_pair(ptr(Wh), ptr(Wl), Wh.shape[2], Wh.stride(0), ptr(o[0]), ptr(o[1]), o[0].shape[2],
+                                                o[0].stride(0), k, co, ci, ops.fmt_b(2), ops.X8_W_EXP, stream()), "single")
+        torch.cuda.synchronize()
+        for a, b, shp in zip(outs_m, outs_s, odd):
+            assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1].view(torch.int16), b[1].view(torch.int16)), shp
+            assert bool((a[0].view(torch.int16) != 0x7777).any())
