@@ -434,7 +434,52 @@ __device__ __forceinline__ void load_params_reg(const float* P, float (&w)[K], f
   for (int j = 0; j <= K; ++j) ev[j] = P[K + j];
 }
 
-// MODE 0: forward (y, logj_elem); MODE 1: bins (tests)
+// Inverse branch on registers (splines.py:306-307, 327-339): the bin is found on the cdf edges (partial areas over the total
+// area, monotone like the widths), then the quadratic is solved for alpha as the walk above does.
+template <int K>
+__device__ __forceinline__ float spline_inverse_core_reg(float (&w)[K], float (&ev)[K + 1], float yv) {
+  const float eps = 1.1920928955078125e-07f;
+  float mw = w[0], mv = ev[0];
+#pragma unroll
+  for (int j = 1; j < K; ++j) mw = fmaxf(mw, w[j]);
+#pragma unroll
+  for (int j = 1; j <= K; ++j) mv = fmaxf(mv, ev[j]);
+  float Z = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    w[j] = exp_nonpos(w[j] - mw);
+    Z += w[j];
+  }
+  const float rZ = rcp_nr(Z);
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = div_r(w[j], Z, rZ);
+#pragma unroll
+  for (int j = 0; j <= K; ++j) ev[j] = exp_nonpos(ev[j] - mv) + 1e-8f;
+  float A = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) A = __builtin_fmaf((ev[j] + ev[j + 1]) * 0.5f, w[j], A);
+  const float rA = rcp_nr(A);
+  float wc = 0.f, area = 0.f, w_l = 0.f, c_l = 0.f;
+  float w_b = w[0], ev_b = ev[0], ev_r = ev[1];
+#pragma unroll
+  for (int j = 0; j < K - 1; ++j) {
+    area = __builtin_fmaf((ev[j] + ev[j + 1]) * 0.5f, w[j], area);
+    wc += w[j];
+    const float cdf = area * rA;
+    const bool lt = cdf < yv;                          // the last edge is 1 and yv < 1
+    w_l = lt ? wc : w_l;
+    c_l = lt ? cdf : c_l;
+    w_b = lt ? w[j + 1] : w_b;
+    ev_b = lt ? ev[j + 1] : ev_b;
+    ev_r = lt ? ev[j + 2 <= K ? j + 2 : 0] : ev_r;
+  }
+  const float v_b = ev_b * rA, v_r = ev_r * rA;
+  const float qa = (v_r - v_b) * w_b / 2.f, qb = v_b * w_b, qc = c_l - yv;
+  const float alpha = (-qb + sqrtf(qb * qb - 4.f * qa * qc)) / (2.f * qa);
+  return fminf(fmaxf(alpha * w_b + w_l, eps), 1.f - eps);
+}
+
+// MODE 0: forward (y, logj_elem); MODE 1: bins (tests); MODE 2: inverse (x = the values to invert, y = the result)
 template <int K, int MODE>
 __global__ __launch_bounds__(SPR_THREADS, 2) void pq_spline_fwd_reg_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ q,
                                                                          float* __restrict__ y, int ldy, float* __restrict__ logj_elem,
@@ -481,7 +526,9 @@ __global__ __launch_bounds__(SPR_THREADS, 2) void pq_spline_fwd_reg_kernel(const
       const float eps = 1.1920928955078125e-07f;
       float yo = xv, lj = 0.f, el = 0.f, er = 0.f;
       int bo = -1;
-      if (inside) {
+      if (inside && MODE == 2) {
+        yo = spline_inverse_core_reg<K>(w, ev, xv);
+      } else if (inside) {
         SplineCore o;
         spline_forward_core_reg<K>(w, ev, xv, o);
         lj = logf(fmaxf(o.L, eps));
@@ -498,7 +545,9 @@ __global__ __launch_bounds__(SPR_THREADS, 2) void pq_spline_fwd_reg_kernel(const
           }
         }
       }
-      if (MODE == 0) {
+      if (MODE == 2) {
+        y[(long long)r * ldy + c] = yo;
+      } else if (MODE == 0) {
         y[(long long)r * ldy + c] = yo;
         logj_elem[e] = lj;
       } else {
@@ -705,6 +754,17 @@ extern "C" int radmmm_pq_spline_inv(const float* y, int ldy, const float* q, int
   RADMMM_REQUIRE(rows > 0 && h > 0 && K >= 1 && K <= SP_KMAX, "pq_spline_inv: bad dims");
   RADMMM_REQUIRE(ldq == h * (2 * K + 1), "pq_spline_inv: q must be dense (ldq == h*(2K+1))");
   const long long total = (long long)rows * h;
+  if (spline_reg_ok(q, K)) {
+    const int nblk = spline_reg_grid(total, K);
+    const size_t smem = (size_t)SPR_THREADS * (2 * K + 1) * sizeof(float);
+    if (K == 32)
+      hipLaunchKernelGGL((pq_spline_fwd_reg_kernel<32, 2>), dim3(nblk), dim3(SPR_THREADS), smem, static_cast<hipStream_t>(stream), y, ldy,
+                         q, x, ldx, nullptr, nullptr, nullptr, nullptr, rows, h);
+    else
+      hipLaunchKernelGGL((pq_spline_fwd_reg_kernel<8, 2>), dim3(nblk), dim3(SPR_THREADS), smem, static_cast<hipStream_t>(stream), y, ldy,
+                         q, x, ldx, nullptr, nullptr, nullptr, nullptr, rows, h);
+    return radmmm::check_launch("pq_spline_inv");
+  }
   const int nblk = (int)((total + SP_THREADS - 1) / SP_THREADS);
   const size_t smem = (size_t)SP_THREADS * (2 * K + 1) * sizeof(float);
   hipLaunchKernelGGL(pq_spline_inv_kernel, dim3(nblk), dim3(SP_THREADS), smem, static_cast<hipStream_t>(stream), y, ldy, q,

@@ -243,9 +243,11 @@ def test_spline_register_kernels_match_the_lds_walk_and_the_oracle(K, rows, h, m
         check(lib.radmmm_pq_spline_bwd(ptr(xd), h, ptr(qd), h * nb, ptr(gyd), h, ptr(gljd), ptr(gx), h, ptr(gq), h * nb, rows, h, K,
                                        stream()), "bwd")
         check(lib.radmmm_pq_spline_bins(ptr(xd), h, ptr(qd), h * nb, ptr(bins), ptr(el), ptr(er), rows, h, K, stream()), "bins")
+        xr = torch.full((rows, h), 7.0, device=DEV)                      # inverse branch (inference): invert this mode's own y
+        check(lib.radmmm_pq_spline_inv(ptr(y), h, ptr(qd), h * nb, ptr(xr), h, rows, h, K, stream()), "inv")
         torch.cuda.synchronize()
         res[mode] = dict(y=y.cpu(), lj=lj.cpu(), gx=gx.cpu(), gq=gq.cpu(), bins=bins.cpu().view(rows, h), el=el.cpu().view(rows, h),
-                         er=er.cpu().view(rows, h))
+                         er=er.cpu().view(rows, h), xr=xr.cpu())
     a, b = res["generic"], res["reg"]
     inside = (x >= 0) & (x < 1)
     assert bool((b["bins"][~inside] == -1).all()) and bool((b["bins"][inside] >= 0).all())
@@ -261,6 +263,12 @@ def test_spline_register_kernels_match_the_lds_walk_and_the_oracle(K, rows, h, m
     assert float(b["gq"].view(rows, h, nb)[~inside].abs().max()) == 0.0
     assert float((a["el"] - b["el"])[ok].abs().max()) < 1e-6 and float((a["er"] - b["er"])[ok].abs().max()) < 1e-6   # <= 8 ulp of 1: 32 roundings each
     assert float((a["y"] - b["y"])[ok].abs().max()) < 1e-5          # the cdf at the left edge: 32-term sums in two different orders
+    # inverse: elements outside pass through; inside, the round trip returns x up to the root formula's cancellation in
+    # nearly linear bins (tests/test_infer.py has the conditioning note), judged by the bulk, and no worse than the walk
+    assert torch.equal(b["xr"][~inside], x[~inside])
+    rt_new, rt_old = (b["xr"] - x)[inside].abs(), (a["xr"] - x)[inside].abs()
+    assert float(torch.quantile(rt_new, 0.9)) < 2e-5 and float(torch.quantile(rt_new, 0.9)) <= 2.0 * float(torch.quantile(rt_old, 0.9)) + 1e-6
+    assert float((rt_new > 1e-3).float().mean()) <= 2.0 * float((rt_old > 1e-3).float().mean()) + 1e-3
     # oracle: values and the gradient of sum(y gy) + sum_r glj_r sum_c logj
     xo = x.clone().requires_grad_(True)
     qo = q.clone().requires_grad_(True)
