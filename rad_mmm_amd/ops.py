@@ -1277,6 +1277,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         ctx.use_rm = use_rm
         ctx.rm8 = rm8
         rm_saved = [X0h, X0lo if X0lo is not None else X0l, *[t for pr in pairs for t in pr]] if use_rm else []
+        # the end conv's weight gradient contracts gO with OUT: with OUT's split pair kept (52 MB per flow step) it runs on
+        # the same row-major kernels as every other weight gradient of the step instead of the fp32-MFMA one (50 -> ~25 us)
+        ctx.out_pair = bool(use_rm and (rm8 or NPR == 3) and debug_env("RADMMM_END_WGRAD_RM", "1") != "0")
+        if ctx.out_pair:
+            rm_saved += [OUTh, OUTl]
         ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
                               start_b, end_b,
                               *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *rm_saved, *layer_params)
@@ -1305,6 +1310,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         if use_rm:                                # row-major split pairs (hi, fp16 lo) of X0 and of the hidden states
             X0pair = (sv[p], sv[p + 1]); p += 2
             Hpair = [(sv[p + 2 * i], sv[p + 2 * i + 1]) for i in range(nl + 1)]; p += 2 * (nl + 1)
+        OUTpair = None
+        if getattr(ctx, "out_pair", False):
+            OUTpair = (sv[p], sv[p + 1]); p += 2
         layer_params = sv[p:]
         in_p, res_p = layer_params[: 3 * nl], layer_params[3 * nl:]
         h = C // 2
@@ -1337,8 +1345,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                                              N, h, scaling, stream()), "affine_coupling_bwd")
         g_end_b = colsum(gO, C, out=grad_out(end_b))
         g_end_w = grad_out(end_w)
-        torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
         gOh, gOl = split_f16(gO, ZLD, SG, ZLD, NPR, GE, flag)
+        if OUTpair is not None:
+            torch.sum(wg_rm((gOh, gOl), OUTpair, C, Wc, 1, 1), dim=0, out=g_end_w.view(1, C, Wc))
+        else:
+            torch.sum(wgrad_slabs(gO, C, OUT, Wc, Wc, T, None), dim=0, out=g_end_w.view(1, C, Wc))
         # the transposed weights of the whole flow step in ONE launch (round 4; FP8-cross scheme): end conv, per layer the
         # in_layer stack (with the free slot of the fused data gradient filled by res_skip j-1's weights) and the start conv
         fuse = debug_env("RADMMM_FUSED_DGRAD", "1") != "0"
@@ -1496,7 +1507,14 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
         g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
-        g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
+        if OUTpair is not None and debug_env("RADMMM_LUS_WGRAD_RM", "1") != "0":
+            # the channel mix's weight gradient (gz1^T z_in, 160 x 160 over all frames) on the row-major split kernels as
+            # well: two 8 MB split passes + a one-tile launch instead of the fp32-MFMA kernel's 50 us
+            gzh, gzl = split_f16(gz1, ZLD, SG, ZLD, NPR, GE, flag)
+            zh, zl = split_f16(z_in, ZLD, 1.0, ZLD, NPR, X8_ACT_EXP)
+            g_W_eff = wg_rm((gzh, gzl), (zh, zl), ZLD, ZLD, 1, 1).sum(0).view(ZLD, ZLD)
+        else:
+            g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
         g_zin = _empty(N, ZLD, like=z_in)
         rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
         return (None, g_zin, g_cond, None, g_W_eff, g_b_eff, g_start_v, g_start_g, g_start_b, g_end_w, g_end_b,
