@@ -1,3 +1,6 @@
+        # (the same move for this 160 x 160 gradient -- two split passes + a one-tile launch -- was measured at 42.34 / 42.35
+        #  against 42.31 / 42.32 ms per step with the fp32-MFMA kernel: nothing; not kept)
+        g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
 """Host-side operators over the C-ABI: allocation + launch sequencing + autograd wiring.
 
 Every numeric step is a kernel of libradmmm_hip.so; torch supplies memory, streams and
