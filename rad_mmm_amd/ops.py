@@ -1507,9 +1507,16 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         g_cond = _empty(N, D, like=z_in)
         check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
         g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
-        # (the same move for this 160 x 160 gradient -- two split passes + a one-tile launch -- was measured at 42.34 / 42.35
-        #  against 42.31 / 42.32 ms per step with the fp32-MFMA kernel: nothing; not kept)
-        g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
+        if OUTpair is not None and T % 16 != 0:
+            # the channel mix's weight gradient (gz1^T z_in, 160 x 160 over all frames): the fp32-MFMA fast path needs K steps
+            # of 16 frames inside one utterance (T % 16 == 0); where it does not apply (configs[4]: T' = 1000, 155 us on the
+            # generic kernel) two 8-bit split passes + a one-tile launch of the row-major split kernel replace it.  At
+            # T % 16 == 0 the same move was measured at 42.34 / 42.35 against 42.31 / 42.32 ms per step: nothing, not taken.
+            gzh, gzl = split_f16(gz1, ZLD, SG, ZLD, NPR, GE, flag)
+            zh, zl = split_f16(z_in, ZLD, 1.0, ZLD, NPR, X8_ACT_EXP)
+            g_W_eff = wg_rm((gzh, gzl), (zh, zl), ZLD, ZLD, 1, 1).sum(0).view(ZLD, ZLD)
+        else:
+            g_W_eff = wgrad_slabs(gz1, ZLD, z_in, ZLD, ZLD, T, None).sum(0).view(ZLD, ZLD)
         g_zin = _empty(N, ZLD, like=z_in)
         rowgemm(A=gz1, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=1, C=g_zin, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T)
         return (None, g_zin, g_cond, None, g_W_eff, g_b_eff, g_start_v, g_start_g, g_start_b, g_end_w, g_end_b,
