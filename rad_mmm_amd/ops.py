@@ -555,7 +555,7 @@ class ConvNormFn(torch.autograd.Function):
         return None, gx, g_v, g_g, g_bias, None
 
 
-def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none", scale_box=None):
+def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none", scale_box=None, nprod=None):
     """scale_box: dict shared by the convs of one backward pass (gradient scale of the split-f16 path,
     fixed by the first node that runs; without it every conv's backward syncs once for its own)."""
     meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act],
@@ -570,6 +570,8 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     # f16 products: the piecewise-quadratic transform's log-Jacobian amplifies errors of its 65 parameters per element
     # (measured: flow-0 log_s off by > 1e-4 with f8x FiLM convs, tests/test_hip_parity.py cfg5_small)
     meta["nprod"] = 3 if prec == "f8x" else NPROD.get(prec, 3)
+    if nprod == 2 and prec == "f8x" and x.shape[0] >= int(debug_env("RADMMM_F8X_MIN_ROWS", "4096")) and v.shape[0] % 32 == 0:
+        meta["nprod"] = 2          # a caller that has established the FP8-cross scheme's accuracy for this conv (FiLM blocks)
     if (prec in NPROD and Cin % 32 == 0 and (taps // 2) * dil <= 16
             and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
         return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
@@ -1550,7 +1552,8 @@ class ConvNormH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
         # the row-major split pair of x is the weight gradient's operand (radmmm_wgrad_rm) when it is an fp16 pair
-        ctx.has_xpair = bool(NPR == 3 and T >= 32 and B <= 1024 and Cin % 8 == 0 and debug_env("RADMMM_WGRAD_RM", "1") != "0")
+        ctx.has_xpair = bool(NPR in (2, 3) and T >= 32 and B <= 1024 and Cin % (32 if NPR == 2 else 8) == 0 and
+                             debug_env("RADMMM_WGRAD_RM", "1") != "0")
         ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
                               inv if inv is not None else v, y, *((xh, xl) if ctx.has_xpair else ()))
         return y
@@ -1583,7 +1586,11 @@ class ConvNormH3Fn(torch.autograd.Function):
               "dact_mul")
         if xpair is not None:
             g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
-            slabs = wgrad_rm_slabs((gph, gpl), xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)
+            if NPR == 2:           # (hi, 8-bit cross array) pairs: the FP8-cross weight gradient (radmmm_wgrad_rm8)
+                slabs = wgrad_rm8_slabs((gph, gpl), GE, xpair, X8_ACT_EXP, B, T, Cout, Cin, taps, dil, 1.0 / SG,
+                                        lens if partial else None)
+            else:
+                slabs = wgrad_rm_slabs((gph, gpl), xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)
         else:
             gy_t, g_bias = transpose_split_act(gpre, Cout, B, T, None, 0, SG, "gy",
                                                colsum=(2 if partial else 0, lens, taps, dil))

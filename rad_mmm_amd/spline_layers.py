@@ -8,6 +8,7 @@ spline transform are fused HIP kernels.  Only the forward (training) direction w
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -41,6 +42,14 @@ class _CN(nn.Module):
         super().__init__()
         self.conv = _WNConv(cin, cout, k)
         self.dilation = dilation
+
+
+# product scheme of the FiLM blocks' convs under RADMMM_PRECISION=f8x: 3 = three f16 products (the `end` conv, which emits the
+# spline parameters, always runs three).  RADMMM_FILM_NPROD=2 is a MEASURED AND REJECTED experiment: configs[4]
+# step 98.4 -> 95.6 ms with outputs still inside 1e-4 (z 2.4e-5, log_s 3.9e-6, NLL 5.4e-6), but the gradients leave their
+# bars (d loss / d mel L2 3.2e-3 against 9.7e-4, worst gradient norm 4.9e-3 against 6.9e-4): the spline's log-Jacobian
+# amplifies errors of its parameters in backward as well.
+FILM_BLOCK_NPROD = int(os.environ.get("RADMMM_FILM_NPROD", "3"))
 
 
 class FiLMPostFn(torch.autograd.Function):
@@ -111,7 +120,8 @@ class FiLMResBlock(nn.Module):
     def forward_cl(self, x, cond, lens32, B, T, n_valid, scale_box=None):
         pp = self.use_partial_padding
         cn = lambda m, t, act: ops.conv_norm(t, m.conv.weight_v, m.conv.weight_g, m.conv.bias, lens32, B, T,
-                                             dil=m.dilation, partial=pp, mask_out=True, act=act, scale_box=scale_box)
+                                             dil=m.dilation, partial=pp, mask_out=True, act=act, scale_box=scale_box,
+                                             nprod=FILM_BLOCK_NPROD)
         x1r = cn(self.input_conv, x, "leaky_relu")            # act(x1) is all that is used downstream
         c1 = cn(self.cond_conv, cond, "none")
         h2 = cn(self.hidden_conv, x1r, "none")
