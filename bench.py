@@ -787,6 +787,12 @@ def main():
                          # weights (4 B), fp32 output (4 B) and its split copy (4 B), each once
                          "own_format_bytes_per_launch": (N * 1024 * 12 + 5 * 1024 * 1024 * 4) if h3 else None,
                          "traffic": traffic, "traffic_static": traffic is not None, "traffic_source": traffic_src,
+                         # FETCH_SIZE counts L2 -> fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM): with 8
+                         # XCDs = 8 private L2s an operand is fetched once per XCD that uses it.  The tile sequence gives an XCD
+                         # r x c = 29 tiles (r row tiles of 224 rows x 4 KB, c column tiles of 5.2 MB of weights); r A + c B is
+                         # minimal at c = 2 (the shipped order: r = 14.5): 13.3 + 10.5 MB per XCD = 190 MB of reads per launch
+                         # for 73 MB of operands -- the floor of this counter for any 8-L2 mapping, not re-reads from HBM
+                         "traffic_floor_8_private_l2": (190.4e6 + N * 1024 * 8.0) if (h3 and N == 12800) else None,
                          # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
                          # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
                          "peak_measured_random_operands": 1620.0 if h3 else None,
