@@ -470,6 +470,14 @@ int radmmm_dact_mul_transposed(const float* g, int ldg, const float* saved, int 
                                int front, int dact, float scale, void* yh, void* yl, int ldyh,
                                const radmmm_split_opts* so, void* oh, void* ol, int ldk, float* part,
                                radmmm_stream_t stream);
+/* radmmm_dact_mul for a backward that needs no fp32 copy of y: y = g * act'(saved) * row factor (rowscale as radmmm_dact_mul:
+ * 0 none, 1 the length mask, 2 mask x partial-conv ratio, partialconv1d.py:75-81) written as the row-major split pair
+ * yh/yl [B*T][ldyh] of scale*y only, and the BIAS-gradient sums in the same pass: part [B * ceil(T / 64)][C] partial rows of
+ * sum_t g * act' * [t < len] (= radmmm_colsum(y, row_weight = rowscale): the ratio and its inverse weight cancel), to be
+ * added by radmmm_colsum_final.  C, ldg, lds multiples of 4, 16-byte aligned g / saved. */
+int radmmm_dact_mul_rows(const float* g, int ldg, const float* saved, int lds, int C, int B, int T, int dact,
+                         int rowscale, const int32_t* lens, int taps, int dil, float scale, void* yh, void* yl,
+                         int ldyh, const radmmm_split_opts* so, float* part, radmmm_stream_t stream);
 /* number of workgroup tiles radmmm_wgrad_h3 launches per split (the caller picks `splits` so that
  * tiles * splits fills whole rounds of the CUs: one workgroup per CU) */
 int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);

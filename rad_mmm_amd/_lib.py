@@ -173,6 +173,7 @@ def _load() -> C.CDLL:
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
         "radmmm_colsum_final": [p, p, i, i, p],
         "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
+        "radmmm_dact_mul_rows": [p, i, p, i, i, i, i, i, i, p, i, i, f, p, p, i, so, p, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_stream_create_masked": [i, C.POINTER(C.c_void_p)],
         "radmmm_stream_destroy": [p],

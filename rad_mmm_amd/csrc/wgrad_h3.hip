@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ saved, int lds, int C, int T, int Tp, int front, int dact,
     float scale, void* __restrict__ yh, void* __restrict__ yl, int ldyh, int fmt, float x8_mul, int* __restrict__ sat_flag,
     _Float16* __restrict__ oh, _Float16* __restrict__ ol, int ldk, float* __restrict__ part, int vec4,
-    void* __restrict__ ylo16) {
+    void* __restrict__ ylo16, int rowscale, const int* __restrict__ lens, int taps, int dil) {
+  // rowscale (radmmm_dact_mul's): 0 none; 1: y *= [t < len]; 2: y *= [t < len] * partial-conv ratio(t).  The column sums are
+  // then those of g * act' * [t < len] -- what radmmm_colsum(y, row_weight = rowscale) returns (ratio x its inverse weight)
   __shared__ float tile[64][65];
   __shared__ float red[16][65];
   const int b = blockIdx.z;
@@ -472,8 +474,16 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
         v.z = gv.z * radmmm::dact_from_out(sv.z, dact);
         v.w = gv.w * radmmm::dact_from_out(sv.w, dact);
       }
+      if (rowscale) {
+        const int len = lens ? lens[b] : T;
+        const float mk = t < len ? 1.f : 0.f;
+        s0 = fmaf(v.x, mk, s0); s1 = fmaf(v.y, mk, s1); s2 = fmaf(v.z, mk, s2); s3 = fmaf(v.w, mk, s3);
+        const float rs = rowscale == 2 ? mk * radmmm::pconv_ratio(t, len, taps, dil) : mk;
+        v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+      } else {
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+      }
       if (yh) sat = fmaxf(sat, radmmm::store_split4_fmt(yh, yl, row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w, ylo16));
-      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
     if (oh) {                                                     // (no transposed copy wanted: nothing to stage)
       tile[tl][tx * 4 + 0] = v.x * scale;
@@ -644,6 +654,27 @@ extern "C" int radmmm_dact_mul_transposed(const float* g, int ldg, const float* 
                      static_cast<_Float16*>(ol), ldk, part,
                      (front % 4 == 0 && Tp % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(oh) & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(ol) & 7) == 0) ? 1 : 0,
-                     so ? so->lo16 : nullptr);
+                     so ? so->lo16 : nullptr, 0, nullptr, 1, 1);
   return radmmm::check_launch("dact_mul_transposed");
+}
+
+// radmmm_dact_mul without the fp32 copy of y and with its bias-gradient sums: y = g * act'(saved) * row factor as the
+// row-major split pair only, the column sums of g * act' * [t < len] as partial rows (include/radmmm_hip.h)
+extern "C" int radmmm_dact_mul_rows(const float* g, int ldg, const float* saved, int lds, int C, int B, int T, int dact,
+                                    int rowscale, const int32_t* lens, int taps, int dil, float scale, void* yh, void* yl,
+                                    int ldyh, const radmmm_split_opts* so, float* part, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(g && yh && yl && part && (saved || !dact), "dact_mul_rows: null pointer");
+  RADMMM_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && T > 0 && ldg >= C && ldg % 4 == 0 && (!dact || (lds >= C && lds % 4 == 0)) &&
+                     rowscale >= 0 && rowscale <= 2 && (rowscale != 2 || (taps >= 1 && dil >= 1)),
+                 "dact_mul_rows: bad dims (C, ldg, lds multiples of 4)");
+  RADMMM_REQUIRE(radmmm::aligned16(g) && (!dact || radmmm::aligned16(saved)), "dact_mul_rows: 16-byte aligned inputs");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(ldyh >= C && ldyh % 4 == 0 && (fmt == RADMMM_SPLIT_F16 || ldyh % 32 == 0),
+                 "dact_mul_rows: row-major split output (ldyh %% 4 == 0; 8-bit formats: %% 32)");
+  hipLaunchKernelGGL(dact_transposed_kernel, dim3((C + 63) / 64, (T + 63) / 64, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, ldg, saved, lds, C, T, T, 0, dact, scale, yh, yl, ldyh, fmt,
+                     ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr, static_cast<_Float16*>(nullptr),
+                     static_cast<_Float16*>(nullptr), 0, part, 0, so ? so->lo16 : nullptr, rowscale, lens, taps > 0 ? taps : 1,
+                     dil > 0 ? dil : 1);
+  return radmmm::check_launch("dact_mul_rows");
 }

@@ -1579,13 +1579,29 @@ class ConvNormH3Fn(torch.autograd.Function):
         flag = sat_flag_bwd_of(box)
         Kp = round_up(Cout, 32)
         rowscale = 2 if partial else (1 if mask_out else 0)
-        gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
         gph, gpl = _halves(N, Kp, like=y, zero=(Kp != Cout))       # K padding of the data gradient must read as zeros
-        check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
-                                  taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), GE, flag), stream()),
-              "dact_mul")
+        # with the row-major weight gradient nothing reads an fp32 copy of the pre-activation gradient: it is written as the
+        # split pair only and the bias sums leave the same pass as partials (radmmm_dact_mul_rows: 12 instead of 20 bytes per
+        # element over two passes; 32 000-row FiLM convs: dact_mul 77 + colsum 27 us -> one launch)
+        fused_rows = (xpair is not None and Cout % 4 == 0 and ldy % 4 == 0 and N == B * T and
+                      debug_env("RADMMM_DACT_ROWS", "1") != "0")
+        if fused_rows:
+            gpre = None
+            nparts = B * (-(-T // 64))
+            part = _empty(nparts, Cout, like=y)
+            check(lib.radmmm_dact_mul_rows(ptr(gy), ldy, ptr(y), ldy, Cout, B, T, act, rowscale, ptr(lens), taps, dil, SG,
+                                           ptr(gph), ptr(gpl), Kp, split_opts(fmt_a(NPR), GE, flag), ptr(part), stream()),
+                  "dact_mul_rows")
+            g_bias = _empty(Cout, like=y)
+            check(lib.radmmm_colsum_final(ptr(part), ptr(g_bias), nparts, Cout, stream()), "colsum_final")
+        else:
+            gpre = torch.zeros_like(y) if ldy != Cout else torch.empty_like(y)
+            check(lib.radmmm_dact_mul(ptr(gy), ldy, ptr(y), ldy, ptr(gpre), ldy, N, Cout, act, rowscale, T, ptr(lens),
+                                      taps, dil, ptr(gph), ptr(gpl), Kp, SG, split_opts(fmt_a(NPR), GE, flag), stream()),
+                  "dact_mul")
         if xpair is not None:
-            g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
+            if not fused_rows:
+                g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
             if NPR == 2:           # (hi, 8-bit cross array) pairs: the FP8-cross weight gradient (radmmm_wgrad_rm8)
                 slabs = wgrad_rm8_slabs((gph, gpl), GE, xpair, X8_ACT_EXP, B, T, Cout, Cin, taps, dil, 1.0 / SG,
                                         lens if partial else None)

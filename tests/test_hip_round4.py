@@ -473,3 +473,41 @@ def test_multi_tensor_weight_preparation_is_bit_identical(nprod):
         for a, b, shp in zip(outs_m, outs_s, odd):
             assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1].view(torch.int16), b[1].view(torch.int16)), shp
             assert bool((a[0].view(torch.int16) != 0x7777).any())
+
+
+@pytest.mark.parametrize("rowscale,act", [(2, "leaky_relu"), (1, "none"), (0, "softplus")])
+def test_dact_mul_rows_equals_dact_mul_plus_column_sums(rowscale, act):
+    """radmmm_dact_mul_rows (the generic conv node's backward when the weight gradient contracts row-major pairs: no fp32 copy
+    of the pre-activation gradient, bias sums from the same pass) against radmmm_dact_mul + radmmm_colsum: the split pair
+    must be IDENTICAL (same products in the same order), the sums equal to rounding -- ragged lengths, a frame count that is
+    no multiple of the 64-frame tile, the length mask alone and with the partial-conv ratio, both split formats."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import lib, check, ptr, stream
+    B, T, C = 3, 150, 96
+    N = B * T
+    g = torch.Generator().manual_seed(5 + rowscale)
+    gy = (torch.randn(N, C, generator=g) * 1e-2).to(DEV)
+    y = torch.nn.functional.softplus(torch.randn(N, C, generator=g)).to(DEV)
+    lens = torch.tensor([150, 97, 64], dtype=torch.int32, device=DEV)
+    taps, dil, SG = 5, 2, 1024.0
+    for nprod in (3, 2):
+        Kp = 96
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        so = ops.split_opts(ops.fmt_a(nprod), ops.X8_GRAD_EXP, flag)
+        ref_h, ref_l = ops._halves(N, Kp, like=gy, zero=True)
+        gpre = torch.empty(N, C, device=DEV)
+        check(lib.radmmm_dact_mul(ptr(gy), C, ptr(y), C, ptr(gpre), C, N, C, ops.ACT[act], rowscale, T, ptr(lens), taps, dil,
+                                  ptr(ref_h), ptr(ref_l), Kp, SG, so, stream()), "dact_mul")
+        ref_b = ops.colsum(gpre, C, rowscale if rowscale == 2 else 0, T, lens, taps, dil)
+        new_h, new_l = ops._halves(N, Kp, like=gy, zero=True)
+        nparts = B * (-(-T // 64))
+        part = torch.empty(nparts, C, device=DEV)
+        check(lib.radmmm_dact_mul_rows(ptr(gy), C, ptr(y), C, C, B, T, ops.ACT[act], rowscale, ptr(lens), taps, dil, SG,
+                                       ptr(new_h), ptr(new_l), Kp, so, ptr(part), stream()), "dact_mul_rows")
+        new_b = torch.empty(C, device=DEV)
+        check(lib.radmmm_colsum_final(ptr(part), ptr(new_b), nparts, C, stream()), "colsum_final")
+        torch.cuda.synchronize()
+        assert torch.equal(new_h.view(torch.int16), ref_h.view(torch.int16)) and torch.equal(new_l.view(torch.int16), ref_l.view(torch.int16))
+        assert float((new_b - ref_b).abs().max()) <= 2e-6 * float(ref_b.abs().max()) + 1e-9
+        if rowscale:
+            assert float(gpre.view(B, T, C)[1, 97:].abs().max()) == 0.0       # (the reference pass masked those frames)
