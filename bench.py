@@ -48,7 +48,7 @@ PEAK_HBM_GBS = 8000.0
 def procedural_state(cfg_kwargs):
     """Random-init weights of the named architecture (no checkpoints exist offline): the same
     closed-form generator the golden fixtures use, so every rank builds identical weights."""
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
     cfg = O.DecoderConfig(**cfg_kwargs)
     sd = O.procedural_decoder_state(O.decoder_state_shapes(cfg))
     return cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
@@ -553,7 +553,7 @@ def main():
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
 
     CFG = CONFIGS[args.config]
     cfg, sd = procedural_state(CFG)

@@ -32,10 +32,17 @@ import torch
 import torch.nn.functional as F
 
 # Synthetic-data / procedural-weight generators and the config mirror are NOT oracle
-# arithmetic; they live in the package (rad_mmm_amd/synthetic.py) so that bench.py can
-# use them without importing the oracle.  Re-exported here for the tests' convenience.
-from rad_mmm_amd.synthetic import (DecoderConfig, decoder_state_shapes,  # noqa: F401
-                                   procedural_decoder_state, procedural_tensor, synthetic_batch)
+# arithmetic; they live in a neutral numpy-only module at the repo root (radmmm_synth.py)
+# that neither imports the product package nor is part of it: bench.py uses them without
+# importing the oracle, and the oracle / tests/golden/make_golden.py use them on a tree
+# with no built libradmmm_hip.so.  Re-exported here for the tests' convenience.
+import os as _os
+import sys as _sys
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+if _ROOT not in _sys.path:
+    _sys.path.insert(0, _ROOT)
+from radmmm_synth import (DecoderConfig, decoder_state_shapes,  # noqa: E402,F401
+                          procedural_decoder_state, procedural_tensor, synthetic_batch)
 
 Tensor = torch.Tensor
 Params = Dict[str, Tensor]

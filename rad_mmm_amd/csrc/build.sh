@@ -32,9 +32,12 @@ mv "$OUT.tmp" "$OUT"
 for o in "$OBJ"/*.o; do
   [[ -f "$HERE/$(basename "${o%.o}")" ]] || rm -f "$o"
 done
+# Only caches nothing has touched for two hours are removed: a concurrent build with other flags (an A/B build with -D
+# options next to pytest's default build) keeps its directory while it compiles and links.
 if [[ "${RADMMM_KEEP_BUILDS:-0}" != "1" ]]; then
   for d in "$HERE"/build/*/; do
-    [[ "$(basename "$d")" == "$KEY" ]] || rm -rf "$d"
+    [[ -d "$d" && "$(basename "$d")" != "$KEY" ]] || continue
+    [[ -n "$(find "$d" -maxdepth 1 -mmin -120 -print -quit)" ]] || rm -rf "$d"
   done
 fi
 echo "built $OUT"

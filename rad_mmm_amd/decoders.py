@@ -74,13 +74,17 @@ class FlowStep(nn.Module):
     def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
                    scale_box=None):
         conv = self.invtbl_conv
-        # (`initialized` is a device buffer: it is read once -- a host synchronisation -- and remembered; loading a state_dict
-        #  forgets the answer)
-        if (isinstance(conv, DataInitializedInvertible1x1Conv) and self.training and not conv.__dict__.get("_init_seen", False)):
-            if not bool(conv.initialized):
-                conv.initialize(z_cl[:, col_offset:], seq_lens, T)
-                print("initialized invertible conv")
-            conv.__dict__["_init_seen"] = True
+        # (`initialized` is a device buffer: it is read once -- a host synchronisation -- and the answer is remembered FOR THAT
+        #  VERSION OF THE BUFFER: any in-place write (`fill_`, `copy_`, load_state_dict, a re-init utility) bumps the tensor's
+        #  version counter and a replaced buffer is another object, so either is seen and read again, as the reference's
+        #  per-forward check would; deepcopy's carried-over entry refers to the source's buffer and never matches)
+        if isinstance(conv, DataInitializedInvertible1x1Conv) and self.training:
+            seen = (id(conv.initialized), conv.initialized._version)
+            if conv.__dict__.get("_init_seen") != seen:
+                if not bool(conv.initialized):
+                    conv.initialize(z_cl[:, col_offset:], seq_lens, T)
+                    print("initialized invertible conv")
+                conv.__dict__["_init_seen"] = (id(conv.initialized), conv.initialized._version)
         if isinstance(conv, Invertible1x1ConvLUS):
             W_eff, log_det_W = conv.weight_and_log_det(ZLD, col_offset)
             b_eff = self._zero_bias(W_eff)
@@ -414,12 +418,14 @@ class RADMMMFlow(nn.Module):
         `precision_guard_trips_needed` CONSECUTIVE measurements above the tolerance (an off-budget measurement is repeated
         in the very next forward): one excursion of a single batch must not cost 1.07x for the rest of the run.  With a
         process group active every decision is rank-independent: the measurement is MAX-all-reduced before it is
-        published, and a measurement still in flight is waited for instead of polled."""
+        published."""
         g = self._guard
-        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-        if g["pending"] and (dist_on or g["event"].query()):
-            if dist_on:
-                g["event"].synchronize()
+        # a measurement is adopted by the forward after the one that took it, behind a WAIT on its event (never a poll: the
+        # step at which the scheme switches must not depend on host timing -- rounds 3 / 4 polled -- and is the same on every
+        # rank).  The wait holds the host until the device has finished the previous forward, once per
+        # `precision_guard_every` steps.
+        if g["pending"]:
+            g["event"].synchronize()
             g["pending"] = False
             g["last"] = float(g["host"][0])
             if not (g["last"] <= self.precision_guard_tol):          # (NaN trips it too)
@@ -450,13 +456,25 @@ class RADMMMFlow(nn.Module):
         g = self._guard
         # nothing to measure when the last flow step does not run the FP8-cross scheme at all: a spline step (its FiLM convs
         # stay on three products), or a batch below the wide kernel's minimum (common.py: three products there too)
-        if getattr(flow, "use_spline", False) or B * Tg < int(debug_env("RADMMM_F8X_MIN_ROWS", "4096")):
+        # `use_spline` is a property of the model (the same on every rank); the batch's row count is NOT (each rank pads to
+        # its own longest utterance), so with a process group active a rank below the minimum still takes part in the
+        # collective below with a measurement of 0 -- a rank that returned here would leave the others' all-reduce to pair
+        # with its next gradient bucket.
+        if getattr(flow, "use_spline", False):
+            g["last"] = 0.0
+            return
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        small = B * Tg < int(debug_env("RADMMM_F8X_MIN_ROWS", "4096"))
+        if small and not dist_on:
             g["last"] = 0.0
             return
         with torch.no_grad():
-            z_ref, _, _ = flow.forward_cl(z_in.detach(), cond2.detach(), unfolded, lens32, B, Tg, off, "h3", {})
-            rel = (z_f8x.detach() - z_ref).abs().max() / z_ref.abs().max().clamp_min(1e-30)
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
+            if small:
+                rel = torch.zeros(1, device=z_in.device, dtype=torch.float32)
+            else:
+                z_ref, _, _ = flow.forward_cl(z_in.detach(), cond2.detach(), unfolded, lens32, B, Tg, off, "h3", {})
+                rel = (z_f8x.detach() - z_ref).abs().max() / z_ref.abs().max().clamp_min(1e-30)
+            if dist_on:
                 rel = rel.reshape(1).clone()
                 torch.distributed.all_reduce(rel, op=torch.distributed.ReduceOp.MAX)       # every rank decides on the same number
             if g["host"] is None:

@@ -42,9 +42,11 @@ class AttentionCTCLoss(nn.Module):
     -1e4 logit (exp underflows to exactly 0 in fp32, so every remaining value is the per-utterance softmax's; a literal
     -inf would turn torch's CTC gradient, exp(lp) - exp(alpha*beta - lp), into NaN at those positions), frames beyond its
     mel length are ignored through input_lengths.  Same values as the loop (tests/golden/tts_step.npz).  On the GPU the
-    CTC itself is radmmm_ctc_monotonic (csrc/ctc.hip): the targets are always 1 .. len, so one wave per utterance carries
-    the 2 len + 1 states in registers -- value and gradient in one launch, torch's gradient formula, no host
-    synchronisation (F.ctc_loss copies its length arguments between host and device: six blocking copies per step even
+    CTC itself is radmmm_ctc_monotonic (csrc/ctc.hip): the targets are always 1 .. len, so the 2 len + 1 states are one
+    THREAD each, the alpha and the beta chain of an utterance run side by side in two workgroups (a double-buffered LDS
+    row, one barrier per frame) and a second, elementwise launch writes torch's gradient formula from the stored alpha /
+    beta ([2][B][T][2 C - 1] floats of scratch: ~65 MB at B = 32, T = 800, 150 tokens) -- two launches, no host
+    synchronisation; a one-wave-per-utterance version with the states in registers was built first and dropped at 5.6 ms (F.ctc_loss copies its length arguments between host and device: six blocking copies per step even
     with host lengths).  The -1e4 mask assumes every real logit lies well above -1e4 + 88 (the attention's
     log-probabilities are >= ~-1e3)."""
 
@@ -76,9 +78,16 @@ class AttentionBinarizationLoss(nn.Module):
     none (hard is exactly 0 / 1)."""
 
     def forward(self, hard_attention, soft_attention):
-        sel = (hard_attention == 1).to(soft_attention.dtype)
-        logp = torch.log(soft_attention).clamp_min(-100.0)
-        return -(sel * logp).sum() / sel.sum()
+        on = hard_attention == 1
+        sel = on.to(soft_attention.dtype)
+        # positions the alignment does not select never reach the log (their value is replaced by 1 first): an exact 0 there
+        # (every padded text column of the masked softmax, an underflowed probability) would otherwise give log's backward
+        # 0 / 0 = NaN although its weight `sel` is 0 -- the reference's boolean gather cannot see those elements at all
+        # (torch's own BCE on the substituted tensor: its value clamps log at -100 and its gradient is
+        #  (x - 1) / max(x (1 - x), 1e-12) -- finite at a SELECTED probability of exactly 0 too, as in the reference's call)
+        ones = torch.ones_like(soft_attention)
+        bce = F.binary_cross_entropy(torch.where(on, soft_attention, ones), ones, reduction="none")
+        return (sel * bce).sum() / sel.sum()
 
 
 class AttentionLoss(nn.Module):

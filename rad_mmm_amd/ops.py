@@ -6,6 +6,7 @@ DESIGN.md.
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -914,6 +915,12 @@ def _all_reduce_or(flags: torch.Tensor) -> torch.Tensor:
     return (bits << sh).sum(1).to(flags.dtype).reshape(flags.shape)
 
 
+def scale_lag() -> int:
+    """number of training passes between a backward pass and the adoption of the scale statistics it produced (GradScale);
+    2 = the pass after next.  RADMMM_SCALE_LAG=1 adopts them in the very next pass (one blocking wait per step)."""
+    return int(os.environ.get("RADMMM_SCALE_LAG", "2"))
+
+
 class GradScale:
     """Scale state of the split GRADIENT tensors of one module (the decoder owns one and hands it to every flow step):
     a power-of-two S with amax * S in [8, 16) (2^12 of fp16 headroom above the first gradient's maximum), the exponent of
@@ -923,12 +930,16 @@ class GradScale:
     of the scheme's 4e-5); bits 2..7, one-hot: by how many powers of two (include/radmmm_hip.h) -- and the bookkeeping that
     keeps all of it off the host's critical path.
 
-    Steady state has NO host synchronisation: the first backward node of pass k queues `amax(|g|)` of its incoming
-    gradient; the next forward queues an asynchronous copy of (amax, flags) to pinned memory behind an event and clears the
-    flags; the first backward node of a later pass polls that event (query, never wait) and adopts the new S and, when the
-    backward's 8-bit parts saturated, an exponent lowered by the reported level (`x8_adaptations` counts them; the
-    exponent of a pass is fixed when its first node asks for the scale, so producers and consumers of a pass agree).  Only
-    the very first pass of a module synchronises once.
+    Steady state never waits for the device: the first backward node of pass k queues `amax(|g|)` of its incoming
+    gradient; forward k + 1 queues an asynchronous copy of (amax, flags) to pinned memory behind an event and clears the
+    flags; forward k + SCALE_LAG (default 2) ADOPTS that publication -- the new S and, when the backward's 8-bit parts
+    saturated, an exponent lowered by the reported level (`x8_adaptations` counts them; the exponent of a pass is fixed when
+    its first node asks for the scale, so producers and consumers of a pass agree).  The adoption is at a FIXED lag, behind
+    `event.synchronize()` on an event that is a whole training step old by then: which pass first runs with a new scale does
+    not depend on host timing, so a run is bitwise repeatable and every rank follows the same rule (rounds 2-4 adopted
+    "whenever `event.query()` happened to succeed": two identical runs could differ at the 1e-5 level).  The wait is over
+    unless the host has queued more than SCALE_LAG - 1 steps ahead of the device; then it holds the host to that lead, which
+    still leaves the device a full step of queued work.  Only the very first pass of a module reads a value synchronously.
 
     What happens to a pass that clamped (`reports`, counters `saturated_passes` / `x8_saturated_passes` /
     `nonfinite_passes`):
@@ -952,10 +963,8 @@ class GradScale:
         self.flags = None         # device int32[2]: forward / backward producers
         self.amax = None          # device fp32[1]
         self.poison = None        # device fp32[1]: 0, or NaN when this pass's incoming gradient is not finite
-        self._host = None         # pinned fp32[3]: amax, forward flags, backward flags
-        self._event = None
-        self._pending = False
-        self._pending_exp = None  # gradient exponent the pass whose flags are in flight ran with
+        self._inflight = collections.deque()   # publications on their way: dict(host pinned fp32[3], event, exp, passno)
+        self._free = []           # recycled (host, event) pairs
         self._fwd_id = 0
         self._bwd_id = -1
         self._stats_fwd = -1      # forward id whose backward produced the device stats
@@ -1001,9 +1010,8 @@ class GradScale:
             self.flags = torch.zeros(2, device=dev, dtype=torch.int32)
             self.amax = torch.zeros(1, device=dev, dtype=torch.float32)
             self.poison = torch.zeros(1, device=dev, dtype=torch.float32)
-            self._host = torch.zeros(3, dtype=torch.float32).pin_memory()
-            self._event = torch.cuda.Event()
-            self._pending = False
+            self._inflight.clear()
+            self._free = []
 
     def _is_strict(self) -> bool:
         return self.strict if self.strict is not None else os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1"
@@ -1051,11 +1059,12 @@ class GradScale:
                                ") lost their cross-term correction (single-fp16-product accuracy, ~5e-4, for those elements); "
                                "RADMMM_PRECISION=h3 has no such limit")
 
-    def _consume(self):
+    def _consume(self, pub):
         """host copy is complete: adopt the scale, report what the producers flagged in that earlier pass"""
-        self._pending = False
-        amax, f_fwd, f_bwd = float(self._host[0]), int(self._host[1]), int(self._host[2])
-        ran_with, self._pending_exp = self._pending_exp, None
+        host = pub["host"]
+        amax, f_fwd, f_bwd = float(host[0]), int(host[1]), int(host[2])
+        ran_with = pub["exp"]
+        self._free.append((host, pub["event"]))
         if not math.isfinite(amax):
             # non-finite upstream gradient (AMP overflow step): that pass was poisoned (see the class docstring); keep S,
             # and do not report the clamping the NaN / Inf values caused
@@ -1076,21 +1085,24 @@ class GradScale:
         """called by the owning module at the start of a training forward"""
         self._ensure(dev)
         sync_ranks = self._is_strict() and self._distributed()
-        if self._pending and (sync_ranks or self._event.query()):
-            if sync_ranks:
-                self._event.synchronize()                   # rank-independent: never decide on a rank-local poll
-            self._consume()
-        if self._stats_fwd == self._fwd_id and not self._pending:
-            # publish the stats of the backward that followed the previous forward, then re-arm the flags
+        if self._stats_fwd == self._fwd_id:
+            # publish the stats of the backward that followed the previous forward (pass number _fwd_id), then re-arm the flags
             fl = self.flags
             if sync_ranks:
                 fl = _all_reduce_or(self.flags)                                              # every rank raises together
-            self._host[0:1].copy_(self.amax, non_blocking=True)
-            self._host[1:3].copy_(fl.float(), non_blocking=True)
-            self._event.record()
+            host, event = self._free.pop() if self._free else (torch.zeros(3, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            host[0:1].copy_(self.amax, non_blocking=True)
+            host[1:3].copy_(fl.float(), non_blocking=True)
+            event.record()
             self.flags.zero_()
-            self._pending = True
-            self._pending_exp = self._bwd_exp
+            self._inflight.append({"host": host, "event": event, "exp": self._bwd_exp, "passno": self._fwd_id})
+        # adopt, at a fixed lag, what earlier passes published: this forward opens pass _fwd_id + 1 (never a poll: the
+        # pass that first runs with the new scale must not depend on host timing -- nor on the rank)
+        lag = max(1, scale_lag())
+        while self._inflight and (self._fwd_id + 1) - self._inflight[0]["passno"] >= lag:
+            pub = self._inflight.popleft()
+            pub["event"].synchronize()
+            self._consume(pub)
         self._fwd_id += 1
 
     _bwd_exp = None               # gradient exponent of the most recent backward pass
@@ -1100,8 +1112,6 @@ class GradScale:
         self._ensure(g.device)
         if self._bwd_id != self._fwd_id:
             self._bwd_id = self._fwd_id
-            if self._pending and not (self._is_strict() and self._distributed()) and self._event.query():
-                self._consume()
             if self.S is None:                              # first pass of this module: one synchronisation
                 self.S = self._pow2(float(g.abs().max()))
             torch.amax(g.detach().abs().reshape(-1), dim=0, keepdim=True, out=self.amax)     # (propagates NaN)
@@ -1118,9 +1128,10 @@ class GradScale:
         """synchronous: raise FloatingPointError if a split producer has clamped since the flags were last cleared (fp16
         range; the softer e4m3 saturation of the cross terms is counted, adapts the gradient exponent and is warned about,
         see `reports`).  With a process group active the flags are OR-all-reduced first: every rank raises together."""
-        if self._pending:
-            self._event.synchronize()
-            self._consume()
+        while self._inflight:
+            pub = self._inflight.popleft()
+            pub["event"].synchronize()
+            self._consume(pub)
         if self.flags is not None:
             fl = self.flags
             if self._distributed():

@@ -153,7 +153,7 @@ def test_bucket_reducer_direct_gradients_match_plain_backward():
     the same gradients as a plain backward, two steps in a row (second step: stale bucket contents)."""
     import numpy as np
     import torch
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -225,7 +225,8 @@ def test_lu_weight_matches_oracle(c, ldw, off):
 def test_saturation_check_flags_an_overflowing_gradient_scale(monkeypatch):
     """RADMMM_CHECK_SATURATION=1: silent fp16 clamping of the split gradients becomes an error.  A normal step
     passes; a gradient scale 2^30 too large must be reported."""
-    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd import ops
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
@@ -258,7 +259,8 @@ def test_saturation_is_detected_by_default(monkeypatch):
     error surfaces (a) synchronously from decoder.check_saturation() and (b) without any synchronisation from a later
     training pass.  A step in range raises nothing."""
     import time
-    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd import ops
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
@@ -317,7 +319,7 @@ def test_nonfinite_upstream_gradient_poisons_the_pass_and_keeps_the_scale(monkey
     values, so the pass is marked instead: every weight-norm gain gradient becomes NaN (what GradScaler / clip_grad_norm_
     look at), nothing raises -- not one step later either -- and the gradient scale keeps its value for the next pass."""
     import time
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
@@ -364,7 +366,8 @@ def test_batch_shape_changes_between_steps():
     weight-gradient GEMMs are reused across steps: a step after a DIFFERENT shape (here one with the same padded
     contraction length but a shorter real extent, the case where stale columns would be contracted) must give
     exactly the gradients of the same step run from a clean pool."""
-    from rad_mmm_amd import ops, synthetic as S
+    from rad_mmm_amd import ops
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
@@ -401,7 +404,7 @@ def test_batch_shape_changes_between_steps():
 def test_second_backward_without_rearming_accumulates():
     """The reducer's direct-write sinks are one-shot: backward twice between prepare() and finish() (gradient
     accumulation) must ADD the second gradient, not overwrite the first."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -441,7 +444,7 @@ def test_autocast_context_does_not_reach_the_kernels():
     """Lightning `precision: bf16-mixed` wraps the step in torch.autocast.  The package computes in fp32 through raw
     pointers, so its Functions switch autocast off inside: decoder forward + backward under autocast(bf16) must
     equal the plain run bit for bit (without the guard the LSTM's input GEMM would hand bf16 to an fp32 kernel)."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
@@ -522,7 +525,7 @@ def test_relu_activation_in_the_wn(monkeypatch):
 def test_frozen_whitening_layer_trains_the_rest():
     """freeze_whitening_layer=True (decoders.py:143-145): flow 0's 1x1 conv gets no gradient, the others do, and the
     bucket reducer copes with parameters outside its buckets."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -619,7 +622,7 @@ def test_sync_masked_batchnorm_two_rank_emulation(monkeypatch):
     returns the cross-rank sum for every call index already resolved; each pass over both ranks resolves at least the next
     index (its inputs only depend on earlier, resolved, collectives), forward calls first, backward calls after."""
     import torch.distributed as dist
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss

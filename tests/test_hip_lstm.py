@@ -61,7 +61,7 @@ def test_decoder_context_lstm_with_normed_recurrent_weights(norm, monkeypatch):
     """context_lstm_norm != None: the HIP recurrence (weights materialised from torch's hooks) must
     agree with torch.nn.LSTM (MIOpen) on the same module, outputs and gradients."""
     import numpy as np
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,
@@ -92,7 +92,7 @@ def test_remove_norms_keeps_the_context(norm):
     context LSTM's recurrent weights is stripped, the eval-mode context is unchanged, the state_dict now carries
     plain `weight_hh_l0*`."""
     import numpy as np
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     kw = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=64, n_f0_dims=1,

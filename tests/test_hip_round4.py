@@ -307,7 +307,7 @@ def test_spline_register_kernels_match_the_lds_walk_and_the_oracle(K, rows, h, m
 @pytest.mark.parametrize("B,T,Lmax,case", [(6, 97, 23, "ragged"), (32, 800, 150, "bench"), (4, 640, 511, "longest"),
                                            (3, 40, 9, "impossible"), (2, 33, 1, "one_symbol")])
 def test_ctc_monotonic_matches_torch_ctc(B, T, Lmax, case):
-    """radmmm_ctc_monotonic (csrc/ctc.hip: targets 1 .. L_b, one wave per utterance, value + gradient in one launch) against
+    """radmmm_ctc_monotonic (csrc/ctc.hip: targets 1 .. L_b, one state per thread, alpha / beta chains in two workgroups per utterance + an elementwise gradient launch) against
     torch's CTC on the CPU in float64 for the value and float32 for the gradient formula (reference: common.py:441-464 feeds
     nn.CTCLoss(zero_infinity=True) one utterance at a time).  Ragged text and mel lengths, the longest text the kernel takes
     (511 symbols: 1023 states, 16 per lane), an utterance whose mel is shorter than its text (infinite loss -> 0 and a zero

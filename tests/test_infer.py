@@ -54,7 +54,7 @@ def test_oracle_infer_matches_reference(tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["cfg1", "cfg2_small", "cfg5_small"])
 def test_hip_infer_matches_reference(tag):
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.decoders import RADMMMFlow
     cfg_kwargs, t, residual, end_scale = _case(tag)
     cfg = S.DecoderConfig(**cfg_kwargs)
@@ -74,7 +74,7 @@ def test_hip_infer_matches_reference(tag):
 @pytest.mark.gpu
 def test_infer_inverts_forward():
     """z = forward(mel); infer with residual = z must return mel (valid frames)."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     cfg_kwargs = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8, n_text_dim=512, n_f0_dims=1,

@@ -94,7 +94,7 @@ def test_checkpoint_resume_continues_bit_exactly():
     """Checkpoint / resume (Lightning ModelCheckpoint saves module + optimizer state_dicts): two
     steps, save both, one more step  ==  fresh module + optimizer, load both, the same third step."""
     import io
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow

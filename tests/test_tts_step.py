@@ -16,7 +16,7 @@ HERE = os.path.dirname(__file__)
 
 @pytest.mark.parametrize("tag,step", [("soft", 0), ("hard", 10)])
 def test_training_step_matches_reference_components(tag, step, monkeypatch):
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.encoder import Encoder
     from rad_mmm_amd.loss import RADMMMLoss
@@ -58,7 +58,7 @@ def test_joint_step_with_attribute_predictors_through_the_bucket_reducer(monkeyp
     (test above, tests/test_attribute_predictors.py); here: the joint loss is the weighted sum of all parts, the
     predictors receive gradients and do not leak any into the decoder / encoder (detached inputs,
     tts_lightning_modules.py:300-369), and the bucketed gradients equal a plain backward bit for bit."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -138,7 +138,7 @@ def test_joint_step_optimizer_update_matches_oracle(monkeypatch):
     tensor by tensor to the same gradients (direct-write parameters sit first in their buckets: the per-tensor
     mapping of the flat update is what this checks on the real parameter set)."""
     from oracle import radmmm_oracle as O
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
@@ -222,7 +222,7 @@ def test_regularisation_and_bce_losses_match_reference_values():
 def test_validation_step_equals_the_training_pass_without_gradients(monkeypatch):
     """validation_step (tts_lightning_modules.py:752-860) = the training pass with the criterion at step 100000,
     no gradients, plus the embedding regularisers of the model config."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd import loss as L
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.encoder import Encoder
@@ -261,7 +261,7 @@ def test_training_step_under_autocast_runs_in_fp32_where_it_matters(monkeypatch)
     """Lightning `precision: bf16-mixed`: the caller's stock matmuls (context = txt_enc x attn) autocast to bf16 as
     they do in the reference; everything behind this package's modules stays fp32 (no bf16 tensor may reach the C
     ABI).  The joint loss must stay within bf16 rounding of the fp32 run and backward must work."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.encoder import Encoder
@@ -304,7 +304,7 @@ def test_training_step_with_host_lengths_never_synchronises():
     step-wide gradient reducer, global-norm clip, FlatRAdam -- makes NO blocking device -> host read: torch's sync debug mode
     is set to "error" around the third step.  Same loss as the step without the host copies (which reads the two length
     tensors once)."""
-    from rad_mmm_amd import synthetic as S
+    import radmmm_synth as S
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.encoder import Encoder

@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     import bench
-    from rad_mmm_amd import ops, synthetic as O
+    from rad_mmm_amd import ops
+    import radmmm_synth as O
     from rad_mmm_amd.data import BetaBinomialInterpolator
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.encoder import Encoder

@@ -34,7 +34,7 @@ def run(step, n=8, warm=3):
 
 def main():
     import bench
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.data import BetaBinomialInterpolator
     from rad_mmm_amd.ddp import BucketedGradReducer

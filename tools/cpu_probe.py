@@ -1,6 +1,6 @@
 import sys, time, os, torch, numpy as np
 sys.path.insert(0, '.')
-from rad_mmm_amd import synthetic as S
+import radmmm_synth as S
 from rad_mmm_amd.common import SequenceLength
 from rad_mmm_amd.decoders import RADMMMFlow
 from rad_mmm_amd.loss import RADMMMLoss

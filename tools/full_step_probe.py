@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=7)
     args = ap.parse_args()
     import bench
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
     from rad_mmm_amd.decoders import RADMMMFlow
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)

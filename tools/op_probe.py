@@ -3,7 +3,7 @@ launch-bound stragglers between the HIP kernels.  Usage: python tools/op_probe.p
 import sys, torch
 sys.path.insert(0, '.')
 from torch.profiler import profile, ProfilerActivity
-from rad_mmm_amd import synthetic as S
+import radmmm_synth as S
 from rad_mmm_amd.common import SequenceLength
 from rad_mmm_amd.decoders import RADMMMFlow
 from rad_mmm_amd.loss import RADMMMLoss

@@ -31,7 +31,7 @@ def main():
     from rad_mmm_amd.common import SequenceLength
     from rad_mmm_amd.decoders import RADMMMFlow
     from rad_mmm_amd.loss import RADMMMLoss
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
     dev = torch.device("cuda:0")
     cfg, sd = bench.procedural_state(bench.RADTTS)
     crit = RADMMMLoss(sigma=1.0, n_group_size=cfg.n_group_size)

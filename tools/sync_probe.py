@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import bench
-    from rad_mmm_amd import synthetic as O
+    import radmmm_synth as O
     from rad_mmm_amd.data import BetaBinomialInterpolator
     from rad_mmm_amd.ddp import BucketedGradReducer
     from rad_mmm_amd.decoders import RADMMMFlow
