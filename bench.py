@@ -38,7 +38,8 @@ RADTTS = dict(n_speaker_dim=16, use_accent_emb_for_decoder=True, n_accent_dim=8,
 RADMMM_SPLINES = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
 # BASELINE configs[2]: the shipped RADMMM decoder (configs/RADMMM_model_config.yaml:16-39): 8 affine flows, D = 1056
 RADMMM = dict(RADTTS, n_text_dim=520, use_accent_emb_for_decoder=False)
-CONFIGS = {"radtts": RADTTS, "radmmm": RADMMM, "radmmm_splines": RADMMM_SPLINES}
+# "joint" = BASELINE configs[3]: the RADMMM decoder + the four attribute predictors in one training step (full_step leg)
+CONFIGS = {"radtts": RADTTS, "radmmm": RADMMM, "radmmm_splines": RADMMM_SPLINES, "joint": RADMMM}
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
@@ -329,7 +330,81 @@ def cpu_baseline(cfg, sd, batch, hip_out, budget_s=25.0):
                       f"1 step = {dt:.1f} s (one utterance alone: {probe:.2f} s)"}, parity
 
 
-def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=150):
+# BASELINE configs[3]: the four attribute predictors of the joint step at the dims their YAMLs ship
+# (configs/RADMMM_{f0,energy,vpred,duration}model_config.yaml: ConvLSTMLinearDAP, in_dim 520, reduction 16, 3 conv layers of
+# 256 channels, kernel 5, dropout 0.5, accent embedding on; all four with loss.AttributeRegressionLoss, weight 1)
+JOINT_PREDICTORS = {"f0": dict(target_offset=-5.0, prefix="f0_"), "energy": dict(target_offset=-0.75, prefix="energy_"),
+                    "voiced": dict(prefix="vpred_"), "duration": dict(log_target=True, prefix="duration_")}
+
+
+def build_joint_predictors(CFG, p_dropout=0.5):
+    from rad_mmm_amd.attribute_predictors import AttributeRegressionLoss, ConvLSTMLinearDAP
+    out = {}
+    for name, spec in JOINT_PREDICTORS.items():
+        out[f"{name}_predictor"] = ConvLSTMLinearDAP(
+            n_speaker_dim=CFG["n_speaker_dim"], n_accent_dim=CFG["n_accent_dim"], use_accent_embedding=True, in_dim=CFG["n_text_dim"],
+            out_dim=1, reduction_factor=16, n_backbone_layers=3, n_hidden=256, kernel_size=5, p_dropout=p_dropout,
+            target_offset=spec.get("target_offset", 0.0), log_target=spec.get("log_target", False), lstm_type="bilstm")
+        out[f"{name}_predictor_loss"] = AttributeRegressionLoss(spec["prefix"], 1.0)
+    return out
+
+
+def joint_parity_vs_cpu(model, batch, cfg, Bs, dev):
+    """The joint step on the first Bs utterances of the bench batch, HIP against the CPU oracle's restatement of
+    TTSModel.training_step (oracle.tts_joint_step), both WITHOUT dropout (the reference's only random element): the summed
+    loss, every loss term, the four predictors' outputs and the decoder's z.  -> (report dict, worst relative figures)"""
+    import torch.nn.functional as F
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd.common import SequenceLength
+    nb = batch["mel"].shape[0]
+    sub = {k: (v[:Bs] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == nb else v) for k, v in batch.items()}
+    real_dropout = F.dropout
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    try:
+        with torch.no_grad():
+            loss, losses, outs = model.training_step(sub, global_step=10)
+            ctx_d, spk_d, acc_d = outs["context"], outs["spk_vecs"], outs["accent_vecs"]
+            ol = SequenceLength(sub["output_lengths"], sub.get("output_lengths_host"))
+            il = SequenceLength(sub["input_lengths"], sub.get("input_lengths_host"))
+            txt_enc, _ = model.encode_text(sub["text"], il.lengths, None, int(il.lengths_host.max()))
+            pred = {"f0": model.f0_predictor(sub["f0"].unsqueeze(1), ctx_d, spk_d, ol, None, None, acc_d)["x_hat"],
+                    "energy": model.energy_predictor(sub["energy_avg"].unsqueeze(1), ctx_d, spk_d, ol, accent_emb=acc_d)["x_hat"],
+                    "voiced": model.voiced_predictor(sub["voiced_mask"].unsqueeze(1), ctx_d, spk_d, ol, accent_emb=acc_d)["x_hat"],
+                    "duration": model.duration_predictor(outs["attn"].sum(2), txt_enc, spk_d, il, accent_emb=acc_d)["x_hat"]}
+    finally:
+        F.dropout = real_dropout
+    torch.cuda.synchronize()
+    p = {n: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for n, v in model.state_dict().items()}
+    cb = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sub.items()}
+    specs = {name: dict(n_layers=3, weight=1.0, **spec) for name, spec in JOINT_PREDICTORS.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = O.tts_joint_step(p, cfg, cb, specs, binarize=True, bin_loss=True)
+    dt = time.perf_counter() - t0
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    terms = {k: {"hip": float(v[0]), "cpu": float(ref["losses"][k][0]), "rel_diff": rel(v[0], ref["losses"][k][0])}
+             for k, v in losses.items() if k in ref["losses"] and torch.is_tensor(v[0])}
+    z_err = float((outs["z_mel"].cpu() - ref["z_mel"]).abs().max() / ref["z_mel"].abs().max())
+    perr = {}
+    for name, xh in pred.items():
+        r = ref["pred"][name]
+        w = r.shape[2]
+        lens = cb["input_lengths"] if name == "duration" else cb["output_lengths"]
+        m = (torch.arange(w)[None, :] < lens[:, None])[:, None]
+        perr[name] = float(((xh.cpu()[:, :, :w] - r) * m).abs().max() / (r * m).abs().max())
+    hard_h, hard_c = outs["attn"].detach().cpu().round(), ref["attn"].round()
+    attn_same = int((hard_h == hard_c).flatten(1).all(1).sum())
+    rep = {"utterances": Bs, "dropout": "off on both sides (the step's only random element)", "oracle_seconds": round(dt, 1),
+           "summed_loss_hip": float(loss), "summed_loss_cpu": float(ref["loss"]), "summed_loss_rel_diff": rel(loss, ref["loss"]),
+           "loss_terms": terms, "z_rel_err_vs_cpu": z_err, "predictor_output_rel_err_vs_cpu": perr,
+           "hard_alignments_identical": f"{attn_same} of {Bs}",
+           "bar": "1e-4 relative on the outputs (BASELINE.json north_star); alignments bit-exact on equal logs"}
+    worst = {"loss": rep["summed_loss_rel_diff"], "terms": max(t["rel_diff"] for t in terms.values()), "z": z_err,
+             "pred": max(perr.values()), "alignments_identical": attn_same}
+    return rep, worst
+
+
+def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=150, joint=False, parity_utts=0):
     """The WHOLE training step the reference's Lightning loop runs per batch (tts_lightning_modules.py:643-750 + clip +
     RAdam, configs/RADMMM_train_config.yaml:7-8): embeddings, text encoder, alignment attention with the beta-binomial
     prior, on-device MAS (binarisation on), context = txt_enc . attn^T, flow decoder, flow NLL + CTC + binarisation losses,
@@ -345,10 +420,18 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=
     from rad_mmm_amd.optim import FlatRAdam
     from rad_mmm_amd.tts_step import TTSTrainingStep
     torch.manual_seed(1234)
+    extra = build_joint_predictors(CFG) if joint else {}
     model = TTSTrainingStep(Encoder(3, CFG["n_text_dim"], 5), dec, RADMMMLoss(sigma=1.0, kl_loss_start_iter=0),
                             n_speakers=8, n_accents=4, n_text_tokens=185, n_text_dim=CFG["n_text_dim"],
                             n_speaker_dim=CFG["n_speaker_dim"], n_accent_dim=CFG["n_accent_dim"], use_accent=True,
-                            use_accent_emb_for_decoder=CFG["use_accent_emb_for_decoder"], binarization_start_iter=0).to(dev).train()
+                            use_accent_emb_for_decoder=CFG["use_accent_emb_for_decoder"], binarization_start_iter=0,
+                            **extra).to(dev).train()
+    if joint:
+        for name in JOINT_PREDICTORS:                       # converge spectral norm's power iteration (fresh u / v leave |W_hh| ~ 10)
+            lstm = getattr(model, f"{name}_predictor").feat_pred_fn.bilstm
+            for _ in range(20):
+                for hook in lstm._forward_pre_hooks.values():
+                    hook(lstm, ())
     g = torch.Generator().manual_seed(99)
     in_lens = [t_txt] * B
     batch = {"mel": gb["mel"] * 2 - 5,                      # the step applies (mel + 5) / 2 itself
@@ -358,12 +441,20 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=
              "input_lengths_host": torch.tensor(in_lens), "output_lengths_host": gb["lengths"].cpu(),
              "attn_prior": BetaBinomialInterpolator(device=dev).batch(in_lens, [T] * B),
              "f0": gb["f0"], "energy_avg": gb["energy"]}
+    if joint:
+        batch["voiced_mask"] = (gb["f0"] > gb["f0"].median()).float()      # synthetic: the upper half of the f0 track counts as voiced
+    joint_parity = None
+    if joint and parity_utts > 0:                           # before the first optimizer step: the oracle sees the same weights
+        joint_parity, _ = joint_parity_vs_cpu(model, batch, cfg, parity_utts, dev)
     reducer = BucketedGradReducer(model)
     opt = FlatRAdam(model.named_parameters(), lr=1e-6, weight_decay=1e-6, reducer=reducer)   # tiny lr: the loss stays put
 
+    last = {}
+
     def step():
         reducer.prepare()
-        loss, losses, _ = model.training_step(batch, global_step=10)
+        loss, losses_, _ = model.training_step(batch, global_step=10)
+        last["losses"] = losses_
         loss.backward()
         reducer.finish()
         opt.clip_grad_norm(1.0)
@@ -438,18 +529,47 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=
         u()
     h1.remove()
     h2.remove()
+    # MAS: the default path takes the correctly rounded device log, the reference numpy's float32 log on the host
+    # (alignment.py:36).  How many of THIS batch's alignments does that choice change?  (bit-equal search on equal logs;
+    # INTEGRATION.md "MAS: which log")
+    from rad_mmm_amd.alignment import binarize_attention
+    with torch.no_grad():
+        _, _, outs = model.training_step(batch, global_step=10)
+        soft, il, ol = outs["attn_soft"], batch["input_lengths"], batch["output_lengths"]
+        prev = os.environ.get("RADMMM_MAS_LOG")
+        os.environ["RADMMM_MAS_LOG"] = "device"
+        hard_dev = binarize_attention(soft, il, ol)
+        os.environ["RADMMM_MAS_LOG"] = "host"
+        hard_host = binarize_attention(soft, il, ol)
+        if prev is None:
+            del os.environ["RADMMM_MAS_LOG"]
+        else:
+            os.environ["RADMMM_MAS_LOG"] = prev
+        mas_diff = int((hard_dev != hard_host).flatten(1).any(1).sum())
     dt_ = lambda a, b: round(marks[a].elapsed_time(marks[b]), 3)
     split = {"forward_text_encoder_ms": dt_("enc0", "enc1"), "forward_attention_mas_ms": dt_("att0", "att1"),
              "forward_decoder_ms": dt_("dec0", "dec1"), "forward_losses_nll_ctc_binarisation_ms": dt_("dec1", "fwd_end"),
              "backward_losses_and_decoder_ms": dt_("fwd_end", "bwd_context_grad"),
              "backward_attention_text_encoder_ms": dt_("bwd_context_grad", "bwd_end"),
              "clip_and_radam_ms": dt_("bwd_end", "opt_end"), "whole_instrumented_step_ms": dt_("t0", "opt_end")}
-    return {"what": "TTSTrainingStep.training_step (text encoder + attention + on-device MAS + decoder + NLL/CTC/binarisation "
-                    "losses) + backward + clip 1.0 + FlatRAdam; tts_lightning_modules.py:643-750",
+    jinfo = {}
+    if joint:
+        npred = sum(p.numel() for n, p in model.named_parameters() if "_predictor." in n)
+        jinfo = {"joint": True, "predictors": sorted(JOINT_PREDICTORS), "predictor_parameters": npred,
+                 "gradient_buckets": [b["key"] for b in reducer.buckets], "loss_terms": sorted(last.get("losses", {})),
+                 "parity_vs_cpu": joint_parity}
+    return {"what": ("BASELINE configs[3]: decoder + f0 / energy / voiced / duration predictors (ConvLSTMLinearDAP at the YAML dims, "
+                     "dropout 0.5 on) in ONE step: " if joint else "") +
+                    "TTSTrainingStep.training_step (text encoder + attention + on-device MAS + decoder + NLL/CTC/binarisation "
+                    "losses) + backward + clip 1.0 + FlatRAdam; tts_lightning_modules.py:643-750", **jinfo,
             "batch": B, "frames": T, "text_tokens": t_txt, "steps": steps, "statistic": "median", "ms_per_step": ms,
             "value": B * T / (ms * 1e-3), "unit": "mel-frames/s", "loss": float(lv.detach()),
             "decoder_fwd_bwd_ms": decoder_only_ms, "ms_outside_decoder_fwd_bwd": ms - decoder_only_ms,
-            "share_outside_decoder": (ms - decoder_only_ms) / ms, "host_syncs_per_step": n_sync, "split": split}
+            "share_outside_decoder": (ms - decoder_only_ms) / ms, "host_syncs_per_step": n_sync, "split": split,
+            "mas_alignments_changed_by_log_choice": {"differing": mas_diff, "of": B,
+                                                     "what": "utterances whose hard alignment differs between the default device "
+                                                             "log (correctly rounded fp32) and RADMMM_MAS_LOG=host (numpy's "
+                                                             "float32 log, the reference's procedure, alignment.py:36)"}}
 
 
 def main():
@@ -481,7 +601,11 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="time only the dominant kernel and exit")
     ap.add_argument("--dominant-only", action="store_true",
                     help="launch only the roofline leg's kernel (the PMC passes of tools/pmc_dominant.sh wrap this)")
+    ap.add_argument("--joint-parity-utts", type=int, default=4,
+                    help="--config joint: utterances of the bench batch the CPU oracle runs the whole joint step on")
     args = ap.parse_args()
+    if args.config == "joint":
+        args.full_step = True
     if args.dominant_only:
         import rad_mmm_amd  # noqa: F401
         torch.cuda.set_device(0)
@@ -764,7 +888,7 @@ def main():
             "config": {"workload": ("RADTTS flow decoder (configs/RADTTS_model_config.yaml: 8 flows, WN 1024x4, "
                                     "D=1048) fwd+NLL+bwd") if args.config == "radtts" else
                                    ("RADMMM flow decoder (configs/RADMMM_model_config.yaml: 8 flows, WN 1024x4, D=1056) "
-                                    "fwd+NLL+bwd") if args.config == "radmmm" else
+                                    "fwd+NLL+bwd") if args.config in ("radmmm", "joint") else
                                    ("RADMMM 16 kHz-dims flow decoder (configs/RADMMM_16khz_model_config.yaml + "
                                     "n_splines=2: 2 spline/FiLM + 6 affine/WN flows, D=1056) fwd+NLL+bwd"),
                        "batch_per_gpu": B, "n_mel": 80, "frames": T,
@@ -854,7 +978,8 @@ def main():
             torch.cuda.synchronize()
         if world == 1 and args.full_step:
             reducer.detach()                          # the step-wide reducer of that leg takes over the decoder's parameters
-            res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms)
+            res["full_step"] = full_step_leg(dec, cfg, CFG, gb, B, T, dev, median_ms, joint=args.config == "joint",
+                                             parity_utts=0 if args.no_cpu_baseline else args.joint_parity_utts)
         # what the split producers reported over the whole run (ops.GradScale; published without host synchronisation)
         res["saturation"] = sat_report if sat_report is not None else saturation_report()
         res["roofline_hbm"] = hbm_rooflines(dec, cfg, B, T)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RADMMM_ABI_VERSION 2
+#define RADMMM_ABI_VERSION 3
 
 typedef void* radmmm_stream_t; /* hipStream_t */
 
@@ -98,7 +98,7 @@ typedef struct {
   int64_t a_item_stride; /* 0: row r at A + r*lda; else item b, frame t at A + b*a_item_stride + t*lda
                             (rows of one item may then overlap: lda < K is allowed, STFT framing) */
   const float* B; int ldb; int64_t b_tap_stride; int b_layout;
-  float* C; int ldc;
+  float* C; int ldc;      /* radmmm_rowgemm_h3: may be NULL when Ch is given (no fp32 copy of the result is written) */
   int M, N, K;
   int taps, dil, sign;
   int T;                 /* frames per item; M must be a multiple of T */
@@ -129,6 +129,13 @@ typedef struct {
    * deterministic), every other path runs radmmm_colsum on C afterwards.  colsum_scratch: device scratch of
    * radmmm_rowgemm_h3_colsum_scratch_floats(M, N) floats. */
   float* colsum_out; float* colsum_scratch;
+  /* optional (radmmm_rowgemm_h3; ABI 3): the dact step reads the saved OUTPUT y from its row-major 8-bit split copy instead
+   * of an fp32 array -- dact_h [M][lddact_h] fp16 hi, dact_x the RADMMM_SPLIT_X8A cross array of the same tensor, both
+   * written with scale 1 and exponent dact_x8_exp:  y = hi + e4m3_lo * 2^-(11 + dact_x8_exp)   (within 2^-15 |y| of the
+   * fp32 value the pair was split from; the softplus derivative 1 - exp(-y) then carries <= 1.2e-5 absolute).  dact_src
+   * must be NULL then.  With it a producer need not keep an fp32 copy of an activation beside its split pair:
+   * radmmm_rowgemm_h3 accepts C == NULL when Ch is given (the split copy alone carries the result). */
+  const void* dact_h; const void* dact_x; int lddact_h; int dact_x8_exp;
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);
@@ -213,7 +220,7 @@ int radmmm_weightnorm_bwd(const float* v, const float* g, const float* inv_norm,
  *   gctx[r, 0:D] (+)= gX0[r, 0:D] ; gz[r, 0:h] += gX0[r, D:D+h]
  * ------------------------------------------------------------------------------------ */
 int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz,
-                        float* X0, int ldx0, int rows, int D, int h,
+                        float* X0 /* may be NULL when the split copy is written (ABI 3) */, int ldx0, int rows, int D, int h,
                         void* X0h, void* X0l /* optional split copy, pitch ldx0, may be NULL */,
                         const radmmm_split_opts* so, radmmm_stream_t stream);
 int radmmm_wn_input_bwd(const float* gX0, int ldx0, float* gctx, int ldctx, int ctx_accum,

@@ -811,17 +811,26 @@ def dap_tx_data(x: Tensor, target_scale: float, target_offset: float, log_target
     return torch.log(x + 1) if log_target else x
 
 
-def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Tensor, n_layers: int) -> Tensor:
+def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Tensor, n_layers: int,
+                gates: Optional[Dict] = None, record: Optional[Dict] = None) -> Tensor:
     """ConvLSTMLinearDAP.forward in eval mode (attribute_predictors.py:172-192, common.py:281-333):
     bottleneck = leaky_relu(mask * weight-normed conv k3 (text_enc)); cat speaker; per utterance
     n_layers x relu(weight-normed conv k3) on the valid frames; packed spectral-normed bi-LSTM;
-    linear.  text_enc [B, C, T] -> x_hat [B, out_dim, T']."""
+    linear.  text_enc [B, C, T] -> x_hat [B, out_dim, T'].
+    Test accounting of the (leaky) ReLU's kink (not reference behaviour): `record` receives the pre-activations
+    ("bottleneck": [B, C, T]; (b, i): [1, C, len_b] of utterance b, layer i); `gates` (same keys, bool) overrides the
+    sign decision pre > 0 of the activation AND of its derivative -- an implementation whose pre-activation differs in
+    the last bits may sit on the other side of 0 for a handful of elements, which moves upstream gradients by O(1e-3);
+    with its decisions imposed the two gradients are comparable at full precision."""
     T = text_enc.shape[2]
     mask = lengths_to_mask(lens, T)[:, None].to(text_enc.dtype)
     pre = prefix + "bottleneck_layer.projection_fn.conv."
     w = weight_norm_fold(p[pre + "weight_v"], p[pre + "weight_g"])
     k = w.shape[-1]
-    ctx = F.leaky_relu(F.conv1d(text_enc, w, p[pre + "bias"], padding=(k - 1) // 2) * mask)
+    pb = F.conv1d(text_enc, w, p[pre + "bias"], padding=(k - 1) // 2) * mask
+    if record is not None:
+        record["bottleneck"] = pb.detach()
+    ctx = F.leaky_relu(pb) if gates is None else torch.where(gates["bottleneck"], pb, 0.01 * pb)
     ctx = torch.cat((ctx, spk[:, :, None].expand(-1, -1, T)), 1)
     outs = []
     for b in range(ctx.shape[0]):
@@ -829,7 +838,10 @@ def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Ten
         for i in range(n_layers):
             q = f"{prefix}feat_pred_fn.convolutions.{i}.conv."
             w = weight_norm_fold(p[q + "weight_v"], p[q + "weight_g"])
-            cur = torch.relu(F.conv1d(cur, w, p[q + "bias"], padding=(w.shape[-1] - 1) // 2))
+            pc = F.conv1d(cur, w, p[q + "bias"], padding=(w.shape[-1] - 1) // 2)
+            if record is not None:
+                record[(b, i)] = pc.detach()
+            cur = torch.relu(pc) if gates is None else torch.where(gates[(b, i)], pc, torch.zeros_like(pc))
         outs.append(cur[0].transpose(0, 1))
     xp = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True)
     lp = dict(p)
@@ -840,6 +852,68 @@ def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Ten
             lp[key] = spectral_weight(p[key + "_orig"], p[key + "_u"], p[key + "_v"])
     y = lstm_bidir_packed(lp, lpre, xp, lens, xp.shape[2] // 2)
     return F.linear(y, p[prefix + "feat_pred_fn.dense.weight"], p[prefix + "feat_pred_fn.dense.bias"]).transpose(1, 2)
+
+
+def tts_joint_step(p: Params, cfg: DecoderConfig, batch: Dict[str, Tensor], predictors: Dict[str, Dict],
+                   binarize: bool = True, bin_loss: bool = True, n_enc_conv: int = 3,
+                   ctc_loss_weight: float = 0.1, binarization_loss_weight: float = 1.0) -> Dict[str, object]:
+    """TTSModel.training_step (tts_lightning_modules.py:643-750) with dropout off, on CPU: mel scaling (:543-545), speaker /
+    accent / text embeddings (:246-268), text encoder, alignment attention with the prior (:440-475), per-item MAS when
+    `binarize` (:270-284), context = txt_enc . attn^T (:669), flow decoder + RADMMMLoss (loss.py:518-537: flow NLL, CTC x
+    ctc_loss_weight, binarisation loss when `bin_loss`), then the attribute predictors on DETACHED inputs (:688-727) with
+    their AttributeRegressionLoss (loss.py:233-250).  `p` holds the step's state_dict (reference names: text_embeddings.,
+    text_encoder., speaker_embeddings., accent_embeddings., attention., decoder., <name>_predictor.);
+    `predictors`: {"f0" | "energy" | "voiced" | "duration": dict(n_layers, target_scale, target_offset, log_target, weight,
+    prefix)}.  batch: mel [B, 80, T], speaker_ids, accent_ids, text [B, L], input_lengths, output_lengths, attn_prior
+    [B, T, L], f0, energy_avg [B, T], voiced_mask [B, T].  Returns losses {name: (value, weight)}, `loss` (their weighted
+    sum, :746-749), `pred` {name: x_hat} and the intermediate attn / context."""
+    in_lens, out_lens = batch["input_lengths"].long(), batch["output_lengths"].long()
+    mel = (batch["mel"] + 5) / 2
+    spk = p["speaker_embeddings.weight"][batch["speaker_ids"]]
+    acc = p["accent_embeddings.weight"][batch["accent_ids"]]
+    txt_emb = p["text_embeddings.weight"][batch["text"]].transpose(1, 2)               # [B, C, L]
+    L = int(in_lens.max())
+    txt_enc = encoder_forward(p, "text_encoder.", txt_emb, in_lens, n_enc_conv).transpose(1, 2)      # [B, C, L]
+    pad_mask = ~lengths_to_mask(in_lens, L)[..., None]
+    attn_soft, attn_logprob = conv_attention_forward(p, "attention.", mel, txt_emb[:, :, :L], pad_mask, batch["attn_prior"][:, :, :L])
+    attn = attn_soft
+    if binarize:
+        a = attn_soft.detach().numpy()
+        hard = np.zeros_like(a)
+        for b in range(a.shape[0]):                     # (the C restatement of the search: bit-equal to mas_width1, tests)
+            hard[b, 0, : int(out_lens[b]), : int(in_lens[b])] = mas_width1_c(a[b, 0, : int(out_lens[b]), : int(in_lens[b])].copy())
+        attn = attn_soft + (torch.from_numpy(hard) - attn_soft).detach()
+    context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
+    dp = {k[len("decoder."):]: v for k, v in p.items() if k.startswith("decoder.")}
+    out = decoder_forward(dp, cfg, mel, spk, context, out_lens, batch["f0"], batch["energy_avg"], acc)
+    losses: Dict[str, Tuple[Tensor, float]] = {}
+    lm, lp = decoder_loss(out, out_lens, cfg.n_group_size)
+    losses["loss_mel"], losses["loss_prior_mel"] = (lm, 1.0), (lp, 0.0)
+    losses["loss_ctc"] = (attention_ctc_loss(attn_logprob, in_lens, out_lens), ctc_loss_weight)
+    if bin_loss:
+        losses["binarization_loss"] = (attention_binarization_loss(attn, attn_soft), binarization_loss_weight)
+    pred = {}
+    spk_acc = torch.cat((spk, acc), 1).detach()
+    T = mel.shape[2]
+    for name, spec in predictors.items():
+        pre = f"{name}_predictor."
+        if name == "duration":
+            target, src, lens, tmask = attn.sum(2).detach(), txt_enc.detach(), in_lens, lengths_to_mask(in_lens, L)[:, None]
+        else:
+            raw = {"f0": batch["f0"], "energy": batch["energy_avg"], "voiced": batch["voiced_mask"]}[name]
+            target, src, lens = raw[:, None], context.detach(), out_lens
+            tmask = batch["voiced_mask"][:, None].bool() if name == "f0" else lengths_to_mask(out_lens, T)[:, None]
+        x = dap_tx_data(target, spec.get("target_scale", 1.0), spec.get("target_offset", 0.0), spec.get("log_target", False))
+        x_hat = dap_forward(p, pre, src, spk_acc, lens, spec["n_layers"])
+        w = x_hat.shape[2]
+        m = tmask[:, :, :w]
+        losses[spec["prefix"] + "loss"] = (F.mse_loss(x_hat[m], x[:, :, :w][m], reduction="sum") / tmask.sum(), spec.get("weight", 1.0))
+        pred[name] = x_hat
+    total = None
+    for v, wgt in losses.values():
+        total = v * wgt if total is None else total + v * wgt
+    return {"loss": total, "losses": losses, "pred": pred, "attn": attn, "attn_soft": attn_soft, "context": context,
+            "txt_enc": txt_enc, "z_mel": out["z_mel"]}
 
 
 def attribute_regression_loss(x_hat: Tensor, x: Tensor, lens: Tensor) -> Tensor:

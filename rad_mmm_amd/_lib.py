@@ -61,6 +61,7 @@ class RowGemmDesc(C.Structure):
         ("sat_flag", C.c_void_p),
         ("Clo", C.c_void_p),
         ("colsum_out", C.c_void_p), ("colsum_scratch", C.c_void_p),
+        ("dact_h", C.c_void_p), ("dact_x", C.c_void_p), ("lddact_h", C.c_int), ("dact_x8_exp", C.c_int),
     ]
 
 
@@ -128,7 +129,7 @@ def _load() -> C.CDLL:
     lib.radmmm_abi_version.restype = C.c_int
     lib.radmmm_gemm_cu_slots.restype = C.c_int
     lib.radmmm_gemm_cu_slots.argtypes = []
-    if lib.radmmm_abi_version() != 2:
+    if lib.radmmm_abi_version() != 3:
         raise ImportError("libradmmm_hip.so ABI version mismatch")
     i, i64, p = C.c_int, C.c_int64, C.c_void_p
     f = C.c_float

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void wn_input_fwd_kernel(
     float v = 0.f;
     if (c < D) v = ctx[(long long)r * ldctx + c];
     else if (c < D + h) v = z[(long long)r * ldz + (c - D)];
-    X0[i] = v;
+    if (X0) X0[i] = v;
     if (Xh) radmmm::store_split1_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v, lo16);   // split copy (same pitch), scale 1
   }
 }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void wn_input_fwd4_kernel(
       if (c + 1 < D + h) v.y = zp[1];
       if (c + 2 < D + h) v.z = zp[2];
     }
-    *reinterpret_cast<float4*>(X0 + (long long)r * ldx0 + c) = v;
+    if (X0) *reinterpret_cast<float4*>(X0 + (long long)r * ldx0 + c) = v;
     if (Xh) radmmm::store_split4_fmt(Xh, Xl, (long long)r * ldx0, c, fmt, x8_mul, 1.f, v.x, v.y, v.z, v.w, lo16);
   }
 }
@@ -629,7 +629,7 @@ extern "C" int radmmm_weightnorm_bwd(const float* v, const float* g, const float
 extern "C" int radmmm_wn_input_fwd(const float* ctx, int ldctx, const float* z, int ldz, float* X0,
                                    int ldx0, int rows, int D, int h, void* Xh, void* Xl,
                                    const radmmm_split_opts* so, radmmm_stream_t stream) {
-  RADMMM_REQUIRE(ctx && z && X0, "wn_input_fwd: null pointer");
+  RADMMM_REQUIRE(ctx && z && (X0 || Xh), "wn_input_fwd: null pointer (X0 may be NULL when the split copy Xh / Xl is written)");
   RADMMM_REQUIRE(rows > 0 && D > 0 && h > 0 && ldx0 >= D + h && ldctx >= D && ldz >= h, "wn_input_fwd: bad dims");
   const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
   RADMMM_REQUIRE(fmt == RADMMM_SPLIT_F16 || !Xh || (ldx0 % 32 == 0 && abs(so->x8_exp) <= 16), "wn_input_fwd: 8-bit format needs ldx0 %% 32 == 0");

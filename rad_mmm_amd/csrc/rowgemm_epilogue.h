@@ -11,7 +11,7 @@ struct EpilogueCtx {
   __device__ __forceinline__ explicit EpilogueCtx(const radmmm_rowgemm_desc& p) {
     need_row = p.pconv || p.premask || p.postmask || p.rowscale;
     vec_ok = (p.ldc % 4 == 0) && aligned16(p.C) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) &&
-             (!p.dact || (p.lddact % 4 == 0 && aligned16(p.dact_src))) &&
+             (!p.dact || p.dact_h || (p.lddact % 4 == 0 && aligned16(p.dact_src))) &&
              (!p.C2 || (p.ldc2 % 4 == 0 && aligned16(p.C2)));
   }
 };
@@ -29,6 +29,15 @@ __device__ __forceinline__ float store_split4(void* hi_, void* lo_, int ld, floa
   for (int e = 0; e < 4 && col + e < N; ++e)
     amax = fmaxf(amax, store_split1_fmt(hi_, lo_, (long long)row * ld, col + e, fmt, mul, s, x[e], lo16_));
   return amax;
+}
+
+// saved output y of the dact step from its 8-bit split copy (include/radmmm_hip.h: dact_h / dact_x):
+// y = hi + e4m3_lo * 2^-(11 + e)
+__device__ __forceinline__ float dact_src_from_pair(const radmmm_rowgemm_desc& p, int row, int col) {
+  const float hi = (float)static_cast<const _Float16*>(p.dact_h)[(long long)row * p.lddact_h + col];
+  const unsigned char b = static_cast<const unsigned char*>(p.dact_x)[(long long)row * p.lddact_h * 2 + x8_lo_off(col, RADMMM_SPLIT_X8A)];
+  const float lo = __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
+  return hi + lo * __builtin_ldexpf(1.f, -(11 + p.dact_x8_exp));
 }
 
 // per-row factors of the epilogue: length mask and partial-conv renormalisation ratio
@@ -75,7 +84,10 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
       const float4 t4 = *reinterpret_cast<const float4*>(p.add + (long long)row * p.ldadd + col);
       addv[0] = t4.x; addv[1] = t4.y; addv[2] = t4.z; addv[3] = t4.w;
     }
-    if (p.dact) {
+    if (p.dact && p.dact_h) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dsv[e] = dact_src_from_pair(p, row, col + e);
+    } else if (p.dact) {
       const float4 t4 = *reinterpret_cast<const float4*>(p.dact_src + (long long)row * p.lddact + col);
       dsv[0] = t4.x; dsv[1] = t4.y; dsv[2] = t4.z; dsv[3] = t4.w;
     }
@@ -88,7 +100,7 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
     for (int e = 0; e < 4; ++e) {
       if (col + e < p.N) {
         if (p.add) addv[e] = p.add[(long long)row * p.ldadd + col + e];
-        if (p.dact) dsv[e] = p.dact_src[(long long)row * p.lddact + col + e];
+        if (p.dact) dsv[e] = p.dact_h ? dact_src_from_pair(p, row, col + e) : p.dact_src[(long long)row * p.lddact + col + e];
         if (p.C2 && p.c2_accum) c2v[e] = p.C2[(long long)row * p.ldc2 + col + e];
       }
     }
@@ -113,14 +125,14 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
   if (p.Ch) amax = store_split4(p.Ch, p.Cl, p.ldch, p.ch_scale, p.split_fmt, p.ch_x8_exp, row, col, p.N, v, p.Clo);
   if (p.C2h) amax = fmaxf(amax, store_split4(p.C2h, p.C2l, p.ldc2h, p.c2h_scale, p.split_fmt, p.c2h_x8_exp, row, col, p.N, c2v));
   if (full) {
-    *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.C) *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
     if (p.C2)
       *reinterpret_cast<float4*>(p.C2 + (long long)row * p.ldc2 + col) = make_float4(c2v[0], c2v[1], c2v[2], c2v[3]);
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (col + e < p.N) {
-        p.C[(long long)row * p.ldc + col + e] = v[e];
+        if (p.C) p.C[(long long)row * p.ldc + col + e] = v[e];
         if (p.C2) p.C2[(long long)row * p.ldc2 + col + e] = c2v[e];
       }
     }

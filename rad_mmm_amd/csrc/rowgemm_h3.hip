@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_h3_kernel(const radmmm_rowgemm
 extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream) {
   RADMMM_REQUIRE(d != nullptr, "rowgemm_h3: null descriptor");
   const radmmm_rowgemm_desc& p = d->base;
-  RADMMM_REQUIRE(d->Ah && d->Al && d->Bh && d->Bl && p.C, "rowgemm_h3: null operand");
+  RADMMM_REQUIRE(d->Ah && d->Al && d->Bh && d->Bl, "rowgemm_h3: null operand");
+  RADMMM_REQUIRE(p.C || p.Ch, "rowgemm_h3: C may be NULL only when the split copy Ch / Cl carries the result");
   RADMMM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.taps >= 1 && p.T > 0 && p.M % p.T == 0, "rowgemm_h3: bad dims");
   RADMMM_REQUIRE(p.K % BK == 0, "rowgemm_h3: K=%d must be a multiple of 32", p.K);
   RADMMM_REQUIRE(p.b_layout == 0, "rowgemm_h3: both operands are K-contiguous (use a transposed weight copy)");
@@ -187,7 +188,10 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
                  "rowgemm_h3: split operands must be 16B aligned");
   RADMMM_REQUIRE(p.sign == 1 || p.sign == -1, "rowgemm_h3: sign must be +-1");
   RADMMM_REQUIRE(!(p.pconv || p.rowscale == 2) || (p.ratio_taps >= 1 && p.ratio_dil >= 1), "rowgemm_h3: ratio_taps/ratio_dil");
-  RADMMM_REQUIRE(!p.dact || p.dact_src, "rowgemm_h3: dact needs dact_src");
+  RADMMM_REQUIRE(!p.dact || (p.dact_src != nullptr) != (p.dact_h != nullptr), "rowgemm_h3: dact needs dact_src or the pair dact_h / dact_x");
+  RADMMM_REQUIRE(!p.dact_h || (p.dact_x && p.lddact_h % 32 == 0 && p.lddact_h >= p.N && abs(p.dact_x8_exp) <= 16 &&
+                               (reinterpret_cast<uintptr_t>(p.dact_h) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dact_x) & 3) == 0),
+                 "rowgemm_h3: dact_h / dact_x: an 8-bit split pair with ld %% 32 == 0");
   RADMMM_REQUIRE(!p.Ch || (p.Cl && p.ldch % 4 == 0 && p.ldch >= ((p.N + 3) & ~3)), "rowgemm_h3: Ch/Cl");
   RADMMM_REQUIRE(!p.C2h || (p.C2l && p.C2 && p.ldc2h % 4 == 0 && p.ldc2h >= ((p.N + 3) & ~3)), "rowgemm_h3: C2h/C2l");
   RADMMM_REQUIRE(p.split_fmt >= RADMMM_SPLIT_F16 && p.split_fmt <= RADMMM_SPLIT_X8B, "rowgemm_h3: split_fmt");
@@ -235,6 +239,7 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
                      (int)a_bytes, (int)b_bytes);
   const int rc = radmmm::check_launch("rowgemm_h3");
   if (rc || !p.colsum_out) return rc;
+  RADMMM_REQUIRE(p.C, "rowgemm_h3: colsum_out on this kernel sums C afterwards: C must not be NULL");
   return radmmm_colsum(p.C, p.ldc, p.colsum_out, p.colsum_scratch, p.M, p.N, p.rowscale == 2 ? 2 : (p.rowscale == 1 ? 1 : 0), p.T,
                        p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
 }

@@ -83,6 +83,10 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
   const radmmm_rowgemm_desc& p = d.base;
   if (rc || !p.colsum_out) return rc;
   if (ek != EK_GENERIC) return radmmm_colsum_final(p.colsum_scratch, p.colsum_out, (p.M + 32 * mb - 1) / (32 * mb), p.N, stream);
+  if (!p.C) {
+    set_error("rowgemm_h3: colsum_out with the generic epilogue sums C afterwards: C must not be NULL");
+    return -1;
+  }
   return radmmm_colsum(p.C, p.ldc, p.colsum_out, p.colsum_scratch, p.M, p.N, p.rowscale == 2 ? 2 : (p.rowscale == 1 ? 1 : 0), p.T,
                        p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
 }
@@ -107,8 +111,10 @@ static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t
     return e && e[0] == 'g';
   }();
   int ek = EK_GENERIC;
+  // (the pair form of the dact input is decoded by the FP8-cross scheme's direct kernels and by the generic epilogue)
   const bool ok = !force_generic && p.N % 2 == 0 && !p.add && p.ldc % 2 == 0 && a8(p.C) && fits(p.ldc, 4) &&
-                  (!p.dact || (p.lddact % 2 == 0 && a8(p.dact_src) && fits(p.lddact, 4))) &&
+                  (!p.dact_h || d.nprod == 2) &&
+                  (!p.dact || (p.dact_h ? fits(p.lddact_h, 2) : (p.lddact % 2 == 0 && a8(p.dact_src) && fits(p.lddact, 4)))) &&
                   (!p.C2 || (p.ldc2 % 2 == 0 && a8(p.C2) && fits(p.ldc2, 4))) &&
                   (!p.Ch || (p.ldch % 2 == 0 && a4(p.Ch) && a4(p.Cl) && a4(p.Clo) && fits(p.ldch, 2))) &&
                   (!p.C2h || (p.ldc2h % 2 == 0 && a4(p.C2h) && a4(p.C2l) && fits(p.ldc2h, 2)));

@@ -117,6 +117,19 @@ __device__ __forceinline__ void epilogue_blocks(const f32x16 (&acc)[MB][2], floa
 // uniform branches (the asm statements keep the optimizer from turning the chain into a dynamic index -- which would
 // move all accumulators to scratch -- or into 7-way selects), so the body exists once (~13 KB of code; seven unrolled
 // copies do not fit the instruction cache: measured +50 us per launch in round 2).
+// TIMING-ONLY builds (wrong results; tools/floor_probe.sh, profiles/r05_nprod1_floor.txt): what is a launch made of?
+//   -DRADMMM_TIMING=1  the cross-term (FP8) MFMAs are not issued: half the matrix work, everything else in place
+//   -DRADMMM_TIMING=2  "nprod = 1" in the instruction stream: additionally no cross-fragment LDS reads (the DMA stays: the
+//                      counted vmcnt waits of the loops depend on the number of pieces)
+//   -DRADMMM_TIMING=3  no MFMA at all (fragments are still read: operands pinned by empty asm): the launch's non-MFMA floor
+#ifndef RADMMM_TIMING
+#define RADMMM_TIMING 0
+#endif
+#if RADMMM_TIMING == 3
+#define RADMMM_MFMA_F16(A, B, C) ([&] { asm volatile("" : : "v"(A), "v"(B)); return (C); }())
+#else
+#define RADMMM_MFMA_F16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0)
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -199,11 +212,16 @@ __device__ __forceinline__ float store_pair_split(__amdgpu_buffer_rsrc_t rH, __a
 //   x = (acc * pre + bias) * post;  x *= act'(dact_src) [EK_DGRAD];  x *= rowscale factor;  y = act(x)
 // X8: the split copies are written in the 8-bit cross format (the FP8-cross scheme's kernels) / as fp16 pairs.
 // ACTK / DACTK: 0 none, 1 softplus, 2 the descriptor's code at run time -- the caller branches ONCE per launch between
-// the specialised copies of the row-block loop, so the per-element code has no activation switch.
-template <int MB, int EK, bool X8, int ACTK, int DACTK>
+// the specialised copies of the row-block loop, so the per-element code has no activation switch.  DACTK 3 / 4 = 1 / 2 with
+// the saved output read from its 8-bit split pair (radmmm_rowgemm_desc.dact_h / dact_x: a 4-byte load of the fp16 hi pair
+// + a 2-byte load of the e4m3 lo pair per row and column pair instead of 8 bytes of fp32; y = hi + lo * 2^-(11 + e)).
+// C == NULL (the split copy alone carries the result): its descriptor has size 0 and the hardware drops the stores.
+template <int MB, int EK, bool X8, int ACTK, int DACTK_>
 __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const float4* rowf, const radmmm_rowgemm_desc& p,
                                               int m0, int n0, int lane, int wave, float& sat) {
   constexpr bool DACT = EK == EK_DGRAD, C2M = EK == EK_RES, SPLIT = EK == EK_SPLIT || EK == EK_DGRAD;
+  constexpr bool DPAIR = DACT && DACTK_ >= 3;
+  constexpr int DACTK = DPAIR ? DACTK_ - 2 : DACTK_;
   constexpr bool SIDE = DACT || C2M;
   const int jj = lane & 31, h = lane >> 5;
   const int col = n0 + wave * 64 + 2 * jj;
@@ -218,10 +236,30 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   const __amdgpu_buffer_rsrc_t rC = rsrc_of(p.C, M * p.ldc * 4);
   const int vC = cok ? (4 * h * p.ldc + col) * 4 : OOB;
   // side input: dact_src (EK_DGRAD) or C2 when accumulating (EK_RES; a null descriptor reads as zeros)
-  const float* side_ptr = DACT ? p.dact_src : ((C2M && p.c2_accum) ? p.C2 : nullptr);
-  const int ldside = DACT ? p.lddact : p.ldc2;
-  const __amdgpu_buffer_rsrc_t rS = rsrc_of(SIDE ? side_ptr : nullptr, M * ldside * 4);
-  const int vS = cok ? (4 * h * ldside + col) * 4 : OOB;
+  const void* side_ptr = DPAIR ? p.dact_h : (DACT ? (const void*)p.dact_src : ((C2M && p.c2_accum) ? (const void*)p.C2 : nullptr));
+  const int ldside = DPAIR ? p.lddact_h : (DACT ? p.lddact : p.ldc2);
+  constexpr int SESZ = DPAIR ? 2 : 4;                            // bytes per element of the side array's rows
+  const __amdgpu_buffer_rsrc_t rS = rsrc_of(SIDE ? side_ptr : nullptr, M * ldside * SESZ);
+  const int vS = cok ? (4 * h * ldside + col) * SESZ : OOB;
+  const __amdgpu_buffer_rsrc_t rSx = rsrc_of(DPAIR ? p.dact_x : nullptr, M * ldside * 2);          // the pair's cross array
+  // (the lo8 pair of columns col, col + 1 is 2-byte aligned; it is fetched as the aligned 4-byte word around it and shifted
+  //  down -- a 2-byte buffer load through the builtin was folded away by the compiler (ROCm 7.2: no buffer_load_ushort in the
+  //  ISA, the hi pair's register was converted instead), found by tests/test_hip_round5.py)
+  const unsigned xlo_off = radmmm::x8_lo_off(col, RADMMM_SPLIT_X8A);
+  const int vSx = (DPAIR && cok) ? (int)(4 * h * ldside * 2 + (xlo_off & ~3u)) : OOB;
+  const int xlo_sh = (int)(xlo_off & 2u) * 8;
+  const float dp_lsc = __builtin_ldexpf(1.f, -(11 + p.dact_x8_exp));
+  // (the pair's two words stay INTEGERS end to end: [0] the fp16 hi pair, [1] the aligned word around the e4m3 lo pair)
+  auto load_side = [&](int row) __attribute__((always_inline)) {
+    u32x2 r;
+    if constexpr (DPAIR) {
+      r[0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rS, vS, row * ldside * 2, 0);
+      r[1] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rSx, vSx, row * ldside * 2, 0);
+    } else {
+      r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rS, vS, row * ldside * 4, 0));
+    }
+    return r;
+  };
   const __amdgpu_buffer_rsrc_t rC2 = rsrc_of(C2M ? p.C2 : nullptr, M * p.ldc2 * 4);
   const int vC2 = cok ? (4 * h * p.ldc2 + col) * 4 : OOB;
   // split outputs (of y: EK_SPLIT / EK_DGRAD; of C2: EK_RES, optional)
@@ -250,11 +288,10 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     if constexpr (DACTK == 1) return y > 20.f ? 1.f : radmmm::one_minus_exp_neg(y);
     else return radmmm::dact_from_out(y, dact);
   };
-  f32x2 side[16], side_n[16];
+  u32x2 side[16], side_n[16];
   if constexpr (SIDE) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      side[e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rS, vS, (m0 + row_of(e)) * ldside * 4, 0));
+    for (int e = 0; e < 16; ++e) side[e] = load_side(m0 + row_of(e));
   }
   const int left = (p.M - m0 + 31) / 32;
   const int nblk = left < MB ? left : MB;
@@ -267,8 +304,7 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     const int r0 = m0 + I * 32;
     if constexpr (SIDE) {                                          // next block's side inputs, ahead of this block's stores
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        side_n[e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rS, vS, (r0 + 32 + row_of(e)) * ldside * 4, 0));
+      for (int e = 0; e < 16; ++e) side_n[e] = load_side(r0 + 32 + row_of(e));
     }
     float4 rfs[16];                                                // the block's row factors (LDS), all requested up front
 #pragma unroll
@@ -280,9 +316,15 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
       const int ru = r0 + row_of(e);                               // uniform part of the row
       const float4 rf = rfs[e];
       float x0 = (v[0][e] * rf.x + b0) * rf.y, x1 = (v[1][e] * rf.x + b1) * rf.y;
-      if constexpr (DACT) {
-        x0 *= dactf(side[e][0]);
-        x1 *= dactf(side[e][1]);
+      const f32x2 sidef = __builtin_bit_cast(f32x2, side[e]);
+      if constexpr (DPAIR) {
+        const f16x2 hp = __builtin_bit_cast(f16x2, side[e][0]);
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)(side[e][1] >> xlo_sh), false);
+        x0 *= dactf(fmaf(lo[0], dp_lsc, (float)hp[0]));
+        x1 *= dactf(fmaf(lo[1], dp_lsc, (float)hp[1]));
+      } else if constexpr (DACT) {
+        x0 *= dactf(sidef[0]);
+        x1 *= dactf(sidef[1]);
       }
       if (cs_on) {                                                 // (uniform)
         const float m = (rf.z != 0.f && ru + 4 * h < p.M) ? 1.f : 0.f;
@@ -296,7 +338,7 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
       RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0));
       if constexpr (C2M) {
         f32x2 c2;
-        c2[0] = side[e][0] + x0; c2[1] = side[e][1] + x1;          // (side reads as zero when not accumulating)
+        c2[0] = sidef[0] + x0; c2[1] = sidef[1] + x1;              // (side reads as zero when not accumulating)
         RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0));
         if (c2split)
           sat = fmaxf(sat, store_pair_split<X8>(rH, rL, rLo16, false, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, c2[0], c2[1]));
@@ -325,6 +367,13 @@ template <int MB, int EK, bool X8>
 __device__ __forceinline__ void direct_epilogue(const f32x16 (&acc)[MB][2], const float4* rowf, const radmmm_rowgemm_desc& p,
                                                 int m0, int n0, int lane, int wave, float& sat) {
   if constexpr (EK == EK_DGRAD) {                      // (host: act none on this kind)
+    if constexpr (X8) {                                // the saved output as its 8-bit split pair (dact_h / dact_x)
+      if (p.dact_h) {
+        if (p.dact == RADMMM_ACT_SOFTPLUS) direct_blocks<MB, EK, X8, 0, 3>(acc, rowf, p, m0, n0, lane, wave, sat);
+        else direct_blocks<MB, EK, X8, 0, 4>(acc, rowf, p, m0, n0, lane, wave, sat);
+        return;
+      }
+    }
     if (p.dact == RADMMM_ACT_SOFTPLUS) direct_blocks<MB, EK, X8, 0, 1>(acc, rowf, p, m0, n0, lane, wave, sat);
     else direct_blocks<MB, EK, X8, 0, 2>(acc, rowf, p, m0, n0, lane, wave, sat);
   } else {

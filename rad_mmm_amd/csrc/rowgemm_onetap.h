@@ -68,19 +68,27 @@ __device__ __forceinline__ void one_tap_steps(f32x16 (&acc)[MB][2], unsigned cha
     fah[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1] + a_off);
   };
   auto read_lo = [&](int t, int a_off) __attribute__((always_inline)) {
+#if RADMMM_TIMING != 2
     fal[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1] + a_off + G::A_PLANE);
+#endif
   };
   auto read_b1 = [&](int set, int kb, int j) __attribute__((always_inline)) {      // B stage = register set
     const int fo = (kb ? bad1 : bad0) + set * G::B_STAGE + j * 32 * ROWB;
     bh[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + fo);
+#if RADMMM_TIMING != 2
     bl[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + fo + G::B_BYTES);
+#endif
   };
   auto cross = [&](int set, int i, int j) __attribute__((always_inline)) {
     const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, fal[2 * i]), __builtin_bit_cast(i32x4, fal[2 * i + 1]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
+#if RADMMM_TIMING == 0
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], RADMMM_X_FMT, RADMMM_X_FMT, 0, x_sa, 0, x_sb);
+#elif RADMMM_TIMING != 2
+    asm volatile("" : : "v"(a8), "v"(b8));
+#endif
   };
 
   // prologue: tiles 0 and 1 (A stages 0 / 1, B stages 0 / 1); tile 0 must have landed everywhere, tile 1 may still fly
@@ -110,13 +118,13 @@ __device__ __forceinline__ void one_tap_steps(f32x16 (&acc)[MB][2], unsigned cha
         __builtin_amdgcn_sched_barrier(0);
       }
       // slot A
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][0], acc[i][0], 0, 0, 0);
+      acc[i][0] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][0], acc[i][0]);
       if (t + D < NT) read_hi(t + D, a_cur);
       else read_hi(t + D - NT, a_nxt);
       if (t >= TW) read_b1(set ^ 1, t - TW, 0);
       __builtin_amdgcn_sched_barrier(0);
       // slot B
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][1], acc[i][1], 0, 0, 0);
+      acc[i][1] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][1], acc[i][1]);
       if (t + D < NT) read_lo(t + D, a_cur);
       else read_lo(t + D - NT, a_nxt);
       if (t >= TW) read_b1(set ^ 1, t - TW, 1);

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   };
   auto read_lo = [&](int t, auto tapc, auto parc) __attribute__((always_inline)) {
     constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
-#ifdef RADMMM_SKIP_LO_READS                 // TIMING-ONLY build (wrong results): the cross-term MFMAs run on the hi fragments -- what do
+#if RADMMM_TIMING == 2
+    (void)t;
+#elif defined(RADMMM_SKIP_LO_READS)         // TIMING-ONLY build (wrong results): the cross-term MFMAs run on the hi fragments -- what do
     fal[t] = fah[t];                        // the 14 lo-fragment LDS reads per wave and K step cost a power-bound launch?
 #else
     fal[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1][tap] + par * G::W_BYTES + G::W_PLANE);
@@ -177,7 +179,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   auto read_b1 = [&](int set, int stage, int kb, int j) __attribute__((always_inline)) {
     const int fo = kb ? bad1 : bad0;
     bh[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + stage * G::B_STAGE + j * 32 * ROWB + fo);
+#if RADMMM_TIMING != 2
     bl[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + stage * G::B_STAGE + G::B_BYTES + j * 32 * ROWB + fo);
+#endif
   };
   const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;       // E8M0 block scales (rowgemm_h3d, PR 2)
   const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
@@ -186,7 +190,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
+#if RADMMM_TIMING == 0
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], RADMMM_X_FMT, RADMMM_X_FMT, 0, x_sa, 0, x_sb);
+#elif RADMMM_TIMING != 2
+    asm volatile("" : : "v"(a8), "v"(b8));
+#endif
   };
   // DMA with the step's position as the instruction's SCALAR offset (no vector add per piece; an out-of-range vector offset
   // stays out of range: the scalar offset takes part in the range check on gfx950)
@@ -257,13 +265,13 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
         __builtin_amdgcn_sched_barrier(0);
       }
       // slot A
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][0], acc[i][0], 0, 0, 0);
+      acc[i][0] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][0], acc[i][0]);
       if (t + D < NT) read_hi(t + D, TapC{}, ParC{});
       else read_hi(t + D - NT, NTapC{}, NParC{});
       if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 0);
       __builtin_amdgcn_sched_barrier(0);
       // slot B
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[t], bh[set][kbk][1], acc[i][1], 0, 0, 0);
+      acc[i][1] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][1], acc[i][1]);
       if (t + D < NT) read_lo(t + D, TapC{}, ParC{});
       else read_lo(t + D - NT, NTapC{}, NParC{});
       if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 1);

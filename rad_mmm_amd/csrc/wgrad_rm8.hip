@@ -76,6 +76,21 @@ using WG8Plain = std::true_type;
 using WG8Plain = std::false_type;
 #endif
 
+// TIMING-ONLY builds (wrong results; rowgemm_h3w_kernel.h has the list): 1 / 2 no cross-term MFMAs, 3 no MFMA at all
+#ifndef RADMMM_TIMING
+#define RADMMM_TIMING 0
+#endif
+#if RADMMM_TIMING == 3
+#define WG8_MFMA_F16(A, B, C) ([&] { asm volatile("" : : "v"(A), "v"(B)); return (C); }())
+#else
+#define WG8_MFMA_F16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0)
+#endif
+#if RADMMM_TIMING == 0
+#define WG8_MFMA_X(A, B, C, SA, SB) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (C), 0, 0, 0, (SA), 0, (SB))
+#else
+#define WG8_MFMA_X(A, B, C, SA, SB) ([&] { asm volatile("" : : "v"(A), "v"(B)); return (C); }())
+#endif
+
 struct Frag { i32x2 lo, hi; };
 // Fragment addressing.  All lane-dependent parts of a fragment's LDS address are computed ONCE (round 3, second pass: the K
 // step carried ~270 VALU instructions beside its 48 MFMAs -- more than the MFMA gaps hide -- of which 30 were these address
@@ -119,9 +134,13 @@ __device__ __forceinline__ void frag_wait3(Frag& a, Frag& b, Frag& c) {
 __device__ __forceinline__ int cvt4_fp8(int lo2, int hi2, float inv) {
   // two packed conversions into the two halves of ONE register.  As inline asm with a write-only destination: the builtin's
   // destination is read-modify-write, and the compiler materialises its (dead) initial value with a v_mov -- 40 per K step.
+#ifdef RADMMM_TIMING_NOCVT                 // TIMING-ONLY build (wrong results): the 80 hi8 conversions per K step are not issued --
+  return lo2 ^ hi2;                         // upper bound of "read the hi8 halves from the cross arrays instead" (profiles/r05_wgrad_hi8.txt)
+#else
   int o;
   asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %3\n\tv_cvt_scalef32_pk_fp8_f16 %0, %2, %3 op_sel:[0,0,1]" : "=&v"(o) : "v"(lo2), "v"(hi2), "v"(inv));
   return o;
+#endif
 }
 __device__ __forceinline__ i32x4 hi8_of(const Frag& f0, const Frag& f1, float inv) {
   i32x4 r;
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         const i32x8 a8 = __builtin_shufflevector(ah8[i & 1], l8c, 0, 1, 2, 3, 4, 5, 6, 7);
         i32x4 h8n;                                                 // hi8 of block i + 1, converted under this block's f16 MFMAs
         // slot 0
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[0], acc[i][0], 0, 0, 0);
+        acc[i][0] = WG8_MFMA_F16(ah0, bh0[0], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         if (i2 < 4) frag_issue<0>(ga0[nx2], ah_base[i2 & 3] + sb2);
         else frag_issue<256>(ga0[nx2], ah_base[i2 & 3] + sb2);
@@ -413,20 +432,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         if (i == 7) frag_issue<0>(xb0[0], bh_base[0] + sbn);        // (bh0[0] holds the old value: last read by the MFMA above)
         __builtin_amdgcn_sched_barrier(0);
         // slot 1
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0[1], acc[i][1], 0, 0, 0);
+        acc[i][1] = WG8_MFMA_F16(ah0, bh0[1], acc[i][1]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         if (i2 < 4) frag_issue<8192>(ga1[nx2], ah_base[i2 & 3] + sb2);
         else frag_issue<8192 + 256>(ga1[nx2], ah_base[i2 & 3] + sb2);
         if (i == 7) frag_issue<0>(xb0[1], bh_base[1] + sbn);
         __builtin_amdgcn_sched_barrier(0);
         // slot 2
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[0], acc[i][0], 0, 0, 0);
+        acc[i][0] = WG8_MFMA_F16(ah1, bh1[0], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         frag8_issue(ga8[nx2], a8_base[i2] + sb2);
         if (i == 7) frag_issue<8192>(xb1[0], bh_base[0] + sbn);
         __builtin_amdgcn_sched_barrier(0);
         // slot 3
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[1], acc[i][1], 0, 0, 0);
+        acc[i][1] = WG8_MFMA_F16(ah1, bh1[1], acc[i][1]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         if (i == 0) {
           frag_wait2<6>(xb8[0], xb8[1]);                           // (younger: this block's six A reads)
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         if (i == 7) frag_issue<8192>(xb1[1], bh_base[1] + sbn);
         __builtin_amdgcn_sched_barrier(0);
         // slot 4
-        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[0], acc[i][0], 0, 0, 0, x_sa, 0, x_sb);
+        acc[i][0] = WG8_MFMA_X(a8, b8[0], acc[i][0], x_sa, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         if (i < 6) dma_piece(nbuf, 2 * i, l_rel, nmask);
         if (i == 1) nmask = row_mask();                            // (first needed by block 2's pieces)
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // slot 5
-        acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[1], acc[i][1], 0, 0, 0, x_sa, 0, x_sb);
+        acc[i][1] = WG8_MFMA_X(a8, b8[1], acc[i][1], x_sa, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
         if (i < 6) dma_piece(nbuf, 2 * i + 1, l_rel, nmask);
         h8n[2] = cvt4_fp8(ga1[nx1].lo[0], ga1[nx1].lo[1], g_inv);

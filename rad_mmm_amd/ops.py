@@ -1230,9 +1230,16 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         #  keeps the three-product gradient on (hi, fp16 lo) pairs for A/B runs)
         rm8 = use_rm and NPR == 2 and Wc % 32 == 0 and debug_env("RADMMM_WGRAD_RM8", "1") != "0"
         lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2 and not rm8) else (lambda: None)
+        # Round 5: with the FP8-cross weight gradient (rm8) NOTHING reads an fp32 copy of the WN input or of the hidden states
+        # any more -- the GEMMs and the weight gradients take the split pairs, and the data gradient's softplus' factor is
+        # rebuilt from the pair (radmmm_rowgemm_desc.dact_h / dact_x: hi + lo8 * 2^-(11+e), 2^-15 relative) -- so the
+        # producers write the pair only (C = NULL): 8 instead of 16 bytes per hidden-state element leave the forward
+        # epilogues, 311 MB per flow step at the benchmark size.  RADMMM_KEEP_FP32=1 (RADMMM_DEBUG) keeps round 4's copies.
+        pair_only = bool(rm8 and debug_env("RADMMM_KEEP_FP32", "0") != "1")
+        hid = (lambda: None) if pair_only else (lambda: _empty(N, Wc, like=z_in))
         z1 = _empty(N, ZLD, like=z_in)
         rowgemm(A=z_in, lda=ZLD, B=W_eff, ldb=ZLD, b_layout=0, C=z1, ldc=ZLD, M=N, N=ZLD, K=ZLD, T=T, bias=b_eff)
-        X0 = _empty(N, Kp, like=z_in)
+        X0 = None if pair_only else _empty(N, Kp, like=z_in)
         X0h, X0l = _halves(N, Kp, like=z_in)
         X0lo = torch.empty(N, Kp, device=z_in.device, dtype=torch.float16) if (use_rm and NPR == 2 and not rm8) else None
         check(lib.radmmm_wn_input_fwd(ptr(cond), D, ptr(z1), ZLD, ptr(X0), Kp, N, D, h, ptr(X0h), ptr(X0l),
@@ -1250,7 +1257,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         Wrh, Wrl, inv_r = [sw[2 + 2 * j][0] for j in range(nl)], [sw[2 + 2 * j][1] for j in range(nl)], [sw[2 + 2 * j][2] for j in range(nl)]
         Weh, Wel, _ = sw[-1]
 
-        H = [_empty(N, Wc, like=z_in)]
+        H = [hid()]
         Hh, Hl = _halves(N, Wc, like=z_in)
         Hlo = lo16()
         rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
@@ -1262,7 +1269,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         for j in range(nl):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
-            Hn = _empty(N, Wc, like=z_in)
+            Hn = hid()
             Hnh, Hnl = _halves(N, Wc, like=z_in)
             Hnlo = lo16()
             rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wih[j], Bl=Wil[j], ldb_h=Wc, b_tap_stride_h=Wih[j].stride(0),
@@ -1289,6 +1296,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         ctx.nl = nl
         ctx.use_rm = use_rm
         ctx.rm8 = rm8
+        ctx.pair_only = pair_only
+        if pair_only:                             # (placeholders keep the saved-tensor layout; never read on this path)
+            X0 = z1[:0]
+            H = [z1[:0]] * (nl + 1)
         rm_saved = [X0h, X0lo if X0lo is not None else X0l, *[t for pr in pairs for t in pr]] if use_rm else []
         # the end conv's weight gradient contracts gO with OUT: with OUT's split pair kept (52 MB per flow step) it runs on
         # the same row-major kernels as every other weight gradient of the step instead of the fp32-MFMA one (50 -> ~25 us)
@@ -1331,12 +1342,13 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         h = C // 2
         N = B * T
         Wc = start_v.shape[0]
-        Kp = X0.shape[1]
+        Kp = Wsh.shape[2]
         g_zout = g_zout.contiguous()
         if g_logs is not None:
             g_logs = g_logs.contiguous()
         box = meta["scale_box"]
         rm8 = ctx.rm8
+        pair_only = getattr(ctx, "pair_only", False)
         lo16 = (lambda: torch.empty(N, Wc, device=z_in.device, dtype=torch.float16)) if (use_rm and NPR == 2 and not rm8) else (lambda: None)
 
         def wg_rm(gpair, xpair_, Mc_, Nc_, taps_, dil_, lens_=None):
@@ -1437,14 +1449,20 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 x_t = x_prev if x_prev is not None else transpose_split_act(H[j + 1], Wc, B, T, None, 0, 1.0, "x")
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc, poison=poison)
-            g_conv = _empty(N, Wc, like=z_in)
             keep_pair = fuse and j > 0               # g_conv_j's split copy becomes the first half of the next pair
             nh, nlo = _halves(2 * N if keep_pair else N, Wc, like=z_in)
             gch, gcl = nh[:N], nlo[:N]
             gclo = lo16()
-            epi = dict(C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens, dact_src=H[j + 1], lddact=Wc, dact=act,
-                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, Clo=gclo, ldch=Wc, ch_scale=SG)
             cs_here = fuse_cs and (fused or G is None)         # (a launch with an `add` input keeps the separate pass)
+            # the fp32 copy of the pre-activation gradient is read by nobody when its bias sums come out of the epilogue
+            # and the weight gradient contracts the pair (round 5: C = NULL, 52 MB per launch less to write)
+            g_conv = None if (pair_only and cs_here and use_rm) else _empty(N, Wc, like=z_in)
+            if pair_only:                            # softplus' of the hidden state from its split pair (hi, cross array)
+                dsrc = dict(dact_h=Hpair[j + 1][0], dact_x=Hpair[j + 1][1], lddact_h=Wc, dact_x8_exp=X8_ACT_EXP)
+            else:
+                dsrc = dict(dact_src=H[j + 1], lddact=Wc)
+            epi = dict(C=g_conv, ldc=Wc, M=N, N=Wc, K=Wc, lens=lens, dact=act, **dsrc,
+                       rowscale=2 if partial else 1, ratio_taps=kt, ratio_dil=d, Ch=gch, Cl=gcl, Clo=gclo, ldch=Wc, ch_scale=SG)
             gb, cs = cs_args(in_p[3 * j + 2]) if cs_here else (None, {})
             if fused:
                 WTh, WTl, ktn, dn = WT_prev
@@ -1488,10 +1506,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 G = None
             else:
                 WiTh, WiTl = pre[("in", j)] if pre else transpose_split(Wih[j], Wil[j], Wc, Wc, Wc, NPR)   # [taps][ci][co]
-                G = _empty(N, Wc, like=z_in)
                 if j == 0:
                     Gh, Gl = _halves(N, Wc, like=z_in)
                     Glo = lo16()
+                # (dL/dH_0: consumed as its split pair by the start conv's gradients; fp32 only for an unfused bias sum)
+                G = None if (pair_only and fuse_cs and j == 0) else _empty(N, Wc, like=z_in)
                 g_start_b, cs = cs_args(start_b) if (fuse_cs and j == 0) else (None, {})
                 rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
                            C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,

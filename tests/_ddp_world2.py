@@ -85,9 +85,11 @@ def main():
         if args.negative and red.active:
             # control: declare the SAME flow step's lower-half bucket final as well -- its gradients (layers 1, 0, the start
             # conv, the channel mix) have not been written yet, so its all-reduce starts on stale data
+            # (flow 1 only: every parameter of its lower half writes through its sink -- flow 0's whitening conv goes through
+            #  stock autograd, which the reducer's own guard would refuse to pair with an early start)
             key = red._by_param[id(red._by_ptr[ptrs[0]])]["key"]
             for bk in red.buckets:
-                if bk["key"] == key[:-3] + ".lo" and not bk["ready"]:
+                if key.startswith("flows.1.") and bk["key"] == key[:-3] + ".lo" and not bk["ready"]:
                     for p in bk["params"]:
                         red._early.add(id(p))
                     bk["pending"], bk["ready"] = 0, True
@@ -145,15 +147,29 @@ def main():
         step(dec, parts[rank])
         red.finish()
         torch.cuda.synchronize()
-        worst_l2, worst_name = 0.0, ""
+        worst_l2, worst_name, worst_sp, worst_sp_name = 0.0, "", 0.0, ""
         gref = dict(ref.named_parameters())
         for n, p in dec.named_parameters():
+            # (scale and bias of the conv that feeds a batch-norm have an analytically ZERO gradient -- the normalisation
+            #  removes both: what is left is rounding residue, not comparable in relative terms)
+            if n.endswith(("hidden_conv.conv.weight_g", "hidden_conv.conv.bias")):
+                continue
             a, w = p.grad.detach().double(), gref[n].grad.detach().double()
             e = float((a - w).norm() / w.norm().clamp_min(1e-30))
-            if e > worst_l2:
+            # the spline flow's own parameters and everything upstream of it (the context LSTM) see the log-Jacobian's KINK at
+            # the knots: synchronised statistics (partial sums all-reduced) and the concatenated run's differ in the last bit,
+            # an element within an ulp of a bin edge then takes the neighbouring bin -- continuous in z, O(1) in that element's
+            # parameter gradient, ~1e-3 of the tensor (profiles/r03_spline_bin_edge_ties.txt).  The affine flow behind
+            # it only sees z: held to 2e-4.  A wrong exchange (stale data, a missing 1/2) is O(1) on every tensor.
+            if n.startswith(("flows.0.", "context_lstm.")):
+                if e > worst_sp:
+                    worst_sp, worst_sp_name = e, n
+            elif e > worst_l2:
                 worst_l2, worst_name = e, n
         assert worst_l2 <= 2e-4, (worst_l2, worst_name)
-        print(f"DDP_WORLD2_SPLINE_SYNCBN_OK rank={rank} worst_l2={worst_l2:.3e} ({worst_name})", flush=True)
+        assert worst_sp <= 5e-3, (worst_sp, worst_sp_name)
+        print(f"DDP_WORLD2_SPLINE_SYNCBN_OK rank={rank} affine_flow_worst_l2={worst_l2:.3e} ({worst_name}) "
+              f"spline_flow_and_upstream_worst_l2={worst_sp:.3e} ({worst_sp_name})", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
