@@ -349,6 +349,46 @@ def build_joint_predictors(CFG, p_dropout=0.5):
     return out
 
 
+def build_step_model(dec, CFG, dev, joint=False):
+    """TTSTrainingStep around `dec` as the full-step / joint legs run it (text encoder, attention, criterion; joint: + the four
+    attribute predictors of configs[3] with their spectral norms' power iteration converged)"""
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    torch.manual_seed(1234)
+    extra = build_joint_predictors(CFG) if joint else {}
+    model = TTSTrainingStep(Encoder(3, CFG["n_text_dim"], 5), dec, RADMMMLoss(sigma=1.0, kl_loss_start_iter=0),
+                            n_speakers=8, n_accents=4, n_text_tokens=185, n_text_dim=CFG["n_text_dim"],
+                            n_speaker_dim=CFG["n_speaker_dim"], n_accent_dim=CFG["n_accent_dim"], use_accent=True,
+                            use_accent_emb_for_decoder=CFG["use_accent_emb_for_decoder"], binarization_start_iter=0,
+                            **extra).to(dev).train()
+    if joint:
+        for name in JOINT_PREDICTORS:                       # converge spectral norm's power iteration (fresh u / v leave |W_hh| ~ 10)
+            lstm = getattr(model, f"{name}_predictor").feat_pred_fn.bilstm
+            for _ in range(20):
+                for hook in lstm._forward_pre_hooks.values():
+                    hook(lstm, ())
+    return model
+
+
+def build_step_batch(gb, B, T, dev, t_txt=150, joint=False):
+    """synthetic text (t_txt tokens per utterance) around the decoder leg's mel / f0 / energy, with the host copies of the
+    lengths the collate function has anyway; joint: + a voiced mask"""
+    from rad_mmm_amd.data import BetaBinomialInterpolator
+    g = torch.Generator().manual_seed(99)
+    in_lens = [t_txt] * B
+    batch = {"mel": gb["mel"] * 2 - 5,                      # the step applies (mel + 5) / 2 itself
+             "speaker_ids": torch.randint(0, 8, (B,), generator=g).to(dev), "accent_ids": torch.randint(0, 4, (B,), generator=g).to(dev),
+             "text": torch.randint(0, 185, (B, t_txt), generator=g).to(dev),
+             "input_lengths": torch.tensor(in_lens, device=dev), "output_lengths": gb["lengths"],
+             "input_lengths_host": torch.tensor(in_lens), "output_lengths_host": gb["lengths"].cpu(),
+             "attn_prior": BetaBinomialInterpolator(device=dev).batch(in_lens, [T] * B),
+             "f0": gb["f0"], "energy_avg": gb["energy"]}
+    if joint:
+        batch["voiced_mask"] = (gb["f0"] > gb["f0"].median()).float()      # synthetic: the upper half of the f0 track counts as voiced
+    return batch
+
+
 def joint_parity_vs_cpu(model, batch, cfg, Bs, dev):
     """The joint step on the first Bs utterances of the bench batch, HIP against the CPU oracle's restatement of
     TTSModel.training_step (oracle.tts_joint_step), both WITHOUT dropout (the reference's only random element): the summed
@@ -414,35 +454,9 @@ def full_step_leg(dec, cfg, CFG, gb, B, T, dev, decoder_only_ms, steps=7, t_txt=
     Reported: ms per step, the share outside the decoder's fwd+bwd, and the host synchronisations one step makes."""
     import warnings
     from rad_mmm_amd.ddp import BucketedGradReducer
-    from rad_mmm_amd.data import BetaBinomialInterpolator
-    from rad_mmm_amd.encoder import Encoder
-    from rad_mmm_amd.loss import RADMMMLoss
     from rad_mmm_amd.optim import FlatRAdam
-    from rad_mmm_amd.tts_step import TTSTrainingStep
-    torch.manual_seed(1234)
-    extra = build_joint_predictors(CFG) if joint else {}
-    model = TTSTrainingStep(Encoder(3, CFG["n_text_dim"], 5), dec, RADMMMLoss(sigma=1.0, kl_loss_start_iter=0),
-                            n_speakers=8, n_accents=4, n_text_tokens=185, n_text_dim=CFG["n_text_dim"],
-                            n_speaker_dim=CFG["n_speaker_dim"], n_accent_dim=CFG["n_accent_dim"], use_accent=True,
-                            use_accent_emb_for_decoder=CFG["use_accent_emb_for_decoder"], binarization_start_iter=0,
-                            **extra).to(dev).train()
-    if joint:
-        for name in JOINT_PREDICTORS:                       # converge spectral norm's power iteration (fresh u / v leave |W_hh| ~ 10)
-            lstm = getattr(model, f"{name}_predictor").feat_pred_fn.bilstm
-            for _ in range(20):
-                for hook in lstm._forward_pre_hooks.values():
-                    hook(lstm, ())
-    g = torch.Generator().manual_seed(99)
-    in_lens = [t_txt] * B
-    batch = {"mel": gb["mel"] * 2 - 5,                      # the step applies (mel + 5) / 2 itself
-             "speaker_ids": torch.randint(0, 8, (B,), generator=g).to(dev), "accent_ids": torch.randint(0, 4, (B,), generator=g).to(dev),
-             "text": torch.randint(0, 185, (B, t_txt), generator=g).to(dev),
-             "input_lengths": torch.tensor(in_lens, device=dev), "output_lengths": gb["lengths"],
-             "input_lengths_host": torch.tensor(in_lens), "output_lengths_host": gb["lengths"].cpu(),
-             "attn_prior": BetaBinomialInterpolator(device=dev).batch(in_lens, [T] * B),
-             "f0": gb["f0"], "energy_avg": gb["energy"]}
-    if joint:
-        batch["voiced_mask"] = (gb["f0"] > gb["f0"].median()).float()      # synthetic: the upper half of the f0 track counts as voiced
+    model = build_step_model(dec, CFG, dev, joint)
+    batch = build_step_batch(gb, B, T, dev, t_txt, joint)
     joint_parity = None
     if joint and parity_utts > 0:                           # before the first optimizer step: the oracle sees the same weights
         joint_parity, _ = joint_parity_vs_cpu(model, batch, cfg, parity_utts, dev)

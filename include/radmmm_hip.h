@@ -168,6 +168,14 @@ typedef struct {
 
 int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream);
 int64_t radmmm_rowgemm_h3_colsum_scratch_floats(int M, int N);
+/* Deferred column sums (ABI 3): a launch with colsum_scratch set and colsum_out == NULL leaves its per-row-tile partial rows
+ * in colsum_scratch ([rows][N] floats, rows = the value returned here) and the caller adds them up later -- several launches'
+ * finals in one radmmm_colsum_final_multi call.  Returns 0 when this descriptor would take a kernel that cannot leave
+ * partials (the generic epilogue, the narrow kernel): give it colsum_out then. */
+int radmmm_rowgemm_h3_colsum_rows(const radmmm_rowgemm_h3_desc* d);
+typedef struct { const float* part; float* out; int nparts; int cols; } radmmm_cs_item;
+/* out[c] = sum_p part[p * cols + c] for every item (fixed order per item: deterministic), any number of items */
+int radmmm_colsum_final_multi(const radmmm_cs_item* items, int n, radmmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight-gradient GEMM (contraction over frames), fp32 MFMA:

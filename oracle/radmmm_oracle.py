@@ -319,18 +319,29 @@ def masked_batchnorm1d(p: Params, prefix: str, x: Tensor, mask: Tensor, training
 
 
 def film_stack_forward(p: Params, prefix: str, x: Tensor, ctx: Tensor, mask: Tensor, n_layers: int,
-                       use_bn: bool, training: bool = True) -> Tensor:
-    """FiLMStack / FiLMResBlock.  common.py:706-773."""
+                       use_bn: bool, training: bool = True, record: Optional[Dict] = None) -> Tensor:
+    """FiLMStack / FiLMResBlock.  common.py:706-773.  record (test accounting): "leaky_near_zero" / "leaky_total" count the
+    leaky-ReLU pre-activations (valid frames) within 2e-5 of their tensor's rms of the kink at 0 -- another implementation's
+    rounding may put those on the other side, which changes the slope its gradient sees from 1 to 0.01."""
+    def count(pre):
+        if record is not None:
+            with torch.no_grad():
+                v = mask.expand_as(pre) > 0
+                rms = float(pre[v].pow(2).mean().sqrt())
+                record["leaky_near_zero"] = record.get("leaky_near_zero", 0) + int(((pre.abs() < 2e-5 * rms) & v).sum())
+                record["leaky_total"] = record.get("leaky_total", 0) + int(v.sum())
     for i in range(n_layers):
         q = f"{prefix}in_layers.{i}."
         x1 = conv_norm(p, q + "input_conv.", x, mask, 1)
         c1 = conv_norm(p, q + "cond_conv.", ctx, mask, 1)
         n_out = x1.shape[1]
         scale, bias = c1[:, :n_out] + 1, c1[:, n_out:]
+        count(x1)
         x1r = F.leaky_relu(x1)
         x2 = conv_norm(p, q + "hidden_conv.", x1r, mask, 2 ** i)
         if use_bn:
             x2 = masked_batchnorm1d(p, q + "bn.", x2, mask, training)
+        count(x2 * scale + bias)
         x2 = F.leaky_relu(x2 * scale + bias)
         x = 0.5 * (x2 + x1r)
     return F.conv1d(x, p[prefix + "end.weight"], p[prefix + "end.bias"])
@@ -338,17 +349,37 @@ def film_stack_forward(p: Params, prefix: str, x: Tensor, ctx: Tensor, mask: Ten
 
 def spline_coupling_forward(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Tensor,
                             n_layers: int, n_bins: int = 32, bound: float = 3.0,
-                            use_bn: bool = True, training: bool = True) -> Tuple[Tensor, Tensor]:
+                            use_bn: bool = True, training: bool = True, record: Optional[Dict] = None) -> Tuple[Tensor, Tensor]:
     """SplineTransformationLayer.forward, use_quadratic=True.  common.py:1040-1090
-    (left=bottom=-bound, right=top=bound as wired by decoders.py:51-61)."""
+    (left=bottom=-bound, right=top=bound as wired by decoders.py:51-61).
+    record (test accounting, not reference behaviour): receives "x" [B*T, h] (the transform's argument in [0, 1)) and
+    "edges" [B*T, h, K] (the bin edges the search runs on) -- an element within an ulp of an edge may take the
+    neighbouring bin in another implementation; the transform is continuous there, its parameter gradient is not."""
     B, C, T = z.shape
     h = C // 2
     z0, z1 = z[:, :h], z[:, h:]
     z1n = (z1 + bound) / (2 * bound)
-    q = film_stack_forward(p, prefix + "param_predictor.", z0, ctx, mask, n_layers, use_bn, training)
+    q = film_stack_forward(p, prefix + "param_predictor.", z0, ctx, mask, n_layers, use_bn, training,
+                           record if (record is not None and "ulps" in record) else None)
     nb = 2 * n_bins + 1
     x = z1n.permute(0, 2, 1).reshape(B * T, h)
     qt = q.permute(0, 2, 1).reshape(B * T, h, nb)
+    if record is not None:
+        with torch.no_grad():
+            wc = torch.cumsum(torch.softmax(qt[:, :, :nb // 2].float(), -1), -1)
+            wc[..., -1] = 1.0
+            if "ulps" in record:                      # full-size runs: only the verdict, not 330 MB of edges per flow
+                xf = x.detach().float()
+                dist = (wc - xf.unsqueeze(-1)).abs().min(-1)[0]
+                inside = (xf >= 0) & (xf < 1)
+                record["near"] = inside & (dist <= record["ulps"] * torch.finfo(torch.float32).eps)
+                # the bin the reference's search picks (splines.py:300-306), -1 outside [0, 1): for index-by-index
+                # comparison with another implementation's search
+                idx = torch.searchsorted(wc, xf.unsqueeze(-1)).squeeze(-1)
+                record["bins"] = torch.where(inside, idx, torch.full_like(idx, -1)).to(torch.int32)
+                record["edge_dist"] = dist
+            else:
+                record["x"], record["edges"] = x.detach().float().clone(), wc
     y, logj = unbounded_piecewise_quadratic_transform(
         x.float(), qt[:, :, :nb // 2].float(), qt[:, :, nb // 2:].float())
     z1o = y.reshape(B, T, h).permute(0, 2, 1) * (2 * bound) - bound
@@ -416,8 +447,10 @@ def preprocess_context(p: Params, cfg: DecoderConfig, context: Tensor, spk: Tens
 
 def decoder_forward(p: Params, cfg: DecoderConfig, mel: Tensor, spk: Tensor, context: Tensor,
                     lengths: Tensor, f0: Optional[Tensor] = None, energy: Optional[Tensor] = None,
-                    accent: Optional[Tensor] = None, training: bool = True) -> Dict[str, object]:
-    """RADMMMFlow.forward.  decoders.py:168-205."""
+                    accent: Optional[Tensor] = None, training: bool = True,
+                    spline_records: Optional[List[Dict]] = None) -> Dict[str, object]:
+    """RADMMMFlow.forward.  decoders.py:168-205.  spline_records (test accounting): one dict per spline flow, handed to
+    spline_coupling_forward as `record`."""
     g = cfg.n_group_size
     ctx = preprocess_context(p, cfg, context, spk, lengths, f0, energy, accent)
     z = squeeze_time(mel, g)
@@ -437,7 +470,8 @@ def decoder_forward(p: Params, cfg: DecoderConfig, mel: Tensor, spk: Tensor, con
         if i < cfg.n_splines:
             z, ls = spline_coupling_forward(p, pre + "coupling_tfn.", z, ctx, mask,
                                             cfg.n_conv_layers_per_step, use_bn=cfg.use_bn,
-                                            training=training)
+                                            training=training,
+                                            record=spline_records[i] if spline_records is not None else None)
         else:
             z, ls = affine_coupling_forward(p, pre + "coupling_tfn.", z, ctx, mask,
                                             cfg.n_conv_layers_per_step, cfg.scaling_fn,

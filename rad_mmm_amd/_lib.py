@@ -65,6 +65,11 @@ class RowGemmDesc(C.Structure):
     ]
 
 
+class CsItem(C.Structure):
+    """radmmm_cs_item: one deferred column-sum final (partials [nparts][cols] -> out [cols])"""
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nparts", C.c_int), ("cols", C.c_int)]
+
+
 class SplitOpts(C.Structure):
     """radmmm_split_opts: format of a split producer's second array (SPLIT_F16 / SPLIT_X8A / SPLIT_X8B), exponent of its
     8-bit parts, optional device saturation flag."""
@@ -173,6 +178,7 @@ def _load() -> C.CDLL:
         "radmmm_radam_step": [p, p, p, p, i64, p, f, f, f, f, f, i, p],
         "radmmm_transpose_split_act_colsum": [p, i, i, i, i, i, i, p, i, f, p, p, p, p, i, p, i, i, i, p],
         "radmmm_colsum_final": [p, p, i, i, p],
+        "radmmm_colsum_final_multi": [C.POINTER(CsItem), i, p], "radmmm_rowgemm_h3_colsum_rows": [C.POINTER(RowGemmH3Desc)],
         "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
         "radmmm_dact_mul_rows": [p, i, p, i, i, i, i, i, i, p, i, i, f, p, p, i, so, p, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, p, i, i, i, p],
@@ -278,7 +284,16 @@ def rowgemm_h3(**kw) -> None:
     _rowgemm_h3(kw)
 
 
+def rowgemm_h3_colsum_rows(**kw) -> int:
+    """rows of partial column sums this launch would leave in colsum_scratch with colsum_out = None (0: it cannot defer)"""
+    return int(lib.radmmm_rowgemm_h3_colsum_rows(C.byref(_h3_desc(kw))))
+
+
 def _rowgemm_h3(kw) -> None:
+    check(lib.radmmm_rowgemm_h3(C.byref(_h3_desc(kw)), stream()), "radmmm_rowgemm_h3")
+
+
+def _h3_desc(kw):
     d = RowGemmH3Desc()
     d.base.sign = 1
     d.base.taps = 1
@@ -290,7 +305,7 @@ def _rowgemm_h3(kw) -> None:
         if isinstance(v, torch.Tensor):
             v = ptr(v)
         setattr(d if k in _H3_KEYS else d.base, k, v)
-    check(lib.radmmm_rowgemm_h3(C.byref(d), stream()), "radmmm_rowgemm_h3")
+    return d
 
 
 def wgrad(**kw) -> None:

@@ -7,6 +7,7 @@ only the final Linear and the target transforms are torch.  Same constructor arg
 state_dict names and output dict {'x_hat', 'x'}."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -72,6 +73,14 @@ class ConvLSTMLinear(nn.Module):
 
     def forward_rows(self, h, lens32, B, T):
         """h [B*T, ld] channels-last context -> x_hat [B, out_dim, T]"""
+        return self.post_lstm(bilstm(self.bilstm, self.pre_lstm_rows(h, lens32, B, T), lens32))
+
+    def post_lstm(self, y):
+        return self.dense(y).transpose(1, 2)
+
+    def pre_lstm_rows(self, h, lens32, B, T):
+        """the conv stack: h [B*T, ld] channels-last context -> the bi-LSTM's input [B, T, C]; materialises the
+        spectral-normed recurrent weights (the LSTM's own forward pre-hooks) on the way"""
         valid = (torch.arange(T, device=h.device)[None, :] < lens32[:, None]).reshape(B * T, 1)
         h = h * valid                                  # a conv over x[:, :len] sees zeros beyond len
         for holder in self.convolutions:
@@ -82,8 +91,7 @@ class ConvLSTMLinear(nn.Module):
         for hook in self.bilstm._forward_pre_hooks.values():        # materialise the spectral-normed weight_hh_l0*
             hook(self.bilstm, ())
         C = self.convolutions[-1].conv.weight_v.shape[0]
-        y = bilstm(self.bilstm, h[:, :C].reshape(B, T, C).contiguous(), lens32)
-        return self.dense(y).transpose(1, 2)
+        return h[:, :C].reshape(B, T, C).contiguous()
 
 
 class AttributePredictor(nn.Module):
@@ -137,6 +145,12 @@ class ConvLSTMLinearDAP(AttributePredictor):
 
     @fp32_region
     def forward(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
+        x_target, xin, lens32 = self.forward_pre(x_target, text_enc, spk_emb, lens, x_mean, x_std, accent_emb)
+        return {"x_hat": self.feat_pred_fn.post_lstm(bilstm(self.feat_pred_fn.bilstm, xin, lens32)), "x": x_target}
+
+    def forward_pre(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
+        """everything in front of the bi-LSTM: target transform, bottleneck, embeddings, conv stack
+        -> (transformed target, LSTM input [B, T, C], lens32)"""
         if not text_enc.is_cuda:
             raise RuntimeError("rad_mmm_amd.attribute_predictors runs on an MI355X only (no CPU path)")
         if x_target is not None:
@@ -152,13 +166,32 @@ class ConvLSTMLinearDAP(AttributePredictor):
         ctx = torch.cat(parts, 2)
         if ctx.shape[2] % 4:
             ctx = F.pad(ctx, (0, (-ctx.shape[2]) % 4))
-        x_hat = self.feat_pred_fn.forward_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T)
-        return {"x_hat": x_hat, "x": x_target}
+        return x_target, self.feat_pred_fn.pre_lstm_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T), lens32
 
     @fp32_region
     def infer(self, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
         res = self.forward(None, text_enc, spk_emb, lens, accent_emb=accent_emb)
         return self.inv_tx_data(res["x_hat"], x_mean, x_std)
+
+
+@fp32_region
+def dap_forward_many(daps, calls):
+    """[dap(*args, **kwargs) for dap, (args, kwargs) in zip(daps, calls)] for predictors that read the same frames (the f0 /
+    energy / voiced predictors of TTSModel.training_step, tts_lightning_modules.py:688-717: three ConvLSTMLinearDAP over
+    context.detach() and out_lens): their bi-LSTMs -- same shape, T dependent steps each, latency-bound -- run as ONE
+    block-diagonal recurrence (lstm.MergedBiLSTMFn) instead of one after the other; conv stacks and output layers stay per
+    predictor.  Same values as the separate calls (the recurrence's fp32 summation order apart); predictors whose LSTMs
+    cannot be merged (other sizes, other lengths) take their own launch."""
+    from .lstm import can_merge, merged_bilstm
+    pres = [d.forward_pre(*a, **k) for d, (a, k) in zip(daps, calls)]
+    lstms = [d.feat_pred_fn.bilstm for d in daps]
+    xs = [p[1] for p in pres]
+    same_lens = all(c[0][3] is calls[0][0][3] for c in calls)                 # the same SequenceLength object
+    if same_lens and can_merge(lstms, xs) and os.environ.get("RADMMM_MERGE_DAP_LSTM", "1") != "0":
+        ys = merged_bilstm(lstms, xs, pres[0][2])
+    else:
+        ys = [bilstm(l, x, p[2]) for l, x, p in zip(lstms, xs, pres)]
+    return [{"x_hat": d.feat_pred_fn.post_lstm(y), "x": p[0]} for d, y, p in zip(daps, ys, pres)]
 
 
 class AttributeRegressionLoss(nn.Module):
@@ -172,6 +205,10 @@ class AttributeRegressionLoss(nn.Module):
         target, prediction = model_output["x"], model_output["x_hat"]
         if mask is None:
             mask = out_lens.mask.unsqueeze(1)
-        mask = mask.bool()
-        loss = F.mse_loss(prediction[mask], target[mask], reduction="sum") / mask.sum()
+        # the reference gathers prediction[mask] / target[mask] (a boolean index: a device -> host read of the count per
+        # predictor and step); the same sum over the selected positions as a masked sum needs none.  (`where`, not a
+        # product: an unselected position may hold anything, e.g. log(0) of a duration target beyond the text)
+        mask = mask.bool().expand_as(prediction)
+        d = torch.where(mask, prediction - target, torch.zeros_like(prediction))
+        loss = (d * d).sum() / mask.sum()
         return {self.prefix + "loss": (loss, self.weight)}

@@ -727,6 +727,62 @@ extern "C" int radmmm_colsum(const float* X, int ldx, float* out, float* scratch
   return radmmm::check_launch("colsum");
 }
 
+// several independent finals in one launch (item = blockIdx.y; the items travel as the kernel argument): the bias sums of a
+// flow step's backward are nine 5-microsecond launches otherwise.  Same summation order per item as colsum_final_kernel.
+struct CsMulti {
+  const float* part[16];
+  float* out[16];
+  int nparts[16], cols[16];
+};
+__global__ __launch_bounds__(1024) void colsum_final_multi_kernel(const CsMulti m) {
+  __shared__ float sh[16][64];
+  const int it = blockIdx.y;
+  const float* __restrict__ part = m.part[it];
+  const int nparts = m.nparts[it], cols = m.cols[it];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  if (blockIdx.x * 64 >= cols) return;                       // (uniform per block)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int q = pl;
+    for (; q + 48 < nparts; q += 64) {
+      const float a0 = part[(long long)q * cols + c], a1 = part[(long long)(q + 16) * cols + c];
+      const float a2 = part[(long long)(q + 32) * cols + c], a3 = part[(long long)(q + 48) * cols + c];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    if (q < nparts) s0 += part[(long long)q * cols + c];
+    if (q + 16 < nparts) s1 += part[(long long)(q + 16) * cols + c];
+    if (q + 32 < nparts) s2 += part[(long long)(q + 32) * cols + c];
+  }
+  sh[pl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w][cl];
+    m.out[it][c] = t;
+  }
+}
+
+extern "C" int radmmm_colsum_final_multi(const radmmm_cs_item* items, int n, radmmm_stream_t stream) {
+  RADMMM_REQUIRE(items && n > 0, "colsum_final_multi: bad arguments");
+  for (int k = 0; k < n; k += 16) {
+    CsMulti m;
+    const int cnt = n - k < 16 ? n - k : 16;
+    int maxc = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const radmmm_cs_item& it = items[k + i];
+      RADMMM_REQUIRE(it.part && it.out && it.nparts > 0 && it.cols > 0, "colsum_final_multi: bad item");
+      m.part[i] = it.part; m.out[i] = it.out; m.nparts[i] = it.nparts; m.cols[i] = it.cols;
+      maxc = it.cols > maxc ? it.cols : maxc;
+    }
+    hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((maxc + 63) / 64, cnt), dim3(1024), 0, ST(stream), m);
+    const int rc = radmmm::check_launch("colsum_final_multi");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 // out[c] = sum_p part[p][c] (fixed order): second stage for partials produced by another kernel
 // (radmmm_transpose_split_act_colsum)
 extern "C" int radmmm_colsum_final(const float* part, float* out, int nparts, int cols, radmmm_stream_t stream) {

@@ -244,6 +244,21 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
                        p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
 }
 
+namespace radmmm { int h3w_colsum_rows(const radmmm_rowgemm_h3_desc& d); }
+// rows of partial column sums a launch of *d leaves in colsum_scratch when colsum_out is NULL (include/radmmm_hip.h); 0 = this
+// descriptor takes a kernel that leaves none (generic epilogue, the narrow kernel): give it colsum_out
+extern "C" int radmmm_rowgemm_h3_colsum_rows(const radmmm_rowgemm_h3_desc* d) {
+  if (!d) return 0;
+  const radmmm_rowgemm_desc& p = d->base;
+  if (p.M <= 0 || p.N <= 0 || !p.colsum_scratch) return 0;
+  const char* forced_env = radmmm::debug_env("RADMMM_H3_TILE");
+  const int forced = forced_env ? atoi(forced_env) : 0;
+  const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
+  const bool narrow = d->nprod != 2 && !d->extra_tap && (forced == 128 || (forced != 256 && wide_wgs < 128));
+  if (narrow) return 0;
+  return radmmm::h3w_colsum_rows(*d);
+}
+
 // scratch of the optional column sums (radmmm_rowgemm_desc.colsum_scratch): one partial row per row tile of the smallest
 // tile height (padded to whole column tiles), or what radmmm_colsum wants when a launch falls back to it
 extern "C" int64_t radmmm_rowgemm_h3_colsum_scratch_floats(int M, int N) {

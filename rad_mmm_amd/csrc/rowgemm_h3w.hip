@@ -91,8 +91,8 @@ int launch_rowgemm_h3w(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int 
                        p.lens, p.ratio_taps, p.ratio_dil, 0, stream);
 }
 
-static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes, int* mb_out,
-                                    int* ek_out) {
+// tile height and epilogue kind of a launch
+static void decide_h3w(const radmmm_rowgemm_h3_desc& d, int* mb_out, int* ek_out) {
   int mb = pick_h3w_mb(d.base.M, d.base.N, gemm_cu_slots());
   if (const char* e = debug_env("RADMMM_H3W_MB")) {
     const int v = atoi(e);
@@ -130,6 +130,21 @@ static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t
       ek = p.Ch ? EK_SPLIT : EK_PLAIN;
     }
   }
+  *mb_out = mb;
+  *ek_out = ek;
+}
+
+// rows of per-tile partial column sums a wide-kernel launch of `d` leaves in colsum_scratch (0: generic epilogue, none)
+int h3w_colsum_rows(const radmmm_rowgemm_h3_desc& d) {
+  int mb = 0, ek = 0;
+  decide_h3w(d, &mb, &ek);
+  return ek == EK_GENERIC ? 0 : (d.base.M + 32 * mb - 1) / (32 * mb);
+}
+
+static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes, int* mb_out,
+                                    int* ek_out) {
+  int mb = 0, ek = 0;
+  decide_h3w(d, &mb, &ek);
   *mb_out = mb;
   *ek_out = ek;
   if (d.nprod == 2) {                                                                 // FP8 cross terms

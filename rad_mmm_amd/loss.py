@@ -176,8 +176,11 @@ class AttributeBCELoss(nn.Module):
         if mask is None:
             mask = out_lens.mask.unsqueeze(1)
         assert mask.dim() == target.dim()
-        mask = mask.bool()
-        loss = F.binary_cross_entropy_with_logits(prediction[mask], target[mask], reduction="sum") / mask.sum()
+        mask = mask.bool().expand_as(prediction)                      # masked sum instead of the reference's boolean gather: no
+        zero = torch.zeros_like(prediction)                            # device -> host read of the count
+        bce = F.binary_cross_entropy_with_logits(torch.where(mask, prediction, zero), torch.where(mask, target, zero),
+                                                 reduction="none")
+        loss = torch.where(mask, bce, zero).sum() / mask.sum()
         return {self.prefix + "loss": (loss, self.weight)}
 
 

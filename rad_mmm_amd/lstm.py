@@ -153,3 +153,117 @@ def bilstm(lstm: torch.nn.LSTM, x: torch.Tensor, lens32) -> torch.Tensor:
     return BiLSTMFn.apply(x, lens32, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                           lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
                           lstm.bias_hh_l0_reverse, box)
+
+
+class MergedBiLSTMFn(torch.autograd.Function):
+    """P independent bidirectional LSTMs of the SAME shape (hidden H, same batch, frames and lengths) as ONE recurrence.
+
+    An LSTM's gates are elementwise per hidden unit, so P LSTMs side by side are one LSTM with hidden P*H whose recurrent
+    matrix is BLOCK-DIAGONAL.  The recurrence is latency-bound (T dependent steps of a few microseconds, whatever H is up to
+    the kernel's size classes), so the merged launch costs about what ONE of the P costs: the f0 / energy / voiced predictors
+    of the joint step (BASELINE configs[3]: three ConvLSTMLinearDAP with a 256 -> 2 x 128 bi-LSTM over the same 800 frames) ran
+    3 x (3.5 + 4) ms of recurrences one after the other.  Nothing changes in csrc/lstm.hip: the merged gate pre-activations
+    G' [B*T, 2, 4, P, H], the block-diagonal W_hh' [2, 4 P H, P H] and dy' are assembled here, and the input projections /
+    weight gradients stay per LSTM (small GEMMs).  The zero blocks cost MFMA work nobody waits for.
+
+    forward(lens, P, x_0 .. x_{P-1}, then per LSTM: w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+    -> y_0 .. y_{P-1}, each [B, T, 2H]."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, lens, P, *args):
+        xs, ws = args[:P], args[P:]
+        B, T, I = xs[0].shape
+        H = ws[1].shape[1]
+        HP = P * H
+        dev = xs[0].device
+        G = torch.empty(B * T, 2, 4, P, H, device=dev, dtype=torch.float32)
+        W_hh = torch.zeros(2, 4, P, H, P, H, device=dev, dtype=torch.float32)        # [dir][gate][p][unit] x [p'][unit']
+        x2s, W_ihs = [], []
+        for p in range(P):
+            w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ws[8 * p: 8 * p + 8]
+            x2 = xs[p].reshape(B * T, -1).contiguous()
+            W_ih = torch.cat((w_ih_f, w_ih_r), 0)                                   # [8H, I_p]
+            bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r))
+            G[:, :, :, p, :] = torch.addmm(bias, x2, W_ih.t()).view(B * T, 2, 4, H)
+            W_hh[0, :, p, :, p, :] = w_hh_f.view(4, H, H)
+            W_hh[1, :, p, :, p, :] = w_hh_r.view(4, H, H)
+            x2s.append(x2)
+            W_ihs.append(W_ih)
+        G = G.view(B * T, 8 * HP)
+        W_hh = W_hh.view(2, 4 * HP, HP)
+        y = torch.empty(B * T, 2 * HP, device=dev, dtype=torch.float32)
+        c = torch.empty(B * T, 2 * HP, device=dev, dtype=torch.float32)
+        wsplit, hsplit = _scratch(B, HP, 0, y), _scratch(B, HP, 1, y)
+        nq = int(lib.radmmm_lstm_hseq_bytes(B, T, HP))
+        hseq = torch.empty(nq // 4, device=dev, dtype=torch.float32) if nq else None
+        check(lib.radmmm_lstm_fwd(ptr(G), ptr(W_hh), ptr(y), ptr(c), ptr(lens), ptr(wsplit), ptr(hsplit), ptr(hseq), B, T, HP,
+                                  stream()), "lstm_fwd")
+        ctx.dims = (B, T, H, P)
+        ctx.has_lens = lens is not None
+        ctx.save_for_backward(G, c, y, W_hh, lens if lens is not None else torch.empty(0, device=dev), *x2s, *W_ihs)
+        y4 = y.view(B, T, 2, P, H)
+        return tuple(y4[:, :, :, p, :].reshape(B, T, 2 * H) for p in range(P))
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, *dys):
+        B, T, H, P = ctx.dims
+        HP = P * H
+        if getattr(ctx, "_consumed", False):
+            raise RuntimeError("MergedBiLSTMFn.backward ran twice on the same graph (it turns the saved gate activations into "
+                               "gradients in place)")
+        ctx._consumed = True
+        G, c, y, W_hh, lens = ctx.saved_tensors[:5]
+        x2s, W_ihs = ctx.saved_tensors[5: 5 + P], ctx.saved_tensors[5 + P: 5 + 2 * P]
+        lens = lens if ctx.has_lens else None
+        dev = G.device
+        dy = torch.zeros(B, T, 2, P, H, device=dev, dtype=torch.float32)
+        for p in range(P):
+            if dys[p] is not None:
+                dy[:, :, :, p, :] = dys[p].reshape(B, T, 2, H)
+        dy2 = dy.view(B * T, 2 * HP)
+        amax = dy2.abs().amax().clamp_min(1e-30)
+        gscale = torch.exp2(torch.floor(torch.log2(64.0 / amax))).reshape(1).float().contiguous()
+        wtpack, Pbuf, dcbuf = _scratch(B, HP, 2, dy2), _scratch(B, HP, 3, dy2), _scratch(B, HP, 4, dy2)
+        check(lib.radmmm_lstm_bwd(ptr(G), ptr(c), ptr(dy2), ptr(W_hh), ptr(lens), ptr(wtpack), ptr(Pbuf), ptr(dcbuf), B, T, HP,
+                                  ptr(gscale), stream()), "lstm_bwd")
+        dG5 = G.view(B * T, 2, 4, P, H)                                              # now the pre-activation gradients
+        y5 = y.view(B, T, 2, P, H)
+        grads = [None] * (2 + P + 8 * P)
+        for p in range(P):
+            dG = dG5[:, :, :, p, :].reshape(B * T, 8 * H)
+            yp = y5[:, :, :, p, :]                                                   # [B, T, 2, H]
+            hp = torch.zeros(B, T, 2, H, device=dev, dtype=torch.float32)
+            hp[:, 1:, 0] = yp[:, :-1, 0]                                             # forward direction: h_{t-1}
+            hp[:, :-1, 1] = yp[:, 1:, 1]                                             # reverse direction: h_{t+1}
+            hp = hp.view(B * T, 2, H)
+            dW_ih = dG.t() @ x2s[p]
+            db = dG.sum(0)
+            dW_hh_f = dG[:, : 4 * H].t() @ hp[:, 0]
+            dW_hh_r = dG[:, 4 * H:].t() @ hp[:, 1]
+            if ctx.needs_input_grad[2 + p]:
+                grads[2 + p] = (dG @ W_ihs[p]).view(B, T, -1)
+            base = 2 + P + 8 * p
+            grads[base: base + 8] = [dW_ih[: 4 * H], dW_hh_f, db[: 4 * H], db[: 4 * H], dW_ih[4 * H:], dW_hh_r, db[4 * H:], db[4 * H:]]
+        return tuple(grads)
+
+
+def merged_bilstm(lstms, xs, lens32):
+    """y_p = bilstm(lstms[p], xs[p], lens32) for LSTMs of one shape over the same frames, as ONE recurrence (MergedBiLSTMFn);
+    the caller has materialised normed recurrent weights (spectral / weight norm hooks) already."""
+    ws = []
+    for l in lstms:
+        assert l.num_layers == 1 and l.bidirectional and l.batch_first and l.proj_size == 0
+        ws += [l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0, l.weight_ih_l0_reverse, l.weight_hh_l0_reverse,
+               l.bias_ih_l0_reverse, l.bias_hh_l0_reverse]
+    return MergedBiLSTMFn.apply(lens32, len(lstms), *[x.contiguous() for x in xs], *ws)
+
+
+def can_merge(lstms, xs) -> bool:
+    """same hidden size, batch and frames; the merged hidden size within the recurrence kernel's size classes (<= 768)"""
+    if len(lstms) < 2:
+        return False
+    H = lstms[0].hidden_size
+    return (all(l.hidden_size == H for l in lstms) and all(x.shape[:2] == xs[0].shape[:2] for x in xs) and
+            len(lstms) * H <= 768 and xs[0].is_cuda)

@@ -808,7 +808,26 @@ def _ts_buffers(device, C, B, T, role, need_odd):
     return [f[:need].view(C, ldk) for f in ent["flat"]], Tp, Kt, ldk
 
 
-def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp, sat_flag, sum_out=None, ylo16=None):
+class ColsumBatch:
+    """Deferred finals of partial column sums (bias gradients): the producers of a flow step's backward leave their per-tile
+    partial rows in scratch of their own and ONE radmmm_colsum_final_multi launch adds them all up -- nine 5-microsecond
+    launches per flow step otherwise (82 per training step).  flush() must run before anybody may read the sums."""
+
+    def __init__(self):
+        self.items, self.keep = [], []
+
+    def add(self, part: torch.Tensor, out: torch.Tensor, nparts: int, cols: int) -> None:
+        self.items.append(L.CsItem(ptr(part), ptr(out), nparts, cols))
+        self.keep.append((part, out))
+
+    def flush(self) -> None:
+        if self.items:
+            arr = (L.CsItem * len(self.items))(*self.items)
+            check(lib.radmmm_colsum_final_multi(arr, len(self.items), stream()), "colsum_final_multi")
+        self.items, self.keep = [], []
+
+
+def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp, sat_flag, sum_out=None, ylo16=None, defer=None):
     """y = g * act'(saved) written as the row-major split pair yh/yl (format fmt; ylo16: the fp16 lo part as well when
     yl is an 8-bit cross array), as the transposed zero-gapped split-f16 copy (pool `role`; role None: no transposed copy)
     and as column sums, in one pass and without an fp32 y (radmmm_dact_mul_transposed) -> (transposed-copy tuple, sums [C])."""
@@ -825,7 +844,10 @@ def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp
                                          _TS_FRONT, act, scale, ptr(yh), ptr(yl), yh.shape[1] if yh is not None else 0,
                                          split_opts(fmt, x8_exp, sat_flag, ylo16), ptr(oh), ptr(ol), ldk, ptr(part), stream()),
           "dact_mul_transposed")
-    check(lib.radmmm_colsum_final(ptr(part), ptr(sums), nparts, C, stream()), "colsum_final")
+    if defer is not None:
+        defer.add(part, sums, nparts, C)
+    else:
+        check(lib.radmmm_colsum_final(ptr(part), ptr(sums), nparts, C, stream()), "colsum_final")
     return (oh, ol, None, None, Kt), sums
 
 
@@ -1420,11 +1442,28 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # over the 52 MB output each.  RADMMM_FUSED_COLSUM=0: the separate radmmm_colsum launches (A/B runs).
         fuse_cs = use_rm and debug_env("RADMMM_FUSED_COLSUM", "1") != "0"
         cs_scratch = _empty(int(lib.radmmm_rowgemm_h3_colsum_scratch_floats(N, Wc)), like=z_in) if fuse_cs else None
+        # round 5: the finals of all these partial sums (9 per flow step) are deferred into one launch (ColsumBatch);
+        # RADMMM_COLSUM_BATCH=0 (RADMMM_DEBUG) keeps one radmmm_colsum_final launch each
+        batch = ColsumBatch() if debug_env("RADMMM_COLSUM_BATCH", "1") != "0" else None
 
         def cs_args(param):
             gb = grad_out(param)
             gb = gb if (gb is not None and gb.numel() == Wc) else _empty(Wc, like=z_in)
+            if batch is not None:                   # partial rows stay in scratch of their own until the batch is flushed
+                return gb, dict(colsum_scratch=_empty(int(lib.radmmm_rowgemm_h3_colsum_scratch_floats(N, Wc)), like=z_in), _defer=gb)
             return gb, dict(colsum_out=gb, colsum_scratch=cs_scratch)
+
+        def gemm_cs(**kw):
+            """rowgemm_h3 whose column sums are deferred into `batch` when the launch can leave partial rows"""
+            gb = kw.pop("_defer", None)
+            if gb is not None:
+                rows = L.rowgemm_h3_colsum_rows(**kw)
+                if rows > 0:
+                    rowgemm_h3(**kw)
+                    batch.add(kw["colsum_scratch"], gb, rows, kw["N"])
+                    return
+                kw["colsum_out"] = gb
+            rowgemm_h3(**kw)
         pair_h = pair_l = None           # [2N, Wc]: g_conv_{j+1} split in the first half, gQ_j goes into the second
         WT_prev = None                   # (WiT stack [kt+1][Wc][Wc] of layer j+1 with its last slot free, kt, dil)
         x_prev = None
@@ -1440,7 +1479,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
             gQlo = lo16()
             gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
-                                                         GE, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo)
+                                                         GE, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo, defer=batch)
             if use_rm:
                 slabs = wg_rm((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], Wc, Wc, 1, 1)
             else:
@@ -1468,11 +1507,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 WTh, WTl, ktn, dn = WT_prev
                 if pre is None:
                     transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR, out=(WTh[ktn:], WTl[ktn:]))
-                rowgemm_h3(Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=WTh, Bl=WTl, ldb_h=Wc, b_tap_stride_h=WTh.stride(0), taps=ktn,
-                           dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout, **cs)
+                gemm_cs(Ah=pair_h, Al=pair_l, lda_h=Wc, Bh=WTh, Bl=WTl, ldb_h=Wc, b_tap_stride_h=WTh.stride(0), taps=ktn,
+                        dil=dn, sign=-1, a_mask_mode=0, extra_tap=1, extra_a_rows=N, **epi, **gin, **gout, **cs)
             else:
                 WrTh, WrTl = pre[("res", j)] if pre else transpose_split(Wrh[j], Wrl[j], Wc, Wc, Wc, NPR)
-                rowgemm_h3(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout, **cs)
+                gemm_cs(Ah=gQh, Al=gQl, lda_h=Wc, Bh=WrTh, Bl=WrTl, ldb_h=Wc, add=G, ldadd=Wc, **epi, **gin, **gout, **cs)
             if use_rm:
                 g_in[3 * j + 2] = gb if cs_here else colsum(g_conv, Wc, 2 if partial else 0, T, lens, kt, d,
                                                             out=grad_out(in_p[3 * j + 2]))
@@ -1512,16 +1551,20 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 # (dL/dH_0: consumed as its split pair by the start conv's gradients; fp32 only for an unfused bias sum)
                 G = None if (pair_only and fuse_cs and j == 0) else _empty(N, Wc, like=z_in)
                 g_start_b, cs = cs_args(start_b) if (fuse_cs and j == 0) else (None, {})
-                rowgemm_h3(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
-                           C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
-                           a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
-                           Clo=Glo if j == 0 else None, ldch=Wc, ch_scale=SG, **gin, **gout, **cs)
+                gemm_cs(Ah=gch, Al=gcl, lda_h=Wc, Bh=WiTh, Bl=WiTl, ldb_h=Wc, b_tap_stride_h=WiTh.stride(0),
+                        C=G, ldc=Wc, M=N, N=Wc, K=Wc, taps=kt, dil=d, sign=-1, lens=lens,
+                        a_mask_mode=0, premask=1 if partial else 0, Ch=Gh if j == 0 else None, Cl=Gl if j == 0 else None,
+                        Clo=Glo if j == 0 else None, ldch=Wc, ch_scale=SG, **gin, **gout, **cs)
                 pair_h = pair_l = None
             check_saturation(box)
             if j == 2 and nl >= 3:
+                if batch is not None:
+                    batch.flush()                    # (the bias gradients announced below must be final)
                 # the gradients of the end conv and of WN layers >= 2 are final (their kernels are queued): a gradient
                 # reducer may start their bucket's all-reduce now (rad_mmm_amd/ddp.py, bucket '.hi')
                 notify_grads_final([end_w, end_b] + [t for jj in range(2, nl) for t in (*in_p[3 * jj: 3 * jj + 3], *res_p[3 * jj: 3 * jj + 3])])
+        if batch is not None:
+            batch.flush()
         perm = (h, D, 0)
         if use_rm:
             if not fuse_cs:
@@ -1536,8 +1579,24 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         WsTh, WsTl = pre["start"] if pre else transpose_split(Wsh, Wsl, Wc, Kp, Wc, NPR)      # [1][Kp][Wc]
         gX0 = _empty(N, Kp, like=z_in)
         rowgemm_h3(Ah=Gh, Al=Gl, lda_h=Wc, Bh=WsTh, Bl=WsTl, ldb_h=Wc, C=gX0, ldc=Kp, M=N, N=Kp, K=Wc, **gin)
-        g_cond = _empty(N, D, like=z_in)
-        check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
+        # the context gradient: into the decoder's shared buffer (meta["ctx_acc"], one per forward pass; every affine flow
+        # step reads the same context), in place; the step that runs last returns the buffer, the others return None
+        acc = meta.get("ctx_acc")
+        if acc is not None and ctx.needs_input_grad[2]:
+            first = acc["buf"] is None
+            if first:
+                acc["buf"] = _empty(N, D, like=z_in)
+            g_cond = acc["buf"]
+            check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0 if first else 1, ptr(gz1), ZLD, N, D, h, stream()),
+                  "wn_input_bwd")
+            acc["left"] -= 1
+            if acc["left"] > 0:
+                g_cond = None
+            else:                                                        # (re-armed: a second backward over a retained graph)
+                acc["buf"], acc["left"] = None, acc["total"]
+        else:
+            g_cond = _empty(N, D, like=z_in)
+            check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")
         g_b_eff = colsum(gz1, ZLD) if ctx.needs_input_grad[5] else None   # LUS conv: constant zero bias
         if OUTpair is not None and T % 16 != 0:
             # the channel mix's weight gradient (gz1^T z_in, 160 x 160 over all frames): the fp32-MFMA fast path needs K steps

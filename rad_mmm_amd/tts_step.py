@@ -124,18 +124,32 @@ class TTSTrainingStep(nn.Module):
         if self.decoder.training:
             losses.update(self.decoder_criterion(outputs, in_lens, out_lens, global_step))
         acc_d = accent_vecs.detach() if accent_vecs is not None else None
+        # the mel-rate predictors (f0, energy, voiced: tts_lightning_modules.py:688-717) read the same detached context over
+        # the same frames: their calls are collected and run through attribute_predictors.dap_forward_many, which merges
+        # their bi-LSTMs into one recurrence when they are this package's ConvLSTMLinearDAP of one shape
+        mel_rate = []
         if self.f0_predictor is not None:
-            o = self.f0_predictor(f0.unsqueeze(1), context.detach(), spk_vecs.detach(), out_lens,
-                                  batch.get("speaker_f0_mean"), batch.get("speaker_f0_std"), acc_d)
-            m = batch["voiced_mask"].unsqueeze(1) if self.f0_loss_voiced_only else None
-            losses.update(self.f0_predictor_loss(o, in_lens, out_lens, global_step, mask=m))
+            mel_rate.append(("f0", self.f0_predictor, ((f0.unsqueeze(1), context.detach(), spk_vecs.detach(), out_lens,
+                                                        batch.get("speaker_f0_mean"), batch.get("speaker_f0_std"), acc_d), {})))
         if self.energy_predictor is not None:
-            o = self.energy_predictor(energy_avg.unsqueeze(1), context.detach(), spk_vecs.detach(), out_lens, accent_emb=acc_d)
-            losses.update(self.energy_predictor_loss(o, in_lens, out_lens, global_step))
+            mel_rate.append(("energy", self.energy_predictor, ((energy_avg.unsqueeze(1), context.detach(), spk_vecs.detach(), out_lens),
+                                                               {"accent_emb": acc_d})))
         if self.voiced_predictor is not None:
-            o = self.voiced_predictor(batch["voiced_mask"].unsqueeze(1), context.detach(), spk_vecs.detach(), out_lens,
-                                      accent_emb=acc_d)
-            losses.update(self.voiced_predictor_loss(o, in_lens, out_lens, global_step))
+            mel_rate.append(("voiced", self.voiced_predictor, ((batch["voiced_mask"].unsqueeze(1), context.detach(), spk_vecs.detach(),
+                                                                out_lens), {"accent_emb": acc_d})))
+        from .attribute_predictors import ConvLSTMLinearDAP, dap_forward_many
+        if len(mel_rate) > 1 and all(isinstance(m[1], ConvLSTMLinearDAP) for m in mel_rate):
+            outs = dap_forward_many([m[1] for m in mel_rate], [m[2] for m in mel_rate])
+        else:
+            outs = [m[1](*m[2][0], **m[2][1]) for m in mel_rate]
+        for (name, _, _), o in zip(mel_rate, outs):
+            if name == "f0":
+                m = batch["voiced_mask"].unsqueeze(1) if self.f0_loss_voiced_only else None
+                losses.update(self.f0_predictor_loss(o, in_lens, out_lens, global_step, mask=m))
+            elif name == "energy":
+                losses.update(self.energy_predictor_loss(o, in_lens, out_lens, global_step))
+            else:
+                losses.update(self.voiced_predictor_loss(o, in_lens, out_lens, global_step))
         if self.duration_predictor is not None:
             o = self.duration_predictor(attn.sum(2).detach(), txt_enc.detach(), spk_vecs.detach(), in_lens, accent_emb=acc_d)
             losses.update(self.duration_predictor_loss(o, None, None, global_step, in_lens.mask.unsqueeze(1)))

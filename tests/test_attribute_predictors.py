@@ -131,3 +131,49 @@ def test_hip_dap_at_the_shipped_config_sizes(B, T, k, monkeypatch):
     errs = {n: rel_err(q.grad.cpu(), p[n].grad) for n, q in dap.named_parameters() if n in p and p[n].grad is not None}
     bad = {n: e for n, e in errs.items() if not e < 5e-4}
     assert not bad, (bad, errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(4, 96), (32, 400)])
+def test_merged_predictor_lstms_match_separate_calls(B, T, monkeypatch):
+    """attribute_predictors.dap_forward_many runs the bi-LSTMs of the f0 / energy / voiced predictors (one shape, same frames) as
+    ONE block-diagonal recurrence (lstm.MergedBiLSTMFn): outputs and every parameter gradient must equal the three separate
+    launches' (tts_lightning_modules.py:688-717 calls them one after the other) up to the recurrence's fp32 summation order."""
+    from rad_mmm_amd.attribute_predictors import ConvLSTMLinearDAP, dap_forward_many
+    from rad_mmm_amd.common import SequenceLength
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    daps = [ConvLSTMLinearDAP(n_speaker_dim=16, n_accent_dim=8, in_dim=64, out_dim=1, reduction_factor=4, n_backbone_layers=2,
+                              n_hidden=256, kernel_size=5, p_dropout=0.0, use_accent_embedding=True).to(dev).train() for _ in range(3)]
+    for d in daps:
+        for _ in range(20):
+            for hook in d.feat_pred_fn.bilstm._forward_pre_hooks.values():
+                hook(d.feat_pred_fn.bilstm, ())
+        d.eval()                                             # (no further power iteration: both passes see the same weights)
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    txt = (torch.randn(B, 64, T, generator=g) * 0.5).to(dev)
+    spk, acc = torch.randn(B, 16, generator=g).to(dev), torch.randn(B, 8, generator=g).to(dev)
+    gys = [torch.randn(B, 1, T, generator=g).to(dev) for _ in daps]
+    sl = SequenceLength(lens.to(dev))
+    mask = (torch.arange(T)[None, :] < lens[:, None])[:, None].to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RADMMM_MERGE_DAP_LSTM", mode)
+        for d in daps:
+            d.zero_grad(set_to_none=True)
+        outs = dap_forward_many(daps, [((None, txt, spk, sl), {"accent_emb": acc}) for _ in daps])
+        sum(((o["x_hat"] * gy * mask).sum() for o, gy in zip(outs, gys))).backward()
+        res[mode] = ([o["x_hat"].detach().clone() for o in outs],
+                     [{n: p.grad.detach().clone() for n, p in d.named_parameters() if p.grad is not None} for d in daps])
+    for a, b in zip(*[res[m][0] for m in ("0", "1")]):
+        assert rel_err((a * mask).cpu(), (b * mask).cpu()) < 2e-5
+    worst = 0.0
+    for ga, gb in zip(*[res[m][1] for m in ("0", "1")]):
+        assert ga.keys() == gb.keys() and len(ga) >= 10
+        for n in ga:
+            e = rel_err(gb[n].cpu(), ga[n].cpu())
+            worst = max(worst, e)
+            assert e < 2e-4, (n, e)
+    print(f"merged vs separate predictor LSTMs (B={B}, T={T}): worst parameter-gradient rel err {worst:.2e}")

@@ -325,16 +325,49 @@ def test_spline_layer_golden(R, golden):
     mask = (torch.arange(Tn)[None] < lens[:, None]).float().reshape(B * Tn, 1).to(DEV)
     scalar = 0.5 * ((zo[:, :C] * mask) ** 2).sum() - (log_s * mask).sum()
     assert abs(float(scalar.detach()) - float(g["sp.out.scalar"])) < 2e-4 * abs(float(g["sp.out.scalar"]))
-    scalar.backward()
-    gz = zcl.grad[:, :C].cpu().reshape(B, Tn, C).permute(0, 2, 1)
-    assert rel_err(gz, g["sp.grad.z"]) < 1e-3
-    gc = ctx.grad.cpu().reshape(B, Tn, -1).permute(0, 2, 1)
-    assert rel_err(gc, g["sp.grad.ctx"]) < 1e-3
+    # ---- accounting of the knots.  The transform is continuous at a bin edge, its parameter gradient is
+    # not: an element whose argument lies within a few ulp of an edge may take the neighbouring bin here (the kernel's running
+    # sum of the widths and torch's cumsum differ in the last bit) and then carries the other one-sided gradient -- O(1) on
+    # that element, ~1e-3 of a tensor (profiles/r03_spline_bin_edge_ties.txt).  Those elements are LOCATED in the oracle's
+    # run of the same layer (pinned to this fixture by tests/test_oracle_golden.py); frames that hold one are taken out of
+    # the loss on both sides, and everything else is held to the common 5e-4.  No such element: the fixture's own gradients.
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    zc = torch.from_numpy(g["sp.in.z"]).requires_grad_(True)
+    cc = torch.from_numpy(g["sp.in.ctx"]).requires_grad_(True)
+    mk = O.lengths_to_mask(lens)[:, None].float()
+    rec = {}
+    zo_o, ls_o = O.spline_coupling_forward(p, "", zc, cc, mk, 2, use_bn=True, training=True, record=rec)
+    x, edges = rec["x"], rec["edges"]                                    # [B*T, h], [B*T, h, K]
+    inside = (x >= 0) & (x < 1)
+    dist = (edges - x.unsqueeze(-1)).abs().min(-1)[0]
+    near = inside & (dist <= 4 * torch.finfo(torch.float32).eps) & (mk.reshape(-1, 1) > 0)
+    drop = near.any(1)                                                   # frames with a knot-adjacent element
+    print(f"spline layer golden: {int(near.sum())} of {int((inside & (mk.reshape(-1, 1) > 0)).sum())} elements within 4 ulp of a "
+          f"bin edge, {int(drop.sum())} frames excluded")
     params = dict(layer.named_parameters())
-    for n, gr in sub(g, "sp.gradp.").items():
-        assert np.abs(params[n].grad.cpu().numpy() - gr).max() < 1e-3 * np.abs(gr).max() + 1e-5, n
-    for n, gn in sub(g, "sp.gradnorm.").items():
-        assert abs(float(params[n].grad.norm()) - float(gn)) < 1e-3 * float(gn) + 1e-6, n
+    if int(drop.sum()) == 0:
+        scalar.backward()
+        want_z, want_c = torch.from_numpy(g["sp.grad.z"]), torch.from_numpy(g["sp.grad.ctx"])
+        want_p = {n: torch.from_numpy(gr) for n, gr in sub(g, "sp.gradp.").items()}
+        want_n = {n: float(gn) for n, gn in sub(g, "sp.gradnorm.").items()}
+    else:
+        keep = (~drop).float().reshape(B * Tn, 1)
+        (0.5 * ((zo[:, :C] * mask * keep.to(DEV)) ** 2).sum() - (log_s * mask * keep.to(DEV)).sum()).backward()
+        mko = mk * keep.reshape(B, Tn)[:, None]
+        (0.5 * ((zo_o * mko) ** 2).sum() - (ls_o * mko).sum()).backward()
+        want_z, want_c = zc.grad, cc.grad
+        want_p = {n: p[n].grad for n in sub(g, "sp.gradp.")}
+        want_n = {n: float(p[n].grad.norm()) for n in sub(g, "sp.gradnorm.")}
+    gz = zcl.grad[:, :C].cpu().reshape(B, Tn, C).permute(0, 2, 1)
+    gc = ctx.grad.cpu().reshape(B, Tn, -1).permute(0, 2, 1)
+    errs = {"z": rel_err(gz, want_z), "ctx": rel_err(gc, want_c)}
+    assert errs["z"] < 5e-4 and errs["ctx"] < 5e-4, errs
+    for n, gr in want_p.items():
+        gr = gr.numpy()
+        assert np.abs(params[n].grad.cpu().numpy() - gr).max() < 5e-4 * np.abs(gr).max() + 1e-5, n
+    for n, gn in want_n.items():
+        assert abs(float(params[n].grad.norm()) - gn) < 5e-4 * gn + 1e-6, n
+    print("spline layer golden gradient errors:", errs)
 
 
 def test_flow_loss_golden(R, golden):
@@ -427,10 +460,15 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     # T' <= 128) carry up to ~1e-3 of it; it averages down with the frame count and the full-size test
     # (test_decoder_full_size_backward_matches_oracle, 12 800 frames) holds f8x to the same 5e-4 as every other mode.
     # Outputs (z, log-det, NLL: BASELINE's 1e-4 bar) and gradient NORMS (5e-4) are held to the common bars here too.
+    # Accounting (round 5): that noise is zero-mean per element, so next to the elementwise maximum every FULL gradient tensor
+    # in the fixture is also held to 5e-4 in L2 (where a systematic error cannot hide), and the elements beyond 5e-4 of
+    # their tensor's maximum are counted and bounded: <= 0.5 % of the elements of any tensor.
     etol = 2e-3 if precision == "f8x" else 5e-4
     assert rel_err(mel.grad.cpu(), g["grad.mel"]) < etol
+    gm = mel.grad.cpu().numpy().astype(np.float64) - g["grad.mel"]
+    assert np.linalg.norm(gm) < 5e-4 * np.linalg.norm(g["grad.mel"]), np.linalg.norm(gm) / np.linalg.norm(g["grad.mel"])
     assert rel_err(ctx.grad[:, :8, :32].cpu(), g["grad.context.slice"]) < etol
-    worst, worst_el = 0.0, 0.0
+    worst, worst_el, n_over, n_all = 0.0, 0.0, 0, 0
     for n, p in dec.named_parameters():
         gn = float(g["gradnorm." + n])
         mine = float(p.grad.norm())
@@ -438,8 +476,13 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
         worst = max(worst, abs(mine - gn) / (gn + 1e-6))
     for n, gr in sub(g, "gradp.").items():
         p = dict(dec.named_parameters())[n]
-        e = np.abs(p.grad.cpu().numpy() - gr).max()
+        d = np.abs(p.grad.cpu().numpy() - gr)
+        e = d.max()
         assert e < etol * np.abs(gr).max() + 1e-8, n
+        assert np.linalg.norm(d) < 5e-4 * np.linalg.norm(gr) + 1e-8, (n, np.linalg.norm(d) / np.linalg.norm(gr))
+        over = int((d > 5e-4 * np.abs(gr).max() + 1e-8).sum())
+        assert over <= max(1, d.size // 200), (n, over, d.size)
+        n_over, n_all = n_over + over, n_all + d.size
         worst_el = max(worst_el, e / (np.abs(gr).max() + 1e-12))
     for n, gr in sub(g, "gradslice.").items():
         p = dict(dec.named_parameters())[n]
@@ -448,7 +491,8 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
         worst_el = max(worst_el, e / (np.abs(gr).max() + 1e-12))
     print(f"{tag}/{precision}: z rel err {rel_err(zm, g['z_mel']):.2e}, loss rel err "
           f"{abs(float(lm) - float(g['loss_mel'])) / abs(float(g['loss_mel'])):.2e}, grad.mel rel {rel_err(mel.grad.cpu(), g['grad.mel']):.2e}, "
-          f"worst grad-norm rel err {worst:.2e}, worst elementwise grad rel err {worst_el:.2e}")
+          f"worst grad-norm rel err {worst:.2e}, worst elementwise grad rel err {worst_el:.2e}, "
+          f"{n_over} of {n_all} full-tensor gradient elements beyond 5e-4 of their tensor's maximum")
 
 
 def test_context_lstm_two_streams_matches_packed_path(R):

@@ -195,21 +195,67 @@ def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
     monkeypatch.setenv("RADMMM_PRECISION", os.environ.get("RADMMM_TEST_C5_PRECISION", "f8x"))
     kw = dict(KW2, n_text_dim=520, use_accent_emb_for_decoder=False, n_splines=2, use_bn=True)
     B, Tn = 32, 2000
-    ref = oracle_decoder_run(kw, B, Tn, 2024, ragged=True)
-    try:
-        dec = RADMMMFlow(use_accent=True, **kw)
-        dec.load_state_dict(ref["sd"])
-        dec = dec.to(DEV).train()
-        dec.precision_guard_every = 0
-        b = ref["batch"]
-        gb = {k: v.to(DEV) for k, v in b.items()}
-        sl = SequenceLength(gb["lengths"])
-        mel = gb["mel"].clone().requires_grad_(True)
+    import radmmm_synth as S
+    from rad_mmm_amd import spline_layers
+    from rad_mmm_amd._lib import lib, check, ptr, stream
+    cfg = S.DecoderConfig(**kw)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in S.procedural_decoder_state(S.decoder_state_shapes(cfg)).items()}
+    b = {k: torch.from_numpy(np.asarray(v)) for k, v in S.synthetic_batch(B, Tn, cfg, 2024, ragged=True).items()}
+    dec = RADMMMFlow(use_accent=True, **kw)
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).train()
+    dec.precision_guard_every = 0
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    sl = SequenceLength(gb["lengths"])
+    mel = gb["mel"].clone().requires_grad_(True)
+    state = {}
+
+    # the bins the HIP forward's search picks, per spline flow (radmmm_pq_spline_bins on the very operands of each
+    # radmmm_pq_spline_fwd call of the pass)
+    real_fwd = lib.radmmm_pq_spline_fwd
+    gpu_bins = []
+
+    def spy(x, ldx, q, ldq, y, ldy, lj, rows, h, K, st):
+        rc = real_fwd(x, ldx, q, ldq, y, ldy, lj, rows, h, K, st)
+        bins = torch.empty(rows, h, dtype=torch.int32, device=DEV)
+        el, er = torch.empty(rows, h, device=DEV), torch.empty(rows, h, device=DEV)
+        check(lib.radmmm_pq_spline_bins(x, ldx, q, ldq, ptr(bins), ptr(el), ptr(er), rows, h, K, st), "pq_spline_bins")
+        gpu_bins.append(bins)
+        return rc
+
+    def hip_forward_and_flipped_frames(recs, m):
+        """runs between the oracle's forward and backward: the HIP forward on the same batch; -> frames that hold an element
+        whose bin differs between the two searches (each must lie within 8 ulp of an edge: asserted)"""
+        monkeypatch.setattr(spline_layers.lib, "radmmm_pq_spline_fwd", spy)
         torch.cuda.reset_peak_memory_stats()
-        out = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
-        lm = RADMMMLoss(n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
-        lm.backward()
+        state["out"] = dec(mel, gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
+        monkeypatch.setattr(spline_layers.lib, "radmmm_pq_spline_fwd", real_fwd)
         torch.cuda.synchronize()
+        assert len(gpu_bins) == len(recs) == 2
+        flipped = torch.zeros(m.numel(), dtype=torch.bool)
+        n_flip, n_far = 0, 0
+        for r, gbn in zip(recs, gpu_bins):
+            hb = gbn.cpu()[:, : r["bins"].shape[1]]
+            d = (hb != r["bins"]) & m.reshape(-1, 1)
+            n_flip += int(d.sum())
+            n_far += int((d & ~r["near"]).sum())
+            flipped |= d.any(1)
+        state["n_flip"], state["n_far"] = n_flip, n_far
+        return flipped
+    ref = oracle_decoder_run(kw, B, Tn, 2024, ragged=True, knot_ulps=8, frame_weight_fn=hip_forward_and_flipped_frames)
+    try:
+        out = state["out"]
+        lm = RADMMMLoss(n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
+        # the backward starts from the SAME loss with the knot frames taken out (compute_flow_loss, loss.py:85-110, with the
+        # frame weights determined above: 0 where a spline element lies within 8 ulp of a bin edge or the two searches differ)
+        mw = (ref["mask"].float() * ref["frame_weight"]).to(DEV)
+        n_el = float(torch.div(gb["lengths"].sum(), 2, rounding_mode="floor"))
+        zm = out["z_mel"] * mw
+        lw = (0.5 * (zm * zm).sum() - sum((ls * mw).sum() for ls in out["log_s_list"])
+              - sum(out["log_det_W_list"]) * n_el) / (n_el * out["z_mel"].shape[1])
+        lw.backward()
+        torch.cuda.synchronize()
+        assert abs(float(lw.detach()) - ref["weighted_loss"]) < 1e-4 * abs(ref["weighted_loss"])
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
         assert torch.isfinite(out["z_mel"]).all() and torch.isfinite(lm) and torch.isfinite(mel.grad).all()
         m = ref["mask"]
@@ -232,16 +278,32 @@ def test_config5_defining_size_T2000_against_the_oracle(monkeypatch):
             go = ref["grads"][n]
             gn, mine = float(go.norm()), float(q.grad.norm())
             r = abs(mine - gn) / (gn + 1e-6)
-            if r > worst and gn > 1e-7:
+            # (scale and bias of the conv that feeds a batch-norm: analytically zero gradient, rounding residue only)
+            if r > worst and gn > 1e-7 and not n.endswith(("hidden_conv.conv.weight_g", "hidden_conv.conv.bias")):
                 worst, worst_n = r, n
         print(f"configs[4] at B=32, T=2000: z rel {zerr:.2e}, log_s sums rel {lserr:.2e}, NLL rel {lerr:.2e}, d/d mel max-rel {gerr:.2e} / "
               f"L2-rel {gl2:.2e} / fraction of elements off by > 5e-4 of the max {gfrac:.2e}, worst grad-norm rel {worst:.2e} ({worst_n}); "
               f"peak device memory {peak:.1f} GiB")
+        print(f"    knot accounting: {ref['knot_elements']} spline elements within 8 ulp of a bin edge; the two bin searches differ "
+              f"on {state['n_flip']} elements ({state['n_far']} of them NOT within 8 ulp); {ref['knot_frames']} of "
+              f"{int(ref['mask'].sum())} frames excluded from the loss the gradients start from")
+        print(f"    kink accounting: {ref['leaky_near_zero']} of {ref['leaky_total']} leaky-ReLU pre-activations of the FiLM stacks lie "
+              f"within 2e-5 rms of 0 in the oracle's run")
         assert zerr < 1e-4 and lserr < 1e-4 and lerr < 1e-4
-        assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3
+        # Round 5 finding: with every frame that holds a knot-adjacent spline element, or an element on which the two bin
+        # searches differ, TAKEN OUT of the loss, the gradient figures do not move at all (9.94e-4 L2 / 2.09e-3 max before and
+        # after): the spline's knots are NOT what separates the two gradients here (DESIGN 2 said so since round 3).  What is
+        # left is the other kink of these flows, the FiLM blocks' leaky ReLUs (slope 1 / 0.01 at 0; common.py:728-735): the
+        # count above is the number of pre-activations that another summation order can push across it, each moving the
+        # gradient of everything in its receptive field.  tests/test_attribute_predictors.py shows the mechanism and its
+        # remedy at the predictors' ReLUs (1e-2 -> 5e-4 once the HIP module's decisions are imposed on the oracle); here
+        # the decisions of 2 x 4 fused FiLM kernels are not observable from their outputs, so the bars stay where the
+        # measured figures are, now with both counts printed: L2 2e-3, max 5e-3 of the tensor's maximum, <= 0.1 % of the
+        # elements beyond 5e-4, gradient norms 1e-3.
+        assert gl2 < 2e-3 and gerr < 5e-3 and gfrac < 1e-3, (gl2, gerr, gfrac)
         assert worst < 1e-3, (worst_n, worst)
     finally:
-        drop(kw, B, Tn, 2024, ragged=True)                       # ~2 GB of host memory
+        drop(kw, B, Tn, 2024, ragged=True, knot_ulps=8, with_fn=True)          # ~2 GB of host memory
 
 
 # ---------------------------------------------------------------------------------------------------------------------
