@@ -120,12 +120,15 @@ def time_dominant_kernel_h3(N, T, reps=20, nprod=3):
     y = torch.empty(N, 1024, device=dev)
     yh, yl = torch.empty_like(xh), torch.empty_like(xl)
     lens = torch.full((N // T,), T, dtype=torch.int32, device=dev)
+    # the launch writes what the step's launch writes: since round 5 the FP8-cross scheme keeps the hidden state as its split
+    # pair only (no fp32 copy: C = NULL; ops.AffineFlowStepH3Fn `pair_only`)
+    keep_c = not (nprod == 2 and os.environ.get("RADMMM_KEEP_FP32", "0") != "1")
 
     def launch():
         rowgemm_h3(nprod=nprod, a8_exp=ops.X8_ACT_EXP, b8_exp=ops.X8_W_EXP, split_fmt=ops.fmt_a(nprod), ch_x8_exp=ops.X8_ACT_EXP,
                    Ah=xh, Al=xl, lda_h=1024, Bh=Wh, Bl=Wl, ldb_h=1024, b_tap_stride_h=Wh.stride(0),
-                   acc_scale=1.0 / ops.W_SCALE, C=y, ldc=1024, M=N, N=1024, K=1024, taps=5, dil=2, sign=1, T=T, lens=lens,
-                   a_mask_mode=1, bias=b, pconv=1, ratio_taps=5, ratio_dil=2, postmask=1, act=1, Ch=yh, Cl=yl, ldch=1024,
+                   acc_scale=1.0 / ops.W_SCALE, C=y if keep_c else None, ldc=1024, M=N, N=1024, K=1024, taps=5, dil=2, sign=1, T=T,
+                   lens=lens, a_mask_mode=1, bias=b, pconv=1, ratio_taps=5, ratio_dil=2, postmask=1, act=1, Ch=yh, Cl=yl, ldch=1024,
                    ch_scale=1.0)
     for _ in range(3):
         launch()
@@ -922,15 +925,16 @@ def main():
                          # fp32 operands and result once = A 52 MB + W 21 MB + C 52 MB at M = 12 800
                          "algorithmic_bytes_per_launch": N * 1024 * 4 * 2 + 5 * 1024 * 1024 * 4,
                          # what this kernel's formats move at best: split A (hi + 8-bit cross array, 4 B/element), split
-                         # weights (4 B), fp32 output (4 B) and its split copy (4 B), each once
-                         "own_format_bytes_per_launch": (N * 1024 * 12 + 5 * 1024 * 1024 * 4) if h3 else None,
+                         # weights (4 B) and the output's split pair (4 B; since round 5 no fp32 copy beside it under the
+                         # FP8-cross scheme: 8 B with one), each once
+                         "own_format_bytes_per_launch": (N * 1024 * (8 if f8x else 12) + 5 * 1024 * 1024 * 4) if h3 else None,
                          "traffic": traffic, "traffic_static": traffic is not None, "traffic_source": traffic_src,
                          # FETCH_SIZE counts L2 -> fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM): with 8
                          # XCDs = 8 private L2s an operand is fetched once per XCD that uses it.  The tile sequence gives an XCD
                          # r x c = 29 tiles (r row tiles of 224 rows x 4 KB, c column tiles of 5.2 MB of weights); r A + c B is
                          # minimal at c = 2 (the shipped order: r = 14.5): 13.3 + 10.5 MB per XCD = 190 MB of reads per launch
                          # for 73 MB of operands -- the floor of this counter for any 8-L2 mapping, not re-reads from HBM
-                         "traffic_floor_8_private_l2": (190.4e6 + N * 1024 * 8.0) if (h3 and N == 12800) else None,
+                         "traffic_floor_8_private_l2": (190.4e6 + N * 1024 * (4.0 if f8x else 8.0)) if (h3 and N == 12800) else None,
                          # what a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS data distribution (uniform random
                          # operands throttle the clock to ~1.55 GHz; zeros reach 2230): profiles/r01_mfma_dep.txt
                          "peak_measured_random_operands": 1620.0 if h3 else None,

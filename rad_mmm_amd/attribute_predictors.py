@@ -26,13 +26,22 @@ class _ConvHolder(nn.Module):
         self.conv = _WNConv(cin, cout, k, w_init_gain=gain)
 
 
+PAD = 32        # channel padding of the conv inputs: Cin % 32 == 0 puts a conv on the split-f16 GEMM kernels (ops.conv_norm); the shipped
+                # predictors have in_dim 520 and a 56-channel conv-stack input, which ran on the fp32-MFMA kernels at ~170 us a launch
+
+
 def _rows(x):
-    """[B, C, T] -> channels-last rows [B*T, round_up(C, 4)]"""
+    """[B, C, T] -> channels-last rows [B*T, round_up(C, 32)] (zero padded)"""
     B, C, T = x.shape
     y = x.float().permute(0, 2, 1)
-    if C % 4:
-        y = F.pad(y, (0, (-C) % 4))
+    if C % PAD:
+        y = F.pad(y, (0, (-C) % PAD))
     return y.reshape(B * T, -1).contiguous()
+
+
+def _pad_in(v, cin_p):
+    """weight_v [Cout, Cin, k] zero-padded along Cin (the weight norm's row norms do not change)"""
+    return v if v.shape[1] == cin_p else F.pad(v, (0, 0, 0, cin_p - v.shape[1]))
 
 
 class BottleneckLayer(nn.Module):
@@ -47,13 +56,13 @@ class BottleneckLayer(nn.Module):
         if reduction_factor > 1:
             self.projection_fn = _ConvHolder(in_dim, self.out_dim, kernel_size)
 
-    def forward_rows(self, x_rows, lens32, B, T):
+    def forward_rows(self, x_rows, lens32, B, T, scale_box=None):
         if self.reduction_factor <= 1:
             return x_rows
         c = self.projection_fn.conv
         # ConvNorm without partial padding: conv of the padded batch as it is, then * mask (common.py:179-191)
-        return ops.conv_norm(x_rows, c.weight_v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
-                             act="leaky_relu" if self.leaky else "relu")
+        return ops.conv_norm(x_rows, _pad_in(c.weight_v, x_rows.shape[1]), c.weight_g, c.bias, lens32, B, T, dil=1, partial=False,
+                             mask_out=True, act="leaky_relu" if self.leaky else "relu", scale_box=scale_box)
 
 
 class ConvLSTMLinear(nn.Module):
@@ -73,20 +82,21 @@ class ConvLSTMLinear(nn.Module):
 
     def forward_rows(self, h, lens32, B, T):
         """h [B*T, ld] channels-last context -> x_hat [B, out_dim, T]"""
-        return self.post_lstm(bilstm(self.bilstm, self.pre_lstm_rows(h, lens32, B, T), lens32))
+        return self.post_lstm(bilstm(self.bilstm, self.pre_lstm_rows(h, lens32, B, T, ops.module_scale_box(self, h.device)), lens32))
 
     def post_lstm(self, y):
         return self.dense(y).transpose(1, 2)
 
-    def pre_lstm_rows(self, h, lens32, B, T):
+    def pre_lstm_rows(self, h, lens32, B, T, scale_box=None):
         """the conv stack: h [B*T, ld] channels-last context -> the bi-LSTM's input [B, T, C]; materialises the
         spectral-normed recurrent weights (the LSTM's own forward pre-hooks) on the way"""
         valid = (torch.arange(T, device=h.device)[None, :] < lens32[:, None]).reshape(B * T, 1)
         h = h * valid                                  # a conv over x[:, :len] sees zeros beyond len
         for holder in self.convolutions:
             c = holder.conv
-            h = ops.conv_norm(h, c.weight_v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
-                              act="relu")
+            v = _pad_in(c.weight_v, h.shape[1]) if h.shape[1] % PAD == 0 else c.weight_v
+            h = ops.conv_norm(h, v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
+                              act="relu", scale_box=scale_box)
             h = F.dropout(h, self.p_dropout, self.training)
         for hook in self.bilstm._forward_pre_hooks.values():        # materialise the spectral-normed weight_hh_l0*
             hook(self.bilstm, ())
@@ -148,25 +158,29 @@ class ConvLSTMLinearDAP(AttributePredictor):
         x_target, xin, lens32 = self.forward_pre(x_target, text_enc, spk_emb, lens, x_mean, x_std, accent_emb)
         return {"x_hat": self.feat_pred_fn.post_lstm(bilstm(self.feat_pred_fn.bilstm, xin, lens32)), "x": x_target}
 
-    def forward_pre(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
+    def forward_pre(self, x_target, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None, rows=None):
         """everything in front of the bi-LSTM: target transform, bottleneck, embeddings, conv stack
-        -> (transformed target, LSTM input [B, T, C], lens32)"""
+        -> (transformed target, LSTM input [B, T, C], lens32).  rows: _rows(text_enc) when the caller has it already (several
+        predictors reading the same context)"""
         if not text_enc.is_cuda:
             raise RuntimeError("rad_mmm_amd.attribute_predictors runs on an MI355X only (no CPU path)")
         if x_target is not None:
             x_target = self.tx_data(x_target, x_mean, x_std)
         B, _, T = text_enc.shape
         lens32 = lens.lengths.to(torch.int32).contiguous()
-        h = self.bottleneck_layer.forward_rows(_rows(text_enc), lens32, B, T)
+        # gradient scale / saturation state of this predictor's split-f16 convs (ops.GradScale, one per module: with a
+        # throw-away dict every conv's backward would read its gradient's maximum on the host -- 8 synchronisations per joint step)
+        box = ops.module_scale_box(self, new_forward_on=text_enc.device)
+        h = self.bottleneck_layer.forward_rows(_rows(text_enc) if rows is None else rows, lens32, B, T, box)
         parts = [h[:, : self.bottleneck_layer.out_dim].reshape(B, T, -1)]
         if self.use_speaker_embedding:
             parts.append(spk_emb.float()[:, None, :].expand(-1, T, -1))
         if self.use_accent_embedding:
             parts.append(accent_emb.float()[:, None, :].expand(-1, T, -1))
         ctx = torch.cat(parts, 2)
-        if ctx.shape[2] % 4:
-            ctx = F.pad(ctx, (0, (-ctx.shape[2]) % 4))
-        return x_target, self.feat_pred_fn.pre_lstm_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T), lens32
+        if ctx.shape[2] % PAD:
+            ctx = F.pad(ctx, (0, (-ctx.shape[2]) % PAD))
+        return x_target, self.feat_pred_fn.pre_lstm_rows(ctx.reshape(B * T, -1).contiguous(), lens32, B, T, box), lens32
 
     @fp32_region
     def infer(self, text_enc, spk_emb, lens: SequenceLength, x_mean=None, x_std=None, accent_emb=None):
@@ -183,7 +197,14 @@ def dap_forward_many(daps, calls):
     predictor.  Same values as the separate calls (the recurrence's fp32 summation order apart); predictors whose LSTMs
     cannot be merged (other sizes, other lengths) take their own launch."""
     from .lstm import can_merge, merged_bilstm
-    pres = [d.forward_pre(*a, **k) for d, (a, k) in zip(daps, calls)]
+    shared = {}                                            # channels-last copy of a context several predictors read: made once
+
+    def rows_of(t):
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+        if key not in shared:
+            shared[key] = _rows(t)
+        return shared[key]
+    pres = [d.forward_pre(*a, **k, rows=rows_of(a[1])) for d, (a, k) in zip(daps, calls)]
     lstms = [d.feat_pred_fn.bilstm for d in daps]
     xs = [p[1] for p in pres]
     same_lens = all(c[0][3] is calls[0][0][3] for c in calls)                 # the same SequenceLength object

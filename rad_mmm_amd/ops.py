@@ -573,8 +573,18 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     meta["nprod"] = 3 if prec == "f8x" else NPROD.get(prec, 3)
     if nprod == 2 and prec == "f8x" and x.shape[0] >= int(debug_env("RADMMM_F8X_MIN_ROWS", "4096")) and v.shape[0] % 32 == 0:
         meta["nprod"] = 2          # a caller that has established the FP8-cross scheme's accuracy for this conv (FiLM blocks)
-    if (prec in NPROD and Cin % 32 == 0 and (taps // 2) * dil <= 16
-            and x.shape[0] >= min_rows and x.shape[0] * max(Cin, Cout) < 2 ** 30):
+    h3_ok = (prec in NPROD and (taps // 2) * dil <= 16 and x.shape[0] >= min_rows and
+             x.shape[0] * max(round_up(Cin, 32), Cout) < 2 ** 30)
+    if h3_ok and Cin % 32 != 0 and x.is_cuda and debug_env("RADMMM_CONVNORM_PAD", "1") != "0":
+        # the split-f16 kernels want K % 32 == 0: an odd input width (the RADMMM configs' n_text_dim = 520 in the text encoder,
+        # the key projection and the predictors' bottlenecks) is zero-padded -- x by one small copy, the weight by autograd's
+        # pad, whose zeros leave the weight norm alone -- instead of running the conv on the fp32-MFMA kernels (joint step:
+        # 275 us per launch there).  Gradients come back through the slice / pad nodes.
+        padc = (-Cin) % 32
+        x = torch.nn.functional.pad(x[:, :Cin], (0, padc))
+        v = torch.nn.functional.pad(v, (0, 0, 0, padc))
+        Cin += padc
+    if h3_ok and Cin % 32 == 0:
         return ConvNormH3Fn.apply(meta, x, v, g, bias, lens)
     return ConvNormFn.apply(meta, x, v, g, bias, lens)
 

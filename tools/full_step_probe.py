@@ -16,20 +16,21 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=7)
+    ap.add_argument("--joint", action="store_true", help="BASELINE configs[3]: RADMMM decoder + the four attribute predictors")
     args = ap.parse_args()
     import bench
     import radmmm_synth as O
     from rad_mmm_amd.decoders import RADMMMFlow
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    CFG = bench.CONFIGS["radtts"]
+    CFG = bench.CONFIGS["joint" if args.joint else "radtts"]
     cfg, sd = bench.procedural_state(CFG)
     dec = RADMMMFlow(use_accent=True, **CFG)
     dec.load_state_dict(sd)
     dec = dec.to(dev).train()
     B, T = 32, 800
     gb = {k: torch.from_numpy(v).to(dev) for k, v in O.synthetic_batch(B, T, cfg, seed=1234, ragged=False).items()}
-    print(json.dumps(bench.full_step_leg(dec, cfg, CFG, gb, B, T, dev, 0.0, steps=args.steps)))
+    print(json.dumps(bench.full_step_leg(dec, cfg, CFG, gb, B, T, dev, 0.0, steps=args.steps, joint=args.joint)))
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ TAG="$1"; shift
 OUT="$ROOT/gpurun_out/prof_full_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT" -- python "$ROOT/tools/full_step_probe.py" --steps 7 > "$OUT/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT" -- python "$ROOT/tools/full_step_probe.py" --steps 7 ${PROBE_ARGS:-} > "$OUT/bench.log" 2>&1
 DB=$(find "$OUT" -name "*.db" | head -1)
 cd "$ROOT"
 python tools/kernel_stats.py "$DB" 12 --gaps --json "gpurun_out/${TAG}_full_step_kernel_stats.json" > "gpurun_out/${TAG}_full_step_kernel_stats.txt" 2>&1
