@@ -426,22 +426,34 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         // slot 0
         acc[i][0] = WG8_MFMA_F16(ah0, bh0[0], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i2 < 4) frag_issue<0>(ga0[nx2], ah_base[i2 & 3] + sb2);
-        else frag_issue<256>(ga0[nx2], ah_base[i2 & 3] + sb2);
+        // -DRADMMM_WG8_SKIP_READS, TIMING-ONLY (wrong results): the A-side fragment reads of every other row block are not
+        // issued -- 24 of the 60 LDS reads of a K step; a 2 x 2 wave tiling of the same 256 x 256 tile would save 12 (48 reads
+        // instead of 60): an upper bound of that redesign before anything is built (profiles/r05_wgrad_hi8.txt)
+#ifdef RADMMM_WG8_SKIP_READS
+        const bool do_rd = (i2 & 1) == 0;
+#else
+        const bool do_rd = true;
+#endif
+        if (do_rd) {
+          if (i2 < 4) frag_issue<0>(ga0[nx2], ah_base[i2 & 3] + sb2);
+          else frag_issue<256>(ga0[nx2], ah_base[i2 & 3] + sb2);
+        }
         frag_wait3<2>(ga0[nx1], ga1[nx1], ga8[nx1]);               // block i + 1's fragments (read a whole block ago): two younger reads in flight
         if (i == 7) frag_issue<0>(xb0[0], bh_base[0] + sbn);        // (bh0[0] holds the old value: last read by the MFMA above)
         __builtin_amdgcn_sched_barrier(0);
         // slot 1
         acc[i][1] = WG8_MFMA_F16(ah0, bh0[1], acc[i][1]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i2 < 4) frag_issue<8192>(ga1[nx2], ah_base[i2 & 3] + sb2);
-        else frag_issue<8192 + 256>(ga1[nx2], ah_base[i2 & 3] + sb2);
+        if (do_rd) {
+          if (i2 < 4) frag_issue<8192>(ga1[nx2], ah_base[i2 & 3] + sb2);
+          else frag_issue<8192 + 256>(ga1[nx2], ah_base[i2 & 3] + sb2);
+        }
         if (i == 7) frag_issue<0>(xb0[1], bh_base[1] + sbn);
         __builtin_amdgcn_sched_barrier(0);
         // slot 2
         acc[i][0] = WG8_MFMA_F16(ah1, bh1[0], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        frag8_issue(ga8[nx2], a8_base[i2] + sb2);
+        if (do_rd) frag8_issue(ga8[nx2], a8_base[i2] + sb2);
         if (i == 7) frag_issue<8192>(xb1[0], bh_base[0] + sbn);
         __builtin_amdgcn_sched_barrier(0);
         // slot 3
