@@ -1,0 +1,99 @@
+"""CPU checks of the oracle's round-5 additions (test infrastructure testing itself, no GPU): the restatement of
+TTSModel.training_step used by `bench.py --config joint` / tests/test_joint_step.py is self-consistent, and the accounting hooks
+(`gates`, `record`) do not change what the oracle computes when they impose nothing new."""
+import numpy as np
+import torch
+
+from oracle import radmmm_oracle as O
+
+
+def _dap_params(in_dim=24, n_hidden=16, k=3, n_layers=2, spk=6, red=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.3
+    b = in_dim // red
+    p = {"bottleneck_layer.projection_fn.conv.weight_v": r(b, in_dim, 3), "bottleneck_layer.projection_fn.conv.weight_g": torch.ones(b, 1, 1),
+         "bottleneck_layer.projection_fn.conv.bias": r(b)}
+    cin = b + spk
+    for i in range(n_layers):
+        q = f"feat_pred_fn.convolutions.{i}.conv."
+        p[q + "weight_v"], p[q + "weight_g"], p[q + "bias"] = r(n_hidden, cin, k), torch.ones(n_hidden, 1, 1), r(n_hidden)
+        cin = n_hidden
+    H = n_hidden // 2
+    for suf in ("", "_reverse"):
+        p[f"feat_pred_fn.bilstm.weight_ih_l0{suf}"], p[f"feat_pred_fn.bilstm.weight_hh_l0{suf}"] = r(4 * H, n_hidden), r(4 * H, H)
+        p[f"feat_pred_fn.bilstm.bias_ih_l0{suf}"], p[f"feat_pred_fn.bilstm.bias_hh_l0{suf}"] = r(4 * H), r(4 * H)
+    p["feat_pred_fn.dense.weight"], p["feat_pred_fn.dense.bias"] = r(1, n_hidden), r(1)
+    return p
+
+
+def test_dap_gates_with_the_natural_decisions_change_nothing():
+    p = _dap_params()
+    g = torch.Generator().manual_seed(1)
+    B, T = 3, 20
+    txt, spk = torch.randn(B, 24, T, generator=g), torch.randn(B, 6, generator=g)
+    lens = torch.tensor([20, 13, 7])
+    rec = {}
+    y0 = O.dap_forward(p, "", txt, spk, lens, 2, record=rec)
+    gates = {k: v > 0 for k, v in rec.items()}
+    y1 = O.dap_forward(p, "", txt, spk, lens, 2, gates=gates)
+    assert torch.equal(y0, y1)
+    # a flipped decision at an element far from the kink DOES change the output (the hook is live)
+    gates[(0, 0)] = ~gates[(0, 0)]
+    y2 = O.dap_forward(p, "", txt, spk, lens, 2, gates=gates)
+    assert not torch.allclose(y0, y2)
+
+
+def test_spline_records_do_not_change_the_transform():
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(50, 4, generator=g)
+    wt, vt = torch.randn(50, 4, 8, generator=g), torch.randn(50, 4, 9, generator=g)
+    y, lj = O.piecewise_quadratic_transform(x, wt, vt)
+    wc = torch.cumsum(torch.softmax(wt, -1), -1)
+    wc[..., -1] = 1.0
+    idx = torch.searchsorted(wc, x.unsqueeze(-1)).squeeze(-1)
+    assert int(idx.min()) >= 0 and int(idx.max()) <= 7 and torch.isfinite(y).all() and torch.isfinite(lj).all()
+    # the element's argument lies inside the bin the search picked
+    lo = torch.gather(torch.nn.functional.pad(wc, (1, 0)), -1, idx.unsqueeze(-1)).squeeze(-1)
+    hi = torch.gather(wc, -1, idx.unsqueeze(-1)).squeeze(-1)
+    assert bool(((x >= lo - 1e-6) & (x <= hi + 1e-6)).all())
+
+
+def test_joint_step_restatement_is_self_consistent():
+    """oracle.tts_joint_step on a small model built exactly as bench.py's joint leg builds it (module construction only: no
+    kernel runs on the CPU): the summed loss is the weighted sum of its terms, every predictor contributes one term and one
+    output of the right rate, hard alignments are 0/1 with one text position per frame."""
+    import bench
+    import radmmm_synth as S
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    CFG = dict(bench.RADMMM, n_flows=2)
+    cfg, sd = bench.procedural_state(CFG)
+    dec = RADMMMFlow(use_accent=True, **CFG)
+    dec.load_state_dict(sd)
+    torch.manual_seed(1234)
+    model = TTSTrainingStep(Encoder(3, CFG["n_text_dim"], 5), dec, RADMMMLoss(sigma=1.0, kl_loss_start_iter=0), n_speakers=8, n_accents=4,
+                            n_text_tokens=185, n_text_dim=CFG["n_text_dim"], n_speaker_dim=16, n_accent_dim=8, use_accent=True,
+                            use_accent_emb_for_decoder=False, binarization_start_iter=0, **bench.build_joint_predictors(CFG))
+    B, T, L = 2, 64, 12
+    b = S.synthetic_batch(B, T, cfg, seed=1, ragged=False)
+    g = torch.Generator().manual_seed(9)
+    batch = {"mel": torch.from_numpy(b["mel"]) * 2 - 5, "speaker_ids": torch.randint(0, 8, (B,), generator=g),
+             "accent_ids": torch.randint(0, 4, (B,), generator=g), "text": torch.randint(0, 185, (B, L), generator=g),
+             "input_lengths": torch.tensor([L, L - 3]), "output_lengths": torch.from_numpy(b["lengths"]),
+             "attn_prior": torch.from_numpy(np.stack([O.interpolated_prior(L, T) for _ in range(B)])).float(),
+             "f0": torch.from_numpy(b["f0"]), "energy_avg": torch.from_numpy(b["energy"])}
+    batch["voiced_mask"] = (batch["f0"] > batch["f0"].median()).float()
+    p = {n: (v.detach().float() if v.is_floating_point() else v.detach()) for n, v in model.state_dict().items()}
+    specs = {name: dict(n_layers=3, weight=1.0, **spec) for name, spec in bench.JOINT_PREDICTORS.items()}
+    with torch.no_grad():
+        r = O.tts_joint_step(p, cfg, batch, specs)
+    total = sum(float(v) * w for v, w in r["losses"].values())
+    assert abs(float(r["loss"]) - total) < 1e-5 * abs(total)
+    assert {"f0_loss", "energy_loss", "vpred_loss", "duration_loss", "loss_mel", "loss_ctc", "binarization_loss"} <= set(r["losses"])
+    assert r["pred"]["f0"].shape == (B, 1, T) and r["pred"]["duration"].shape == (B, 1, L)
+    assert all(torch.isfinite(v).all() for v in r["pred"].values())
+    hard = r["attn"].round()
+    assert bool(((hard == 0) | (hard == 1)).all()) and bool((hard[0, 0].sum(1) == 1).all())
+    assert int(hard[1, 0, :, L - 3:].sum()) == 0                      # nothing aligned to the padded text positions
