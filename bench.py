@@ -15,6 +15,9 @@ backward (rad_mmm_amd/ddp.py).  Rank 0 prints ONE JSON line.  Extra objects:
   wn_stack     the north_star's derived view: algorithmic fp32 bytes of the WN stack / step time
   cpu_baseline the CPU oracle (a port of the reference's arithmetic) timed on the host cores
                on a bounded sample of the same workload (rank 0, N=1 only)
+Other workloads beside the headline line: --full-step (the whole training step of the reference's loop), --config joint
+(BASELINE configs[3]: RADMMM decoder + the four attribute predictors in ONE step, with its own parity block against the CPU
+oracle's restatement of TTSModel.training_step), --config radmmm / radmmm_splines (configs[2] / configs[4]).
 """
 import argparse
 import json
@@ -210,15 +213,15 @@ def hbm_rooflines(dec, cfg, B, T):
     """SURVEY 8(d)'s second regime: the HBM-bound kernel classes of the step, each as algorithmic bytes per step / in-step time
     per step against the 8 TB/s peak.  Bytes are computed here from the model's shapes; the in-step durations cannot be taken
     from inside the process (they are per-kernel sums over a step) and are QUOTED from the committed rocprofv3 kernel trace of
-    this very workload, profiles/r04_kernel_stats.json (tools/prof_step.sh), labelled static."""
+    this very workload, profiles/r05_kernel_stats.json (tools/prof_step.sh), labelled static."""
     import math
     # a trace belongs to ONE workload: the default bench line's (RADTTS, B = 32, T = 800) or BASELINE configs[4]'s
     # (`--config radmmm_splines --frames 2000`); any other shape has no committed trace and gets no static figures
     n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
     if (B, T) == (32, 800) and not n_spl and cfg.cond_dims == 1048:
-        trace = "r04_kernel_stats.json"
+        trace = "r05_kernel_stats.json"
     elif (B, T) == (32, 2000) and n_spl == 2:
-        trace = "r04_c5_kernel_stats.json"
+        trace = "r05_c5_kernel_stats.json"
     else:
         return None
     path = os.path.join(ROOT, "profiles", trace)
@@ -254,7 +257,8 @@ def hbm_rooflines(dec, cfg, B, T):
         "dact_transposed_kernel": ("gQ = gOUT * softplus'(R): two fp32 reads, split pair written (4 layers x flows)", N * 1024 * (4 + 4 + 4.0) * 4 * (len(dec.flows) - n_spl)),
         "affine_coupling_fwd_kernel": ("affine coupling forward (O, z1 read; z, log s written)", N * (C + C + C + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
         "affine_coupling_bwd_kernel": ("affine coupling backward", N * (C * 5 + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
-        "wn_input_fwd4_kernel": ("WN input assembly [context | z half] + split copy", N * (1048 + 80 + 1152 + 1152) * 4.0 * (len(dec.flows) - n_spl)),
+        "wn_input_fwd4_kernel": ("WN input assembly [context | z half] written as its split pair only (round 5: no fp32 copy)",
+                                 N * (1048 + 80 + 1152) * 4.0 * (len(dec.flows) - n_spl)),
     }
     out = []
     for sub, (what, bytes_step) in rows.items():
@@ -861,7 +865,7 @@ def main():
             # each bracketed by HIP events on its stream, over three more steps.  Back to back the kernel runs into the
             # chip's power limit (MFMA at full tilt throttles the clock); in the step it alternates with memory-bound
             # kernels.  The in-step average is what rocprofv3's kernel trace of the step shows for this kernel
-            # (profiles/r04_kernel_stats.json) and what `achieved` is priced on; the back-to-back figure stays beside it.
+            # (profiles/r05_kernel_stats.json) and what `achieved` is priced on; the back-to-back figure stays beside it.
             kdur = float(np.mean(in_step)) if in_step else kdur_iso
             n_in_step = len(in_step)
             # executed MFMA work in f16-equivalent products: 3 f16 products, or 1 f16 + 2 FP8 products at twice the rate

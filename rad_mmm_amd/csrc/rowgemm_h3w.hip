@@ -157,6 +157,13 @@ static int launch_rowgemm_h3w_inner(const radmmm_rowgemm_h3_desc& d, hipStream_t
     return launch_h3d_pr2(mb, ek, d, stream, a_bytes, b_bytes);
   }
   if (d.nprod == 1) return launch_h3d_pr1(mb, ek, d, stream, a_bytes, b_bytes);       // 16-bit throughput mode
+  {                                                                                   // three f16 products
+    const char* s3 = debug_env("RADMMM_SLOT3");       // RADMMM_DEBUG: RADMMM_SLOT3=0 keeps rowgemm_h3d for every three-product launch (A/B, tests)
+    if (!(s3 && atoi(s3) == 0)) {
+      if (rowgemm_win_ok(mb, ek, d)) return launch_rowgemm_win(mb, ek, d, stream, a_bytes, b_bytes);
+      if (rowgemm_one_ok(mb, ek, d)) return launch_rowgemm_one(mb, ek, d, stream, a_bytes, b_bytes);
+    }
+  }
   return launch_h3d_pr3(mb, ek, d, stream, a_bytes, b_bytes);
 }
 

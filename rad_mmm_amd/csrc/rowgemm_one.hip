@@ -11,7 +11,7 @@
 
 namespace {
 
-template <int MB, int EK>
+template <int MB, int EK, int PR = 2>
 __global__ __launch_bounds__(256, 1) void rowgemm_one_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes, const int b_bytes) {
   using G = OneGeo<MB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_one_kernel(const radmmm_rowgem
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;       // E8M0 block scales (rowgemm_h3d, PR 2)
   const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
-  one_tap_steps<MB>(acc, sm, kpt, lane, wave, x_sa, x_sb, dma_a, dma_b);
+  one_tap_steps<MB, PR>(acc, sm, kpt, lane, wave, x_sa, x_sb, dma_a, dma_b);
 
   const radmmm::EpilogueCtx ec(p);
   float sat = 0.f;
@@ -89,18 +89,18 @@ __global__ __launch_bounds__(256, 1) void rowgemm_one_kernel(const radmmm_rowgem
     rowf4[tid] = make_float4(q.acc_scale * pre, post, rsc, 0.f);
   }
   __syncthreads();
-  direct_epilogue<MB, EK, true>(acc, rowf4, p, m0, n0, lane, wave, sat);
+  direct_epilogue<MB, EK, PR == 2>(acc, rowf4, p, m0, n0, lane, wave, sat);
   {
     const int xe = p.Ch ? (p.C2h && p.c2h_x8_exp > p.ch_x8_exp ? p.c2h_x8_exp : p.ch_x8_exp) : p.c2h_x8_exp;
     radmmm::raise_sat_flag(p.sat_flag, sat, ((p.Ch || p.C2h) && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, xe) : 0.f);
   }
 }
 
-template <int MB, int EK>
+template <int MB, int EK, int PR = 2>
 int launch_one(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = OneGeo<MB>;
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_one_kernel<MB, EK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_one_kernel<MB, EK, PR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_one<%d,%d>): %s", MB, EK, hipGetErrorString(e));
@@ -111,7 +111,7 @@ int launch_one(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_one_kernel<MB, EK>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_one_kernel<MB, EK, PR>), dim3(ntm * ntn), dim3(256), G::SMEM, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_one");
 }
 
@@ -133,10 +133,19 @@ bool rowgemm_one_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d) {
 #ifdef RADMMM_QUICK
   if (mb != 7) return false;
 #endif
-  return d.nprod == 2 && mb >= 4 && mb <= 8 && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_RES || ek == EK_DGRAD) && p.taps == 1 &&
+  // (three f16 products, round 5: the C-only launches of the tall tiles -- the FiLM stacks' 1x1 convs and their data
+  //  gradients at configs[4]'s 32 000 rows, the context LSTM's projection -- take the slot-pinned loop as well)
+  const bool scheme_ok = d.nprod == 2 || ((d.nprod == 3 || d.nprod == 0) && (mb == 7 || mb == 8) && ek == EK_PLAIN);
+  return scheme_ok && mb >= 4 && mb <= 8 && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_RES || ek == EK_DGRAD) && p.taps == 1 &&
          !d.extra_tap && (p.K / BK) % 2 == 0 && p.K >= 2 * BK && (!(p.a_mask_mode && p.lens) || (p.T > 0 && p.M % p.T == 0));
 }
 int launch_rowgemm_one(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  if (d.nprod != 2) {                                 // three f16 products: EK_PLAIN, MB 7 / 8 (rowgemm_one_ok)
+#ifndef RADMMM_QUICK
+    if (mb == 8) return launch_one<8, EK_PLAIN, 3>(d, stream, a_bytes, b_bytes);
+#endif
+    return launch_one<7, EK_PLAIN, 3>(d, stream, a_bytes, b_bytes);
+  }
 #ifndef RADMMM_QUICK
   switch (mb) {
     case 4: return launch_one_ek<4>(ek, d, stream, a_bytes, b_bytes);

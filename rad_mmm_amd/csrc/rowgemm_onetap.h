@@ -35,7 +35,10 @@ struct OneGeo {
 
 // DMA pieces of tile `rel` (relative K step) -- the caller's lambdas:  dma_a(k, stage, soff)  k = 0 .. MB-1,
 // dma_b(w, stage, soff)  w = 0 .. 7;  soff = rel * 64 bytes (the K position as the instruction's scalar offset).
-template <int MB, class DmaA, class DmaB>
+// PR = product scheme: 2 (FP8 cross terms; Al / Bl = 8-bit cross arrays) or 3 (three f16 products; Al / Bl = fp16 lo arrays of
+// the same row pitch: the DMA pieces, the swizzle and the fragment reads are identical, only the slot-C MFMAs differ -- the one
+// block-scaled FP8 MFMA of a (row block, column block) becomes Al.Bh + Ah.Bl for both k blocks: four f16 MFMAs)
+template <int MB, int PR = 2, class DmaA, class DmaB>
 __device__ __forceinline__ void one_tap_steps(f32x16 (&acc)[MB][2], unsigned char* sm, const int kpt, const int lane, const int wave,
                                               const int x_sa, const int x_sb, DmaA dma_a, DmaB dma_b) {
   using G = OneGeo<MB>;
@@ -80,6 +83,16 @@ __device__ __forceinline__ void one_tap_steps(f32x16 (&acc)[MB][2], unsigned cha
 #endif
   };
   auto cross = [&](int set, int i, int j) __attribute__((always_inline)) {
+    if constexpr (PR == 3) {
+#if RADMMM_TIMING == 0
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[2 * i + kb], bh[set][kb][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[2 * i + kb], bl[set][kb][j], acc[i][j], 0, 0, 0);
+      }
+#endif
+      return;
+    }
     const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, fal[2 * i]), __builtin_bit_cast(i32x4, fal[2 * i + 1]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),

@@ -71,7 +71,7 @@ __device__ __forceinline__ void pin_items_win() {
 }
 
 // one K step (compile-time tap) -- see the kernel
-template <int MB, int EK, bool XT>
+template <int MB, int EK, bool XT, int PR = 2>
 __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgemm_h3_desc q, const int a_bytes, const int b_bytes) {
   using G = WGeo<MB>;
   constexpr int NT = 2 * MB, D = WLOOK, NPW = G::NPW;
@@ -186,6 +186,16 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;       // E8M0 block scales (rowgemm_h3d, PR 2)
   const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
   auto cross = [&](int set, int i, int j) __attribute__((always_inline)) {
+    if constexpr (PR == 3) {                // three f16 products (rowgemm_onetap.h): Al.Bh + Ah.Bl of both k blocks
+#if RADMMM_TIMING == 0
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[2 * i + kb], bh[set][kb][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[2 * i + kb], bl[set][kb][j], acc[i][j], 0, 0, 0);
+      }
+#endif
+      return;
+    }
     const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, fal[2 * i]), __builtin_bit_cast(i32x4, fal[2 * i + 1]),
                                              0, 1, 2, 3, 4, 5, 6, 7);
     const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, bl[set][0][j]), __builtin_bit_cast(i32x4, bl[set][1][j]),
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       dma16s(x_isl[k] ? rAl : rAh, (lds_u32_ptr)(sm + stage * OG::A_STAGE + x_dst[k]), x_vo[k], soff);
     };
     auto dma_xb = [&](int w, int stage, int soff) __attribute__((always_inline)) { dma_b2(w, stage, WTAPS * b_tap_bytes + soff); };
-    one_tap_steps<MB>(acc, sm, kpt, lane, wave, x_sa, x_sb, dma_xa, dma_xb);
+    one_tap_steps<MB, PR>(acc, sm, kpt, lane, wave, x_sa, x_sb, dma_xa, dma_xb);
   }
 
   const radmmm::EpilogueCtx ec(p);
@@ -350,17 +360,17 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     if (s == 1.2345e-30f) p.C[0] = s;
   }
 #else
-  direct_epilogue<MB, EK, true>(acc, rowf4, p, m0, n0, lane, wave, sat);
+  direct_epilogue<MB, EK, PR == 2>(acc, rowf4, p, m0, n0, lane, wave, sat);
   radmmm::raise_sat_flag(p.sat_flag, sat, (p.Ch && p.split_fmt != RADMMM_SPLIT_F16) ? __builtin_ldexpf(1.f, p.ch_x8_exp) : 0.f);
 #endif
 }
 
-template <int MB, int EK, bool XT>
+template <int MB, int EK, bool XT, int PR = 2>
 int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
   using G = WGeo<MB>;
   constexpr int smem_bytes = XT && OneGeo<MB>::SMEM > G::SMEM ? OneGeo<MB>::SMEM : G::SMEM;     // (the extra segment's A ring)
   static int once = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_win_kernel<MB, EK, XT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_win_kernel<MB, EK, XT, PR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
       radmmm::set_error("hipFuncSetAttribute(rowgemm_win<%d,%d>): %s", MB, EK, hipGetErrorString(e));
@@ -371,12 +381,13 @@ int launch_win(const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes,
   if (once) return once;
   const radmmm_rowgemm_desc& p = d.base;
   const int ntm = (p.M + G::BMR - 1) / G::BMR, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK, XT>), dim3(ntm * ntn), dim3(256), smem_bytes, stream, d, a_bytes, b_bytes);
+  hipLaunchKernelGGL((rowgemm_win_kernel<MB, EK, XT, PR>), dim3(ntm * ntn), dim3(256), smem_bytes, stream, d, a_bytes, b_bytes);
   return radmmm::check_launch("rowgemm_win");
 }
 
 template <int MB>
 int launch_win_ek(int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {
+  if (d.nprod != 2) return launch_win<MB, EK_PLAIN, false, 3>(d, stream, a_bytes, b_bytes);   // (rowgemm_win_ok: this kind only)
   if (d.extra_tap) return launch_win<MB, EK_DGRAD, true>(d, stream, a_bytes, b_bytes);      // (rowgemm_win_ok: this kind only)
   switch (ek) {
     case EK_SPLIT: return launch_win<MB, EK_SPLIT, false>(d, stream, a_bytes, b_bytes);
@@ -394,7 +405,9 @@ bool rowgemm_win_ok(int mb, int ek, const radmmm_rowgemm_h3_desc& d) {
 #ifdef RADMMM_QUICK
   if (mb != 7) return false;
 #endif
-  return d.nprod == 2 && (mb == 7 || mb == 8) && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_DGRAD) && p.taps == WTAPS &&
+  // (three f16 products, round 5: C-only launches without the extra segment -- the FiLM stacks' 5-tap hidden convs)
+  const bool scheme_ok = d.nprod == 2 || ((d.nprod == 3 || d.nprod == 0) && ek == EK_PLAIN && !d.extra_tap);
+  return scheme_ok && (mb == 7 || mb == 8) && (ek == EK_PLAIN || ek == EK_SPLIT || ek == EK_DGRAD) && p.taps == WTAPS &&
          (!d.extra_tap || (ek == EK_DGRAD && !p.a_mask_mode)) && (p.K / BK) % 2 == 0 && p.dil >= 1 && p.dil <= WDMAX && p.T >= 32 * mb && p.M % p.T == 0 && (p.sign == 1 || p.sign == -1);
 }
 int launch_rowgemm_win(int mb, int ek, const radmmm_rowgemm_h3_desc& d, hipStream_t stream, int a_bytes, int b_bytes) {

@@ -1639,13 +1639,17 @@ class ConvNormH3Fn(torch.autograd.Function):
         Cout, Cin, taps = v.shape
         N = B * T
         assert x.shape[0] == N and x.shape[1] >= Cin and x.is_contiguous()
-        xh, xl = split_f16(x, Cin, 1.0, Cin, NPR, X8_ACT_EXP, flag)
-        Wh, Wl, inv = split_weight(v, g, Cin, nprod=NPR)
+        # K extent of the forward GEMM: a 1x1 conv whose input width is an odd multiple of 32 (the FiLM blocks' cond conv:
+        # 1056 = 33 x 32) gets one zero K step more, so that it qualifies for the one-tap kernel, which walks K in pairs of
+        # steps (split_f16 / split_weight zero-fill the pad columns; +3 % work for the faster loop)
+        Kx = round_up(Cin, 64) if (taps == 1 and Cin % 64) else Cin
+        xh, xl = split_f16(x, Cin, 1.0, Kx, NPR, X8_ACT_EXP, flag)
+        Wh, Wl, inv = split_weight(v, g, Kx, nprod=NPR)
         ldy = round_up(Cout, 4)
         y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
-        rowgemm_h3(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, Ah=xh, Al=xl, lda_h=Cin, Bh=Wh, Bl=Wl, ldb_h=Cin,
+        rowgemm_h3(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, Ah=xh, Al=xl, lda_h=Kx, Bh=Wh, Bl=Wl, ldb_h=Kx,
                    b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
-                   C=y, ldc=ldy, M=N, N=Cout, K=Cin, taps=taps, dil=dil, sign=1, T=T, lens=lens,
+                   C=y, ldc=ldy, M=N, N=Cout, K=Kx, taps=taps, dil=dil, sign=1, T=T, lens=lens,
                    a_mask_mode=1 if partial else 0, bias=bias, pconv=1 if partial else 0, ratio_taps=taps, ratio_dil=dil,
                    postmask=1 if mask_out else 0, act=act)
         ctx.meta = meta

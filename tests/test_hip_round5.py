@@ -266,3 +266,48 @@ def test_forward_epilogue_without_an_fp32_copy_writes_the_same_pair(taps, monkey
     assert torch.equal(out[True][1].view(torch.int16), out[False][1].view(torch.int16))
     with pytest.raises(RadmmmError, match="C may be NULL only"):
         rowgemm_h3(C=None, **{k: v for k, v in base.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps,K,N,mb", [(1, 1088, 512, 8), (1, 512, 1024, 7), (5, 512, 512, 8), (5, 512, 512, 7)])
+def test_three_product_launches_on_the_slot_pinned_kernels(taps, K, N, mb, monkeypatch):
+    """Round 5: the C-only launches of the three-f16-product scheme (FiLM convs of the spline flows, the context LSTM's
+    projection) take rowgemm_one / rowgemm_win with the slot-C MFMA replaced by Al.Bh + Ah.Bl (four f16 MFMAs).  Same operands,
+    same products, another fp32 summation order than rowgemm_h3d<*, 3>: equal to 1e-6 of the result's maximum, and both within
+    3e-6 of a float64 reference.  Ragged batch, masked input rows, partial-conv ratio, bias, leaky ReLU."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    B, T, lens_l = 3, 300, [300, 251, 170]
+    M = B * T
+    gen = torch.Generator().manual_seed(taps * 100 + K)
+    x = (torch.randn(M, K, generator=gen)).to(DEV)
+    w = (torch.randn(N, K, taps, generator=gen) * 0.03).to(DEV)
+    bias = (torch.randn(N, generator=gen) * 0.1).to(DEV)
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=DEV)
+    xh, xl = ops.split_f16(x, K, 1.0, K, 3)
+    Wh, Wl, _ = ops.split_weight(w, None, K, nprod=3)
+    monkeypatch.setenv("RADMMM_H3W_MB", str(mb))
+    dil = 2 if taps > 1 else 1
+    base = dict(nprod=3, acc_scale=1.0 / ops.W_SCALE, T=T, Ah=xh, Al=xl, lda_h=K, Bh=Wh, Bl=Wl, ldb_h=K, b_tap_stride_h=Wh.stride(0),
+                ldc=N, M=M, N=N, K=K, taps=taps, dil=dil, sign=1, lens=lens, a_mask_mode=1, bias=bias, pconv=1 if taps > 1 else 0,
+                ratio_taps=taps, ratio_dil=dil, postmask=1, act=3)
+    outs = {}
+    for slot in ("0", "1"):
+        monkeypatch.setenv("RADMMM_SLOT3", slot)
+        C = torch.full((M, N), float("nan"), device=DEV)
+        rowgemm_h3(C=C, **base)
+        torch.cuda.synchronize()
+        outs[slot] = C.cpu()
+    scale = float(outs["0"].abs().max())
+    assert torch.isfinite(outs["1"]).all() and float((outs["1"] - outs["0"]).abs().max()) <= 1e-6 * scale
+    # float64 reference of the same conv (masked rows, partial-conv ratio, bias, leaky ReLU)
+    xd = x.double().cpu().view(B, T, K).permute(0, 2, 1)
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens_l)[:, None])[:, None].double()
+    wd = w.double().cpu()
+    pad = dil * (taps - 1) // 2
+    raw = torch.nn.functional.conv1d(xd * mask, wd, None, padding=pad, dilation=dil)
+    cnt = torch.nn.functional.conv1d(mask, torch.ones(1, 1, taps, dtype=torch.float64), padding=pad, dilation=dil)
+    ratio = taps / (cnt + 1e-6) * cnt.clamp(0, 1) if taps > 1 else torch.ones_like(cnt)
+    ref = torch.nn.functional.leaky_relu((raw * ratio + bias.double().cpu()[None, :, None]) * mask)
+    ref = ref.permute(0, 2, 1).reshape(M, N)
+    assert float((outs["1"].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
