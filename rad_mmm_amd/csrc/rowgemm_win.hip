@@ -183,6 +183,28 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     bl[set][kb][j] = *reinterpret_cast<const f16x8*>(sm + stage * G::B_STAGE + G::B_BYTES + j * 32 * ROWB + fo);
 #endif
   };
+#ifdef RADMMM_B_GLOBAL
+  // EXPERIMENT (round 5, -DRADMMM_B_GLOBAL; MEASURED AND REJECTED, profiles/r05_nprod1_floor.txt): the wave-private B fragments
+  // straight from global memory into registers -- no LDS-DMA pieces and no ds_reads for B: 32 KB of LDS writes and 32 KB of LDS
+  // reads per CU and K step less on a port that is 81 % busy.  Bit-identical (38 shared-window cases, the step's loss), but the
+  // launch gets SLOWER: 5-tap forward 255 -> 282 us, fused data gradient 316 -> 353 us, step 41.9 -> 43.5 ms -- a fragment load
+  // touches 32 weight rows with 32 bytes each (half cache lines through the texture path), which costs more than the LDS port
+  // it relieves; the LDS-DMA path moves the same bytes as 16 rows x 64 bytes per instruction.  Lane
+  // (n = lane & 31, half) of column block j wants the 16 bytes of weight row n0 + 64 wave + 2 n + j (the interleaved order of
+  // the direct epilogue) at k block kb: chunk 2 kb + half of the 64-byte K step.
+  int gb_vo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wave * 64 + 2 * (lane & 31) + j;
+    gb_vo[j] = n < p.N ? (n * q.ldb_h + half * 8) * 2 : OOB;
+  }
+  auto load_b_piece = [&](int w, int set, int soff) __attribute__((always_inline)) {      // w = 4 arr + 2 kb + j
+    const int arr = w >> 2, kb = (w >> 1) & 1, j = w & 1;
+    const f16x8 v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(arr ? rBl : rBh, gb_vo[j] + kb * 32, soff, 0));
+    if (arr) bl[set][kb][j] = v;
+    else bh[set][kb][j] = v;
+  };
+#endif
   const int x_sa = (lane >> 5) ? 127 - 11 - q.a8_exp : 127 - q.a8_exp;       // E8M0 block scales (rowgemm_h3d, PR 2)
   const int x_sb = (lane >> 5) ? 127 - q.b8_exp : 127 - 11 - q.b8_exp;
   auto cross = [&](int set, int i, int j) __attribute__((always_inline)) {
@@ -237,6 +259,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   //   The look-ahead crosses the step boundary: items 12 / 13 read items 0 / 1 of the NEXT step (next tap's row shift).
 #pragma unroll
   for (int k = 0; k < NPW; ++k) dma_win2(k, 0, 0);
+#ifdef RADMMM_B_GLOBAL
+#pragma unroll
+  for (int w = 0; w < 8; ++w) load_b_piece(w, 0, 0);
+  __syncthreads();
+#else
 #pragma unroll
   for (int w = 0; w < 8; ++w) dma_b2(w, 0, 0);
 #pragma unroll
@@ -246,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
     for (int j = 0; j < 2; ++j) read_b1(0, 0, kb, j);
+#endif
 #pragma unroll
   for (int t = 0; t < D; ++t) {
     read_hi(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -259,6 +287,8 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     constexpr int ntap = tap == WTAPS - 1 ? 0 : tap + 1, npar = tap == WTAPS - 1 ? (par ^ 1) : par;   // tile of step + 1
     constexpr int tap2 = (tap + 2) % WTAPS;                           // tile of step + 2
     const int soff2 = tap2 * b_tap_bytes + (kb + (tap + 2) / WTAPS) * (BK * 2);
+    const int soff1 = ntap * b_tap_bytes + (kb + (tap + 1) / WTAPS) * (BK * 2);        // tile of step + 1 (RADMMM_B_GLOBAL)
+    (void)soff1;
     using TapC = std::integral_constant<int, tap>;
     using ParC = std::integral_constant<int, par>;
     using NTapC = std::integral_constant<int, ntap>;
@@ -278,21 +308,31 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
       acc[i][0] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][0], acc[i][0]);
       if (t + D < NT) read_hi(t + D, TapC{}, ParC{});
       else read_hi(t + D - NT, NTapC{}, NParC{});
+#ifndef RADMMM_B_GLOBAL
       if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // slot B
       acc[i][1] = RADMMM_MFMA_F16(fah[t], bh[set][kbk][1], acc[i][1]);
       if (t + D < NT) read_lo(t + D, TapC{}, ParC{});
       else read_lo(t + D - NT, NTapC{}, NParC{});
+#ifndef RADMMM_B_GLOBAL
       if (t >= TW) read_b1(set ^ 1, set ^ 1, t - TW, 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // slot C (items 1 .. 13; the 14th follows the loop)
       if (t > 0) {
         if (kbk == 1) cross(set, i, 0);
         else cross(set, i - 1, 1);
         const int c = t - 1;
+#ifdef RADMMM_B_GLOBAL
+        // B(s + 1) first (into the register set this step does not use: a whole step of flight time), the window pieces behind
+        if (c < 8) load_b_piece(c, set ^ 1, soff1);
+        else if (c - 8 < NW) dma_win2(G::WPT * tap + (c - 8), par ^ 1, kb + 1);
+#else
         if (c < NW) dma_win2(G::WPT * tap + c, par ^ 1, kb + 1);
         else if (c - NW < 8) dma_b2(c - NW, set, soff2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
