@@ -125,6 +125,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
     const int lr = 16 * j + d_row;                                    // LDS row 0 .. 255, interleaved as in rowgemm_h3d
     const int n = n0 + (lr & ~63) + 2 * (lr & 31) + ((lr >> 5) & 1);
     b_voff[k] = n < p.N ? (n * q.ldb_h + d_chunk * 8) * 2 : OOB;
+#ifdef RADMMM_TIMING_BOOB      // timing only (wrong results): 1 = every second B piece, 2 = every B piece is an out-of-range
+    if (RADMMM_TIMING_BOOB == 2 || (k & 1)) b_voff[k] = OOB;   // DMA -- zeros written to LDS, nothing fetched from L2
+#endif
     b_dst[k] = j * 1024;
   }
   const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.Ah), 0, a_bytes, 0x00020000);

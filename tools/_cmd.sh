@@ -1,13 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export RADMMM_DEBUG=1
-L=$PWD/rad_mmm_amd/libradmmm_hip_bglobal.so
-(RADMMM_LIB_PATH=$L timeout 900 python -m pytest tests/test_hip_round3.py -m gpu -q -k "shared_window" 2>&1 | tail -4)
-for v in "" _bglobal; do
-RADMMM_LIB_PATH=$PWD/rad_mmm_amd/libradmmm_hip$v.so python tools/floor_probe.py --tag "lib${v:-_product}" --only "5-tap fwd, SPLIT epilogue, pair only" 2>&1 | grep '^{'
-RADMMM_LIB_PATH=$PWD/rad_mmm_amd/libradmmm_hip$v.so python tools/floor_probe.py --tag "lib${v:-_product}" --only "fused dgrad, dact from the split pair, pair only" 2>&1 | grep '^{'
-done
-for i in 1 2; do
-(timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
-(RADMMM_LIB_PATH=$L timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
-done
+timeout 400 python tools/aten_ops_probe.py radmmm_splines 2000 2>&1 | tail -60 > gpurun_out/aten_c5.txt
+timeout 300 python tools/aten_ops_probe.py radtts 800 2>&1 | tail -50 > gpurun_out/aten_c2.txt
+head -50 gpurun_out/aten_c5.txt

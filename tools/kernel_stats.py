@@ -51,12 +51,15 @@ def main():
         ev = db.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
         ev = ev[int(len(ev) * 0.4):]                                  # the timed steps at the end of the run
         span = ev[-1][1] - ev[0][0]
-        busy, idle, cur_end, big, prev_name = 0, [], ev[0][0], [], ""
+        busy, idle, cur_end, big, prev_name, pairs = 0, [], ev[0][0], [], "", {}
         for s0, e0, name in ev:
             if s0 > cur_end:
                 idle.append(s0 - cur_end)
                 if s0 - cur_end > 1e5:
                     big.append((s0 - cur_end, prev_name, name))
+                if s0 - cur_end > 5e3:
+                    k = (prev_name, name)
+                    pairs[k] = (pairs.get(k, (0, 0))[0] + 1, pairs.get(k, (0, 0))[1] + s0 - cur_end)
             busy += max(0, e0 - max(s0, cur_end))
             if e0 >= cur_end:
                 prev_name = name
@@ -69,6 +72,9 @@ def main():
         short = lambda n: n.replace("_ZN12_GLOBAL__N_1", "").replace("_ZN2at6native", "at:")[:48]
         for g, a, b in sorted(big, reverse=True)[:40]:
             print(f"    {g / 1e3:8.0f} us   after {short(a):48s} before {short(b)}")
+        print("  gaps > 5 us by (kernel before, kernel after), largest totals:")
+        for (a, b), (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:30]:
+            print(f"    {n:5d} x  total {t / 1e6:7.3f} ms   after {short(a):48s} before {short(b)}")
     if hist:
         durs = [r[0] / 1e3 for r in db.execute(
             f"select d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id where s.kernel_name like ?",

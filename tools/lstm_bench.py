@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=524)
     ap.add_argument("--inp", type=int, default=1040)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--modes", default="1,1p,0", help="comma list of 1 (single launch), 1p (+ probe loads), 0 (launch per step)")
     args = ap.parse_args()
     os.environ["RADMMM_DEBUG"] = "1"
     from rad_mmm_amd.lstm import bilstm
@@ -32,7 +33,8 @@ def main():
     lens = torch.tensor(sorted([int(T * (0.6 + 0.4 * i / max(1, B - 1))) for i in range(B)], reverse=True), dtype=torch.int32, device=dev)
     gy = (torch.randn(B, T, 2 * H, generator=g) * 1e-3).to(dev)
     outs = {}
-    for mode in ("1", "1p", "0"):
+    modes = args.modes.split(",")
+    for mode in modes:
         os.environ["RADMMM_LSTM_PERSISTENT"] = mode[0]
         os.environ["RADMMM_LSTM_PROBE"] = "3" if mode.endswith("p") else "0"
         for _ in range(2):
@@ -55,6 +57,8 @@ def main():
         outs[mode] = (y.detach().clone(), x.grad.clone(), lstm.weight_hh_l0.grad.clone())
         print(f"RADMMM_LSTM_PERSISTENT={mode[0]} PROBE={os.environ['RADMMM_LSTM_PROBE']}: forward {tf / args.iters:.3f} ms, backward {tb / args.iters:.3f} ms "
               f"(B={B} T'={T} I={I} H={H}; includes the input projection and the gradient GEMMs)")
+    if "1" not in outs or "0" not in outs:
+        return
     a, b = outs["1"], outs["0"]
     for n, u, v in zip(("y", "dx", "dW_hh"), a, b):
         print(f"  single launch vs per step, {n}: max |diff| / max |ref| = {float((u - v).abs().max() / v.abs().max()):.2e}")
