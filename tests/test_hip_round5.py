@@ -311,3 +311,63 @@ def test_three_product_launches_on_the_slot_pinned_kernels(taps, K, N, mb, monke
     ref = torch.nn.functional.leaky_relu((raw * ratio + bias.double().cpu()[None, :, None]) * mask)
     ref = ref.permute(0, 2, 1).reshape(M, N)
     assert float((outs["1"].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_utterances_are_independent_and_gradients_add_up_beyond_the_bench_size(monkeypatch):
+    """Size-independent properties at 5x the benchmark's rows (B = 32, T = 4000: 64 000 grouped frames, a 2000-step context
+    LSTM; the CPU oracle would need minutes here).  The decoder has no cross-utterance term in its forward pass
+    (decoders.py:168-205: convs, LSTM and couplings act per utterance, padding is masked), so
+      * z of utterances [8k, 8k + 8) in the full batch  ==  z of the same eight utterances run alone (same padded length), and
+      * the NLL is a sum over utterances divided by the batch's element count (loss.py:85-110), so the full batch's parameter
+        gradients are the chunk gradients weighted by n_k / n:   grad = sum_k (n_k / n) grad_k.
+    Both would break on a 32-bit offset overflow, a tile that reads across an utterance boundary, or a mask that depends on
+    the position of an utterance inside the batch."""
+    import radmmm_synth as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", "f8x")
+    B, T, CH = 32, 4000, 8
+    cfg = S.DecoderConfig(**KW)
+    dec = RADMMMFlow(use_accent=True, **KW)
+    dec.load_state_dict(_T(S.procedural_decoder_state(S.decoder_state_shapes(cfg))))
+    dec = dec.to(DEV).train()
+    dec.precision_guard_every = 0
+    crit = RADMMMLoss(sigma=1.0, n_group_size=2)
+    b = {k: v.to(DEV) for k, v in _T(S.synthetic_batch(B, T, cfg, 77, ragged=True)).items()}
+    b["lengths"] = b["lengths"] // 2 * 2          # even lengths: the loss's element count, sum(len) // 2, is then additive over chunks
+
+    def run(sel):
+        dec.zero_grad(set_to_none=True)
+        sl = SequenceLength(b["lengths"][sel])
+        out = dec(b["mel"][sel], b["spk"][sel], b["context"][sel], sl, b["f0"][sel], b["energy"][sel], b["accent"][sel])
+        loss = crit(out, None, sl, 0)["loss_mel"][0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return out["z_mel"].detach().clone(), float(loss.detach()), {n: p.grad.detach().clone() for n, p in dec.named_parameters() if p.grad is not None}
+
+    run(slice(0, B))                                                  # (first pass: the gradient scale settles)
+    z_full, l_full, g_full = run(slice(0, B))
+    assert np.isfinite(l_full) and bool(torch.isfinite(z_full).all())
+    n = (b["lengths"] // 2).double()
+    acc, l_acc, worst_z = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g_full.items()}, 0.0, 0.0
+    for k in range(B // CH):
+        sel = slice(k * CH, (k + 1) * CH)
+        w = float(n[sel].sum() / n.sum())
+        z_k, l_k, g_k = run(sel)
+        worst_z = max(worst_z, float((z_k - z_full[sel]).abs().max()))
+        l_acc += w * l_k
+        for name, g in g_k.items():
+            acc[name] += w * g.double()
+    assert worst_z == 0.0, worst_z                                    # bit-identical rows, wherever the utterance sits in the batch
+    assert abs(l_acc - l_full) <= 2e-6 * abs(l_full), (l_acc, l_full)
+    gmax = max(float(v.norm()) for v in g_full.values())
+    bad = {}
+    for name, g in g_full.items():
+        if float(g.norm()) < 1e-6 * gmax:
+            continue
+        r = float((acc[name] - g.double()).norm() / g.double().norm())
+        if r > 3e-4:                                                  # two HIP runs with different gradient scales: FP8-cross noise only
+            bad[name] = r
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
