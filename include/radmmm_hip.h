@@ -493,6 +493,20 @@ int radmmm_dact_mul_transposed(const float* g, int ldg, const float* saved, int 
 int radmmm_dact_mul_rows(const float* g, int ldg, const float* saved, int lds, int C, int B, int T, int dact,
                          int rowscale, const int32_t* lens, int taps, int dil, float scale, void* yh, void* yl,
                          int ldyh, const radmmm_split_opts* so, float* part, radmmm_stream_t stream);
+/* y_j = g * act'(saved_j), j < n <= 4, in ONE pass over g (the four res/skip layers of a WN all start from the gradient of the
+ * skip sum, common.py:816-835): per item the row-major split pair yh / yl (pitch ldyh, format / exponent / saturation flag from
+ * `so`; ylo16: the optional fp16 lo part beside an 8-bit cross array) and B * ceil(T / 64) rows of column-sum partials (pitch
+ * C) for radmmm_colsum_final(_multi) -- element for element what n calls of radmmm_dact_mul_rows with rowscale 0 write.
+ * All saved tensors share the pitch lds; so->lo16 is ignored (per item). */
+typedef struct radmmm_dact_item {
+  const float* saved;
+  void* yh;
+  void* yl;
+  void* ylo16; /* or NULL */
+  float* part;
+} radmmm_dact_item;
+int radmmm_dact_mul_rows_multi(const float* g, int ldg, const radmmm_dact_item* items, int n, int lds, int C, int B, int T,
+                               int dact, float scale, int ldyh, const radmmm_split_opts* so, radmmm_stream_t stream);
 /* number of workgroup tiles radmmm_wgrad_h3 launches per split (the caller picks `splits` so that
  * tiles * splits fills whole rounds of the CUs: one workgroup per CU) */
 int radmmm_wgrad_h3_tiles(int Mc, int Nc, int taps);

@@ -70,6 +70,11 @@ class CsItem(C.Structure):
     _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nparts", C.c_int), ("cols", C.c_int)]
 
 
+class DactItem(C.Structure):
+    """radmmm_dact_item: one saved tensor of radmmm_dact_mul_rows_multi with its split pair and partial-sum rows"""
+    _fields_ = [("saved", C.c_void_p), ("yh", C.c_void_p), ("yl", C.c_void_p), ("ylo16", C.c_void_p), ("part", C.c_void_p)]
+
+
 class SplitOpts(C.Structure):
     """radmmm_split_opts: format of a split producer's second array (SPLIT_F16 / SPLIT_X8A / SPLIT_X8B), exponent of its
     8-bit parts, optional device saturation flag."""
@@ -181,6 +186,7 @@ def _load() -> C.CDLL:
         "radmmm_colsum_final_multi": [C.POINTER(CsItem), i, p], "radmmm_rowgemm_h3_colsum_rows": [C.POINTER(RowGemmH3Desc)],
         "radmmm_dact_mul_transposed": [p, i, p, i, i, i, i, i, i, i, f, p, p, i, so, p, p, i, p, p],
         "radmmm_dact_mul_rows": [p, i, p, i, i, i, i, i, i, p, i, i, f, p, p, i, so, p, p],
+        "radmmm_dact_mul_rows_multi": [p, i, C.POINTER(DactItem), i, i, i, i, i, i, f, i, so, p],
         "radmmm_lstm_fwd": [p, p, p, p, p, p, p, p, i, i, i, p],
         "radmmm_stream_create_masked": [i, C.POINTER(C.c_void_p)],
         "radmmm_stream_destroy": [p],

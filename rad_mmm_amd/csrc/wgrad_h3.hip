@@ -543,7 +543,98 @@ __global__ __launch_bounds__(256) void dact_transposed_kernel(
   radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
 }
 
+// radmmm_dact_mul_rows_multi: y_j = g * act'(saved_j) for up to four saved tensors in ONE pass over g (round 5: the four
+// res/skip layers of a WN share the gradient of the skip sum, 52 MB that four separate passes read four times).  Per j: the
+// row-major split pair (+ optional fp16 lo part) and one row of column-sum partials per (utterance, 64-frame block), as
+// dact_transposed_kernel writes them with no row scale and no transposed copy -- same arithmetic per element.
+struct DactMulti {
+  const float* saved[4];
+  void* yh[4];
+  void* yl[4];
+  void* lo16[4];
+  float* part[4];
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256) void dact_rows_multi_kernel(const float* __restrict__ g, int ldg, const DactMulti a, int lds,
+                                                              int C, int T, int dact, float scale, int ldyh, int fmt,
+                                                              float x8_mul, int* __restrict__ sat_flag) {
+  __shared__ float red[NJ][16][65];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = c0 + tx * 4;
+  float s[NJ][4], sat = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) s[j][0] = s[j][1] = s[j][2] = s[j][3] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + i * 16 + ty;
+    if (t < T && c < C) {
+      const long long row = (long long)b * T + t;
+      const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + c);
+      float4 sv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sv[j] = *reinterpret_cast<const float4*>(a.saved[j] + row * lds + c);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float4 v;
+        v.x = gv.x * radmmm::dact_from_out(sv[j].x, dact);
+        v.y = gv.y * radmmm::dact_from_out(sv[j].y, dact);
+        v.z = gv.z * radmmm::dact_from_out(sv[j].z, dact);
+        v.w = gv.w * radmmm::dact_from_out(sv[j].w, dact);
+        s[j][0] += v.x; s[j][1] += v.y; s[j][2] += v.z; s[j][3] += v.w;
+        sat = fmaxf(sat, radmmm::store_split4_fmt(a.yh[j], a.yl[j], row * ldyh, c, fmt, x8_mul, scale, v.x, v.y, v.z, v.w, a.lo16[j]));
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    red[j][ty][tx * 4 + 0] = s[j][0]; red[j][ty][tx * 4 + 1] = s[j][1]; red[j][ty][tx * 4 + 2] = s[j][2]; red[j][ty][tx * 4 + 3] = s[j][3];
+  }
+  __syncthreads();
+  {
+    const int j = threadIdx.x >> 6, cl = threadIdx.x & 63;       // 4 x 64 threads: one of the (up to four) sums per 64-thread group
+    if (j < NJ && c0 + cl < C) {
+      float t16 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t16 += red[j][w][cl];
+      a.part[j][((long long)b * gridDim.y + blockIdx.y) * C + c0 + cl] = t16;
+    }
+  }
+  radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
+}
+
 }  // namespace
+
+extern "C" int radmmm_dact_mul_rows_multi(const float* g, int ldg, const radmmm_dact_item* items, int n, int lds, int C, int B,
+                                          int T, int dact, float scale, int ldyh, const radmmm_split_opts* so,
+                                          radmmm_stream_t stream) {
+  RADMMM_REQUIRE(g && items && n >= 1 && n <= 4 && dact, "dact_mul_rows_multi: null pointer / 1 .. 4 items / an activation");
+  RADMMM_REQUIRE(C > 0 && C % 4 == 0 && B > 0 && T > 0 && ldg >= C && ldg % 4 == 0 && lds >= C && lds % 4 == 0,
+                 "dact_mul_rows_multi: bad dims (C, ldg, lds multiples of 4)");
+  const int fmt = so ? so->fmt : RADMMM_SPLIT_F16;
+  RADMMM_REQUIRE(ldyh >= C && ldyh % 4 == 0 && (fmt == RADMMM_SPLIT_F16 || ldyh % 32 == 0),
+                 "dact_mul_rows_multi: row-major split output (ldyh %% 4 == 0; 8-bit formats: %% 32)");
+  RADMMM_REQUIRE(radmmm::aligned16(g), "dact_mul_rows_multi: 16-byte aligned g");
+  DactMulti a{};
+  for (int j = 0; j < n; ++j) {
+    RADMMM_REQUIRE(items[j].saved && items[j].yh && items[j].yl && items[j].part && radmmm::aligned16(items[j].saved),
+                   "dact_mul_rows_multi: item with a null pointer / unaligned saved tensor");
+    a.saved[j] = items[j].saved; a.yh[j] = items[j].yh; a.yl[j] = items[j].yl; a.lo16[j] = items[j].ylo16; a.part[j] = items[j].part;
+  }
+  const dim3 grid((C + 63) / 64, (T + 63) / 64, B);
+  const float x8_mul = ldexpf(1.f, so ? so->x8_exp : 0);
+  int* flag = so ? so->sat_flag : nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (n) {
+    case 1: hipLaunchKernelGGL(dact_rows_multi_kernel<1>, grid, dim3(256), 0, st, g, ldg, a, lds, C, T, dact, scale, ldyh, fmt, x8_mul, flag); break;
+    case 2: hipLaunchKernelGGL(dact_rows_multi_kernel<2>, grid, dim3(256), 0, st, g, ldg, a, lds, C, T, dact, scale, ldyh, fmt, x8_mul, flag); break;
+    case 3: hipLaunchKernelGGL(dact_rows_multi_kernel<3>, grid, dim3(256), 0, st, g, ldg, a, lds, C, T, dact, scale, ldyh, fmt, x8_mul, flag); break;
+    default: hipLaunchKernelGGL(dact_rows_multi_kernel<4>, grid, dim3(256), 0, st, g, ldg, a, lds, C, T, dact, scale, ldyh, fmt, x8_mul, flag); break;
+  }
+  return radmmm::check_launch("dact_mul_rows_multi");
+}
 
 static int launch_transpose(const float* x, int ld, int C, int B, int T, int Tp, int front, const int32_t* lens,
                             int mask_mode, float scale, void* oh, void* ol, void* o1h, void* o1l, int ldk, float* part,

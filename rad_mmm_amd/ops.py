@@ -861,6 +861,24 @@ def dact_mul_transposed(g, saved, C, B, T, act, scale, role, yh, yl, fmt, x8_exp
     return (oh, ol, None, None, Kt), sums
 
 
+def dact_mul_rows_multi(g, saved, C, B, T, act, scale, dst, lo16s, fmt, x8_exp, sat_flag, sum_outs, defer=None):
+    """y_j = g * act'(saved[j]) for up to four saved tensors in ONE pass over g (radmmm_dact_mul_rows_multi): the split pairs
+    dst[j] = (yh, yl) (+ lo16s[j]) and the column sums -> list of sums [C] (final after defer.flush() when deferred)."""
+    n = len(saved)
+    nparts = B * (-(-T // 64))
+    parts = [_empty(nparts, C, like=g) for _ in range(n)]
+    sums = [so if (so is not None and so.numel() == C) else _empty(C, like=g) for so in sum_outs]
+    items = (L.DactItem * n)(*[L.DactItem(ptr(saved[j]), ptr(dst[j][0]), ptr(dst[j][1]), ptr(lo16s[j]), ptr(parts[j])) for j in range(n)])
+    check(lib.radmmm_dact_mul_rows_multi(ptr(g), g.shape[1], items, n, saved[0].shape[1], C, B, T, act, scale, dst[0][0].shape[1],
+                                         split_opts(fmt, x8_exp, sat_flag, None), stream()), "dact_mul_rows_multi")
+    for j in range(n):
+        if defer is not None:
+            defer.add(parts[j], sums[j], nparts, C)
+        else:
+            check(lib.radmmm_colsum_final(ptr(parts[j]), ptr(sums[j]), nparts, C, stream()), "colsum_final")
+    return sums
+
+
 def transpose_split_act(x, C, B, T, lens, mask_mode, scale, role, need_odd=False, colsum=None, sum_out=None):
     """channels-last fp32 [B*T, ld] -> transposed zero-gapped split copy [C, ldk] (+ advanced copy).
     Buffers come from a small zero-initialised pool keyed by role: the pads are never written, the data
@@ -1477,19 +1495,37 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         pair_h = pair_l = None           # [2N, Wc]: g_conv_{j+1} split in the first half, gQ_j goes into the second
         WT_prev = None                   # (WiT stack [kt+1][Wc][Wc] of layer j+1 with its last slot free, kt, dil)
         x_prev = None
+        # Round 5: gQ_j = gOUT * act'(R_j) of ALL res/skip layers in one pass over gOUT (radmmm_dact_mul_rows_multi; gOUT is the
+        # same 52 MB for the four layers).  Their destinations are the second halves of the layer pairs, which are therefore
+        # allocated up front.  RADMMM_DACT_MULTI=0 (RADMMM_DEBUG): one launch per layer as before.
+        multi = bool(use_rm and fuse and 2 <= nl <= 4 and act and debug_env("RADMMM_DACT_MULTI", "1") != "0")
+        pre_pairs, gq_pre = {}, None
+        if multi:
+            for j in range(nl - 1, 0, -1):
+                pre_pairs[j] = _halves(2 * N, Wc, like=z_in)
+            top = _halves(N, Wc, like=z_in)
+            gq_dst = [(pre_pairs[j + 1][0][N:], pre_pairs[j + 1][1][N:]) if j < nl - 1 else top for j in range(nl)]
+            gq_lo = [lo16() for _ in range(nl)]
+            gq_sums = dact_mul_rows_multi(gOUT, [R[j] for j in range(nl)], Wc, B, T, act, SG, gq_dst, gq_lo, fa, GE, flag,
+                                          [grad_out(res_p[3 * j + 2]) for j in range(nl)], defer=batch)
+            gq_pre = (gq_dst, gq_lo, gq_sums)
         for j in range(nl - 1, -1, -1):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
             fused = fuse and pair_h is not None
-            if fused:
-                gQh, gQl = pair_h[N:], pair_l[N:]
+            if gq_pre is not None:
+                (gQh, gQl), gQlo, g_res[3 * j + 2] = gq_pre[0][j], gq_pre[1][j], gq_pre[2][j]
+                gy_t = None
             else:
-                gQh, gQl = _halves(N, Wc, like=z_in)
-            # through softplus of the res/skip branch: gQ = gOUT * act'(R_j), written as the dgrad GEMM's row-major split
-            # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
-            gQlo = lo16()
-            gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
-                                                         GE, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo, defer=batch)
+                if fused:
+                    gQh, gQl = pair_h[N:], pair_l[N:]
+                else:
+                    gQh, gQl = _halves(N, Wc, like=z_in)
+                # through softplus of the res/skip branch: gQ = gOUT * act'(R_j), written as the dgrad GEMM's row-major split
+                # operand, as the weight gradient's transposed split operand and as bias sums in one pass (no fp32 gQ)
+                gQlo = lo16()
+                gy_t, g_res[3 * j + 2] = dact_mul_transposed(gOUT, R[j], Wc, B, T, act, SG, None if use_rm else "gy", gQh, gQl, fa,
+                                                             GE, flag, sum_out=grad_out(res_p[3 * j + 2]), ylo16=gQlo, defer=batch)
             if use_rm:
                 slabs = wg_rm((gQh, gQlo if gQlo is not None else gQl), Hpair[j + 1], Wc, Wc, 1, 1)
             else:
@@ -1499,7 +1535,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
                 slabs = wgrad_h3_slabs(gy_t, x_t, Wc, Wc, Wc, 1, 1, 1.0 / SG, WPR)
             g_res[3 * j], g_res[3 * j + 1] = weightnorm_bwd(res_p[3 * j], res_p[3 * j + 1], inv_r[j], slabs, Wc, poison=poison)
             keep_pair = fuse and j > 0               # g_conv_j's split copy becomes the first half of the next pair
-            nh, nlo = _halves(2 * N if keep_pair else N, Wc, like=z_in)
+            nh, nlo = pre_pairs[j] if (keep_pair and j in pre_pairs) else _halves(2 * N if keep_pair else N, Wc, like=z_in)
             gch, gcl = nh[:N], nlo[:N]
             gclo = lo16()
             cs_here = fuse_cs and (fused or G is None)         # (a launch with an `add` input keeps the separate pass)

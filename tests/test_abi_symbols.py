@@ -76,7 +76,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     import subprocess
     import rad_mmm_amd._lib as L
     pairs = [("radmmm_rowgemm_desc", L.RowGemmDesc), ("radmmm_wgrad_desc", L.WgradDesc),
-             ("radmmm_rowgemm_h3_desc", L.RowGemmH3Desc), ("radmmm_wn_item", L.WnItem), ("radmmm_tp_item", L.TpItem), ("radmmm_cs_item", L.CsItem)]
+             ("radmmm_rowgemm_h3_desc", L.RowGemmH3Desc), ("radmmm_wn_item", L.WnItem), ("radmmm_tp_item", L.TpItem), ("radmmm_cs_item", L.CsItem), ("radmmm_dact_item", L.DactItem)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HDR}"', "int main(void) {"]
     for cname, mirror in pairs:
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -371,3 +371,31 @@ def test_utterances_are_independent_and_gradients_add_up_beyond_the_bench_size(m
         if r > 3e-4:                                                  # two HIP runs with different gradient scales: FP8-cross noise only
             bad[name] = r
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,T,C", [(4, 3, 200, 1024), (2, 2, 77, 64), (3, 1, 64, 128)])
+def test_one_pass_over_the_skip_gradient_writes_what_one_pass_per_layer_wrote(n, B, T, C):
+    """radmmm_dact_mul_rows_multi (the res/skip layers' gQ_j = gOUT * softplus'(R_j) from ONE read of gOUT) against n calls
+    of radmmm_dact_mul_transposed: identical split pairs (hi, 8-bit cross array), column sums equal up to the order of their
+    64-frame partial blocks."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    N = B * T
+    gout = (torch.randn(N, C, generator=g) * 3e-3).to(DEV)
+    saved = [torch.nn.functional.softplus(torch.randn(N, C, generator=g) * 2).to(DEV) for _ in range(n)]
+    flag = torch.zeros(4, dtype=torch.int32, device=DEV)
+    fmt, ge, SG, act = L.SPLIT_X8A, 6, 256.0, L.ACT["softplus"]
+    ref = []
+    for j in range(n):
+        yh, yl = ops._halves(N, C, like=gout)
+        _, s = ops.dact_mul_transposed(gout, saved[j], C, B, T, act, SG, None, yh, yl, fmt, ge, flag)
+        ref.append((yh, yl, s))
+    dst = [ops._halves(N, C, like=gout) for _ in range(n)]
+    sums = ops.dact_mul_rows_multi(gout, saved, C, B, T, act, SG, dst, [None] * n, fmt, ge, flag, [None] * n)
+    torch.cuda.synchronize()
+    for j in range(n):
+        assert torch.equal(dst[j][0].view(torch.int16), ref[j][0].view(torch.int16)), j
+        assert torch.equal(dst[j][1].view(torch.int16), ref[j][1].view(torch.int16)), j
+        assert float((sums[j] - ref[j][2]).abs().max()) <= 2e-6 * float(ref[j][2].abs().max()), j
