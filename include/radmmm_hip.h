@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RADMMM_ABI_VERSION 3
+#define RADMMM_ABI_VERSION 4
 
 typedef void* radmmm_stream_t; /* hipStream_t */
 
@@ -136,6 +136,12 @@ typedef struct {
    * must be NULL then.  With it a producer need not keep an fp32 copy of an activation beside its split pair:
    * radmmm_rowgemm_h3 accepts C == NULL when Ch is given (the split copy alone carries the result). */
   const void* dact_h; const void* dact_x; int lddact_h; int dact_x8_exp;
+  /* optional (ABI 4): the value that goes to C2 / C2h is  ((c2_src[0] + c2_src[1]) + c2_src[2]) + y  instead of C2 + y --
+   * n_c2_src = 1 .. 3 fp32 arrays [M][ldc2] (0: the read-modify-write of C2 as before; c2_accum is ignored otherwise).  The
+   * LAST res/skip layer of a WN adds the earlier layers' outputs itself (same association as the running sum, so the same
+   * bits), and the earlier layers write their own output only: the skip sum is neither read nor written four times.  C2
+   * may then be NULL when C2h is given (only the split copy of the sum is kept). */
+  const float* c2_src[3]; int n_c2_src;
 } radmmm_rowgemm_desc;
 
 int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t stream);

@@ -62,6 +62,7 @@ class RowGemmDesc(C.Structure):
         ("Clo", C.c_void_p),
         ("colsum_out", C.c_void_p), ("colsum_scratch", C.c_void_p),
         ("dact_h", C.c_void_p), ("dact_x", C.c_void_p), ("lddact_h", C.c_int), ("dact_x8_exp", C.c_int),
+        ("c2_src", C.c_void_p * 3), ("n_c2_src", C.c_int),
     ]
 
 
@@ -139,7 +140,7 @@ def _load() -> C.CDLL:
     lib.radmmm_abi_version.restype = C.c_int
     lib.radmmm_gemm_cu_slots.restype = C.c_int
     lib.radmmm_gemm_cu_slots.argtypes = []
-    if lib.radmmm_abi_version() != 3:
+    if lib.radmmm_abi_version() != 4:
         raise ImportError("libradmmm_hip.so ABI version mismatch")
     i, i64, p = C.c_int, C.c_int64, C.c_void_p
     f = C.c_float
@@ -308,6 +309,10 @@ def _h3_desc(kw):
     d.base.ratio_dil = 1
     d.acc_scale = 1.0
     for k, v in kw.items():
+        if k == "c2_src":                               # list of 1 .. 3 fp32 tensors (radmmm_rowgemm_desc.c2_src / n_c2_src)
+            d.base.c2_src = (C.c_void_p * 3)(*[ptr(t) for t in v], *([None] * (3 - len(v))))
+            d.base.n_c2_src = len(v)
+            continue
         if isinstance(v, torch.Tensor):
             v = ptr(v)
         setattr(d if k in _H3_KEYS else d.base, k, v)

@@ -12,7 +12,9 @@ struct EpilogueCtx {
     need_row = p.pconv || p.premask || p.postmask || p.rowscale;
     vec_ok = (p.ldc % 4 == 0) && aligned16(p.C) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) &&
              (!p.dact || p.dact_h || (p.lddact % 4 == 0 && aligned16(p.dact_src))) &&
-             (!p.C2 || (p.ldc2 % 4 == 0 && aligned16(p.C2)));
+             (!p.C2 || (p.ldc2 % 4 == 0 && aligned16(p.C2))) &&
+             (p.n_c2_src <= 0 || (p.ldc2 % 4 == 0 && aligned16(p.c2_src[0]) && aligned16(p.c2_src[p.n_c2_src > 1 ? 1 : 0]) &&
+                                  aligned16(p.c2_src[p.n_c2_src > 2 ? 2 : 0])));
   }
 };
 
@@ -91,7 +93,12 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
       const float4 t4 = *reinterpret_cast<const float4*>(p.dact_src + (long long)row * p.lddact + col);
       dsv[0] = t4.x; dsv[1] = t4.y; dsv[2] = t4.z; dsv[3] = t4.w;
     }
-    if (p.C2 && p.c2_accum) {
+    if (p.n_c2_src > 0) {
+      for (int k = 0; k < p.n_c2_src; ++k) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.c2_src[k] + (long long)row * p.ldc2 + col);
+        c2v[0] += t4.x; c2v[1] += t4.y; c2v[2] += t4.z; c2v[3] += t4.w;
+      }
+    } else if (p.C2 && p.c2_accum) {
       const float4 t4 = *reinterpret_cast<const float4*>(p.C2 + (long long)row * p.ldc2 + col);
       c2v[0] = t4.x; c2v[1] = t4.y; c2v[2] = t4.z; c2v[3] = t4.w;
     }
@@ -101,7 +108,11 @@ __device__ __forceinline__ float epilogue_store4_pre(const radmmm_rowgemm_desc& 
       if (col + e < p.N) {
         if (p.add) addv[e] = p.add[(long long)row * p.ldadd + col + e];
         if (p.dact) dsv[e] = p.dact_h ? dact_src_from_pair(p, row, col + e) : p.dact_src[(long long)row * p.lddact + col + e];
-        if (p.C2 && p.c2_accum) c2v[e] = p.C2[(long long)row * p.ldc2 + col + e];
+        if (p.n_c2_src > 0) {
+          for (int k = 0; k < p.n_c2_src; ++k) c2v[e] += p.c2_src[k][(long long)row * p.ldc2 + col + e];
+        } else if (p.C2 && p.c2_accum) {
+          c2v[e] = p.C2[(long long)row * p.ldc2 + col + e];
+        }
       }
     }
   }

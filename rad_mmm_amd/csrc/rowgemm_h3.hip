@@ -193,13 +193,18 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
                                (reinterpret_cast<uintptr_t>(p.dact_h) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dact_x) & 3) == 0),
                  "rowgemm_h3: dact_h / dact_x: an 8-bit split pair with ld %% 32 == 0");
   RADMMM_REQUIRE(!p.Ch || (p.Cl && p.ldch % 4 == 0 && p.ldch >= ((p.N + 3) & ~3)), "rowgemm_h3: Ch/Cl");
-  RADMMM_REQUIRE(!p.C2h || (p.C2l && p.C2 && p.ldc2h % 4 == 0 && p.ldc2h >= ((p.N + 3) & ~3)), "rowgemm_h3: C2h/C2l");
+  RADMMM_REQUIRE(p.n_c2_src >= 0 && p.n_c2_src <= 3, "rowgemm_h3: n_c2_src must be 0 .. 3");
+  for (int k = 0; k < p.n_c2_src; ++k)
+    RADMMM_REQUIRE(p.c2_src[k] && radmmm::aligned16(p.c2_src[k]), "rowgemm_h3: c2_src[%d] null / not 16-byte aligned", k);
+  RADMMM_REQUIRE(p.n_c2_src == 0 || ((p.C2 || p.C2h) && p.ldc2 % 4 == 0 && p.ldc2 >= p.N),
+                 "rowgemm_h3: c2_src needs C2 or C2h to receive the sum, and the sources' pitch in ldc2");
+  RADMMM_REQUIRE(!p.C2h || (p.C2l && (p.C2 || p.n_c2_src > 0) && p.ldc2h % 4 == 0 && p.ldc2h >= ((p.N + 3) & ~3)), "rowgemm_h3: C2h/C2l");
   RADMMM_REQUIRE(p.split_fmt >= RADMMM_SPLIT_F16 && p.split_fmt <= RADMMM_SPLIT_X8B, "rowgemm_h3: split_fmt");
   RADMMM_REQUIRE(p.split_fmt == RADMMM_SPLIT_F16 || ((!p.Ch || p.ldch % 32 == 0) && (!p.C2h || p.ldc2h % 32 == 0) &&
                                                       abs(p.ch_x8_exp) <= 16 && abs(p.c2h_x8_exp) <= 16),
                  "rowgemm_h3: 8-bit split outputs need ld %% 32 == 0 and |x8_exp| <= 16");
   RADMMM_REQUIRE(d->nprod >= 0 && d->nprod <= 3, "rowgemm_h3: nprod");
-  RADMMM_REQUIRE(!p.colsum_out || (p.colsum_scratch && !p.add && !p.C2), "rowgemm_h3: colsum_out needs colsum_scratch (and no add / C2 input)");
+  RADMMM_REQUIRE(!p.colsum_out || (p.colsum_scratch && !p.add && !p.C2 && !p.n_c2_src), "rowgemm_h3: colsum_out needs colsum_scratch (and no add / C2 input)");
   RADMMM_REQUIRE(d->nprod != 2 || (abs(d->a8_exp) <= 16 && abs(d->b8_exp) <= 16 && d->lda_h % 32 == 0 && d->ldb_h % 32 == 0 &&
                                    d->b_tap_stride_h % 32 == 0),
                  "rowgemm_h3: nprod 2 needs ld %% 32 == 0 and |x8_exp| <= 16");

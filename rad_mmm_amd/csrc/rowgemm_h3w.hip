@@ -116,6 +116,8 @@ static void decide_h3w(const radmmm_rowgemm_h3_desc& d, int* mb_out, int* ek_out
                   (!p.dact_h || d.nprod == 2) &&
                   (!p.dact || (p.dact_h ? fits(p.lddact_h, 2) : (p.lddact % 2 == 0 && a8(p.dact_src) && fits(p.lddact, 4)))) &&
                   (!p.C2 || (p.ldc2 % 2 == 0 && a8(p.C2) && fits(p.ldc2, 4))) &&
+                  (p.n_c2_src <= 0 || (p.ldc2 % 2 == 0 && fits(p.ldc2, 4) && a8(p.c2_src[0]) && a8(p.c2_src[p.n_c2_src > 1 ? 1 : 0]) &&
+                                       a8(p.c2_src[p.n_c2_src > 2 ? 2 : 0]))) &&
                   (!p.Ch || (p.ldch % 2 == 0 && a4(p.Ch) && a4(p.Cl) && a4(p.Clo) && fits(p.ldch, 2))) &&
                   (!p.C2h || (p.ldc2h % 2 == 0 && a4(p.C2h) && a4(p.C2l) && fits(p.ldc2h, 2)));
   // (a direct kernel writes its split copies in its own scheme's format: 8-bit cross arrays under nprod 2, fp16 pairs else)
@@ -124,7 +126,7 @@ static void decide_h3w(const radmmm_rowgemm_h3_desc& d, int* mb_out, int* ek_out
   if (ok && fmt_ok) {
     if (p.dact) {
       if (!p.C2 && p.Ch && !p.C2h && p.act == RADMMM_ACT_NONE) ek = EK_DGRAD;
-    } else if (p.C2) {
+    } else if (p.C2 || p.n_c2_src > 0) {
       if (!p.Ch) ek = EK_RES;
     } else if (!p.C2h) {
       ek = p.Ch ? EK_SPLIT : EK_PLAIN;

@@ -236,7 +236,7 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   const __amdgpu_buffer_rsrc_t rC = rsrc_of(p.C, M * p.ldc * 4);
   const int vC = cok ? (4 * h * p.ldc + col) * 4 : OOB;
   // side input: dact_src (EK_DGRAD) or C2 when accumulating (EK_RES; a null descriptor reads as zeros)
-  const void* side_ptr = DPAIR ? p.dact_h : (DACT ? (const void*)p.dact_src : ((C2M && p.c2_accum) ? (const void*)p.C2 : nullptr));
+  const void* side_ptr = DPAIR ? p.dact_h : (DACT ? (const void*)p.dact_src : ((C2M && p.c2_accum && p.n_c2_src <= 0) ? (const void*)p.C2 : nullptr));
   const int ldside = DPAIR ? p.lddact_h : (DACT ? p.lddact : p.ldc2);
   constexpr int SESZ = DPAIR ? 2 : 4;                            // bytes per element of the side array's rows
   const __amdgpu_buffer_rsrc_t rS = rsrc_of(SIDE ? side_ptr : nullptr, M * ldside * SESZ);
@@ -259,6 +259,19 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
       r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rS, vS, row * ldside * 4, 0));
     }
     return r;
+  };
+  // EK_RES with source arrays (radmmm_rowgemm_desc.c2_src): the side value is ((src0 + src1) + src2), summed when a block's
+  // loads have landed; missing sources are null descriptors (zeros), C2 itself is not read
+  const bool c2src = C2M && p.n_c2_src > 0;
+  const __amdgpu_buffer_rsrc_t rQ0 = rsrc_of(c2src ? p.c2_src[0] : nullptr, M * p.ldc2 * 4);
+  const __amdgpu_buffer_rsrc_t rQ1 = rsrc_of((c2src && p.n_c2_src > 1) ? p.c2_src[1] : nullptr, M * p.ldc2 * 4);
+  const __amdgpu_buffer_rsrc_t rQ2 = rsrc_of((c2src && p.n_c2_src > 2) ? p.c2_src[2] : nullptr, M * p.ldc2 * 4);
+  auto sum_src = [&](const u32x2& q0, const u32x2& q1, const u32x2& q2) __attribute__((always_inline)) {
+    const f32x2 a = __builtin_bit_cast(f32x2, q0), b = __builtin_bit_cast(f32x2, q1), c = __builtin_bit_cast(f32x2, q2);
+    f32x2 r;
+    r[0] = (a[0] + b[0]) + c[0];
+    r[1] = (a[1] + b[1]) + c[1];
+    return __builtin_bit_cast(u32x2, r);
   };
   const __amdgpu_buffer_rsrc_t rC2 = rsrc_of(C2M ? p.C2 : nullptr, M * p.ldc2 * 4);
   const int vC2 = cok ? (4 * h * p.ldc2 + col) * 4 : OOB;
@@ -289,9 +302,20 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     else return radmmm::dact_from_out(y, dact);
   };
   u32x2 side[16], side_n[16];
+  u32x2 q1_n[C2M ? 16 : 1], q2_n[C2M ? 16 : 1];                  // (EK_RES: the second and third source of the next block)
   if constexpr (SIDE) {
+    if (c2src) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) side[e] = load_side(m0 + row_of(e));
+      for (int e = 0; e < 16; ++e) {
+        const int ro = (m0 + row_of(e)) * ldside * 4;
+        side[e] = sum_src(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ0, vS, ro, 0)),
+                          __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ1, vS, ro, 0)),
+                          __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ2, vS, ro, 0)));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) side[e] = load_side(m0 + row_of(e));
+    }
   }
   const int left = (p.M - m0 + 31) / 32;
   const int nblk = left < MB ? left : MB;
@@ -303,8 +327,20 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   for (int I = 0; I < nblk; ++I) {
     const int r0 = m0 + I * 32;
     if constexpr (SIDE) {                                          // next block's side inputs, ahead of this block's stores
+      if (c2src) {
+        if constexpr (C2M) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) side_n[e] = load_side(r0 + 32 + row_of(e));
+          for (int e = 0; e < 16; ++e) {
+            const int ro = (r0 + 32 + row_of(e)) * ldside * 4;
+            side_n[e] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ0, vS, ro, 0));
+            q1_n[e] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ1, vS, ro, 0));
+            q2_n[e] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rQ2, vS, ro, 0));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) side_n[e] = load_side(r0 + 32 + row_of(e));
+      }
     }
     float4 rfs[16];                                                // the block's row factors (LDS), all requested up front
 #pragma unroll
@@ -347,8 +383,15 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
         sat = fmaxf(sat, store_pair_split<X8>(rH, rL, rLo16, has_lo16, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, x0, x1));
     }
     if constexpr (SIDE) {
+      if (c2src) {
+        if constexpr (C2M) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) side[e] = side_n[e];
+          for (int e = 0; e < 16; ++e) side[e] = sum_src(side_n[e], q1_n[e], q2_n[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) side[e] = side_n[e];
+      }
     }
   }
   if (cs_on) {

@@ -1313,7 +1313,10 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         rowgemm_h3(Ah=X0h, Al=X0l, lda_h=Kp, Bh=Wsh, Bl=Wsl, ldb_h=Kp, C=H[0], ldc=Wc, M=N, N=Wc, K=Kp,
                    bias=start_b, Ch=Hh, Cl=Hl, Clo=Hlo, ldch=Wc, ch_scale=1.0, **gin, **gout)
         pairs = [(Hh, Hlo if Hlo is not None else Hl)]
-        OUT = _empty(N, Wc, like=z_in)
+        out_pair = bool(use_rm and (rm8 or NPR == 3) and debug_env("RADMMM_END_WGRAD_RM", "1") != "0")
+        res_src = bool(2 <= nl <= 4 and debug_env("RADMMM_RES_SRC", "1") != "0")
+        # (no fp32 OUT at all when the backward takes OUT's split pair: the last layer's C2 stores are dropped)
+        OUT = None if (res_src and out_pair) else _empty(N, Wc, like=z_in)
         OUTh, OUTl = _halves(N, Wc, like=z_in)
         R = []
         for j in range(nl):
@@ -1331,9 +1334,22 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             pairs.append((Hnh, Hnlo if Hnlo is not None else Hnl))
             Rj = _empty(N, Wc, like=z_in)
             last = j == nl - 1
-            rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc,
-                       K=Wc, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
-                       C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0, **gin, **gout)
+            if res_src:
+                # Round 5: the skip sum is formed ONCE, by the last layer's epilogue, from the earlier layers' outputs
+                # (radmmm_rowgemm_desc.c2_src: ((R0 + R1) + R2) + R3, the running sum's association and bits) -- the earlier
+                # layers write their own output only, and with the end conv's weight gradient on OUT's split pair nobody reads
+                # an fp32 OUT: 208 MB less per flow step than four read-modify-writes of it.
+                if last:
+                    rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc, K=Wc,
+                               bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_src=R, C2h=OUTh, C2l=OUTl, ldc2h=Wc,
+                               c2h_scale=1.0, **gin, **gout)
+                else:
+                    rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc, K=Wc,
+                               bias=res_p[3 * j + 2], act=act, **gin, **gout)
+            else:
+                rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc,
+                           K=Wc, bias=res_p[3 * j + 2], act=act, C2=OUT, ldc2=Wc, c2_accum=1 if j > 0 else 0,
+                           C2h=OUTh if last else None, C2l=OUTl if last else None, ldc2h=Wc, c2h_scale=1.0, **gin, **gout)
             R.append(Rj)
         O = _empty(N, ZLD, like=z_in)
         rowgemm_h3(Ah=OUTh, Al=OUTl, lda_h=Wc, Bh=Weh, Bl=Wel, ldb_h=Wc, C=O, ldc=ZLD, M=N, N=C, K=Wc,
@@ -1353,9 +1369,11 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         rm_saved = [X0h, X0lo if X0lo is not None else X0l, *[t for pr in pairs for t in pr]] if use_rm else []
         # the end conv's weight gradient contracts gO with OUT: with OUT's split pair kept (52 MB per flow step) it runs on
         # the same row-major kernels as every other weight gradient of the step instead of the fp32-MFMA one (50 -> ~25 us)
-        ctx.out_pair = bool(use_rm and (rm8 or NPR == 3) and debug_env("RADMMM_END_WGRAD_RM", "1") != "0")
+        ctx.out_pair = out_pair
         if ctx.out_pair:
             rm_saved += [OUTh, OUTl]
+        if OUT is None:
+            OUT = z1[:0]                              # (placeholder in the saved-tensor layout; never read with out_pair)
         ctx.save_for_backward(z_in, z1, X0, OUT, O, lens, W_eff, start_v, start_g, end_w, Wsh, Wsl, inv_s, Weh, Wel,
                               start_b, end_b,
                               *H, *R, *Wih, *Wil, *inv_i, *Wrh, *Wrl, *inv_r, *rm_saved, *layer_params)

@@ -399,3 +399,93 @@ def test_one_pass_over_the_skip_gradient_writes_what_one_pass_per_layer_wrote(n,
         assert torch.equal(dst[j][0].view(torch.int16), ref[j][0].view(torch.int16)), j
         assert torch.equal(dst[j][1].view(torch.int16), ref[j][1].view(torch.int16)), j
         assert float((sums[j] - ref[j][2]).abs().max()) <= 2e-6 * float(ref[j][2].abs().max()), j
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nsrc", [("one", 3), ("one", 1), ("h3d", 2), ("generic", 3)])
+def test_last_res_skip_layer_forms_the_skip_sum_from_the_earlier_outputs(kind, nsrc, monkeypatch):
+    """radmmm_rowgemm_desc.c2_src (ABI 4): the launch's second output is ((src0 + src1) + src2) + y.  Against the running
+    read-modify-write over the same layers (C2 += y per layer): the fp32 sum, its split pair and the layer's own output are
+    bit-identical; with C2 == NULL the pair alone is written and is still the same.  One-tap slot-pinned kernel, per-tap
+    tiles (MB 4) and the generic LDS-parking epilogue (odd ldc2 alignment is not a case: the flow step's arrays are dense)."""
+    from rad_mmm_amd import ops
+    from rad_mmm_amd._lib import rowgemm_h3
+    monkeypatch.setenv("RADMMM_H3W_MB", "4" if kind == "h3d" else "7")
+    W, B, T = 512, 3, 300
+    N = B * T
+    gen = torch.Generator().manual_seed(5 + nsrc)
+    extra = dict(add=(torch.randn(N, W, generator=gen) * 1e-3).to(DEV), ldadd=W) if kind == "generic" else {}   # (an `add` input: generic epilogue)
+    xs = [torch.nn.functional.softplus(torch.randn(N, W, generator=gen)).to(DEV) for _ in range(nsrc + 1)]
+    ws = [(torch.randn(W, W, 1, generator=gen) * 0.03).to(DEV) for _ in range(nsrc + 1)]
+    bs = [(torch.randn(W, generator=gen) * 0.1).to(DEV) for _ in range(nsrc + 1)]
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def launch(j, **kw):
+        Ah, Al = ops.split_f16(xs[j], W, 1.0, W, 2, ops.X8_ACT_EXP)
+        Wh, Wl, _ = ops.split_weight(ws[j], None, W, nprod=2)
+        rowgemm_h3(nprod=2, a8_exp=ops.X8_ACT_EXP, b8_exp=ops.X8_W_EXP, acc_scale=1.0 / ops.W_SCALE, T=T, sat_flag=flag, Ah=Ah, Al=Al,
+                   lda_h=W, Bh=Wh, Bl=Wl, ldb_h=W, ldc=W, M=N, N=W, K=W, bias=bs[j], act=1, ldc2=W, ldc2h=W, c2h_scale=1.0,
+                   split_fmt=ops.SPLIT_X8A, c2h_x8_exp=ops.X8_ACT_EXP, **extra, **kw)
+    # reference: the running sum
+    OUT = torch.empty(N, W, device=DEV)
+    Rr = [torch.empty(N, W, device=DEV) for _ in range(nsrc + 1)]
+    oh, ol = ops._halves(N, W, like=OUT)
+    for j in range(nsrc + 1):
+        last = j == nsrc
+        launch(j, C=Rr[j], C2=OUT, c2_accum=1 if j else 0, C2h=oh if last else None, C2l=ol if last else None)
+    # sources: the earlier layers write their own output only, the last one adds them up
+    Rs = [torch.empty(N, W, device=DEV) for _ in range(nsrc + 1)]
+    for j in range(nsrc):
+        launch(j, C=Rs[j])
+    OUT2 = torch.full((N, W), float("nan"), device=DEV)
+    ph, pl = ops._halves(N, W, like=OUT)
+    launch(nsrc, C=Rs[nsrc], C2=OUT2, c2_src=Rs[:nsrc], C2h=ph, C2l=pl)
+    qh, ql = ops._halves(N, W, like=OUT)
+    qh.fill_(float("nan"))
+    Rn = torch.empty(N, W, device=DEV)
+    launch(nsrc, C=Rn, C2=None, c2_src=Rs[:nsrc], C2h=qh, C2l=ql)
+    torch.cuda.synchronize()
+    assert torch.isfinite(OUT).all() and float(OUT.abs().max()) > 0
+    for j in range(nsrc + 1):
+        assert torch.equal(_bits(Rs[j]), _bits(Rr[j])), j
+    assert torch.equal(_bits(Rn), _bits(Rr[nsrc]))
+    assert torch.equal(_bits(OUT2), _bits(OUT))
+    for a, b_ in ((ph, oh), (pl, ol), (qh, oh), (ql, ol)):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+
+
+@pytest.mark.gpu
+def test_flow_step_without_an_fp32_skip_sum_is_bit_identical(monkeypatch):
+    """The whole decoder step with the skip sum formed once (default) against four read-modify-writes of an fp32 OUT
+    (RADMMM_RES_SRC=0) and one softplus' pass per res/skip layer (RADMMM_DACT_MULTI=0): identical z, loss and gradients."""
+    import radmmm_synth as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    monkeypatch.setenv("RADMMM_PRECISION", "f8x")
+    monkeypatch.setenv("RADMMM_DEBUG", "1")
+    cfg = S.DecoderConfig(**KW)
+    sd = _T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    b = {k: v.to(DEV) for k, v in _T(S.synthetic_batch(6, 800, cfg, 9, ragged=True)).items()}
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RADMMM_RES_SRC", mode)
+        monkeypatch.setenv("RADMMM_DACT_MULTI", mode)
+        dec = RADMMMFlow(use_accent=True, **KW)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).train()
+        dec.precision_guard_every = 0
+        sl = SequenceLength(b["lengths"])
+        out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+        loss = RADMMMLoss(sigma=1.0, n_group_size=2)(out, None, sl, 0)["loss_mel"][0]
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (out["z_mel"].detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None})
+    assert torch.equal(_bits(res["1"][0]), _bits(res["0"][0])) and torch.equal(_bits(res["1"][1]), _bits(res["0"][1]))
+    # (bias gradients of the res/skip layers: the one-pass kernel adds its 64-frame partial blocks in another order)
+    for n, g in res["1"][2].items():
+        g0 = res["0"][2][n]
+        if "res_skip_layers" in n and n.endswith("bias"):
+            assert float((g - g0).abs().max()) <= 2e-6 * float(g0.abs().max()), n
+        else:
+            assert torch.equal(_bits(g), _bits(g0)), n

@@ -1,9 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export RADMMM_DEBUG=1
-timeout 900 python -m pytest tests/test_hip_round5.py -m gpu -q -x -k "one_pass or repeatable or independent" 2>&1 | tail -8
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x 2>&1 | tail -4
-for i in 1 2; do
-(RADMMM_DACT_MULTI=0 timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
-(timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
-done
+RADMMM_RES_SRC=0 timeout 600 bash tools/prof_step.sh res0 > /dev/null 2>&1
+timeout 600 bash tools/prof_step.sh res1 > /dev/null 2>&1
+for t in res0 res1; do echo "== $t"; grep -E "rowgemm_one_kernel|TOTAL" gpurun_out/${t}_kernel_stats.txt | cut -c1-130; done
