@@ -1,6 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export RADMMM_DEBUG=1
-RADMMM_RES_SRC=0 timeout 600 bash tools/prof_step.sh res0 > /dev/null 2>&1
-timeout 600 bash tools/prof_step.sh res1 > /dev/null 2>&1
-for t in res0 res1; do echo "== $t"; grep -E "rowgemm_one_kernel|TOTAL" gpurun_out/${t}_kernel_stats.txt | cut -c1-130; done
+timeout 1500 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/pytest_gpu.txt 2>&1
+tail -25 gpurun_out/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+tail -c 1500 gpurun_out/bench_default.json
