@@ -254,7 +254,8 @@ def hbm_rooflines(dec, cfg, B, T):
         "weightnorm_fwd_h3": ("weight norm + scale + split of every conv weight, one launch per flow step (fp32 v read, fp16 hi + 8-bit cross written)", wn_elems * 8.0),
         "weightnorm_bwd": ("weight-norm backward over the split-K slabs of the weight gradients", bwd_bytes),
         "transpose_pair_x8": ("transposed copies of the split weights, one launch per flow step for the data-gradient GEMMs", tr_bytes),
-        "dact_transposed_kernel": ("gQ = gOUT * softplus'(R): two fp32 reads, split pair written (4 layers x flows)", N * 1024 * (4 + 4 + 4.0) * 4 * (len(dec.flows) - n_spl)),
+        "dact_rows_multi_kernel": ("gQ_j = gOUT * softplus'(R_j), j < 4, in one pass per flow step: gOUT read once, four fp32 R read, four split pairs written",
+                                   N * 1024 * (4 + 4 * (4 + 4.0)) * (len(dec.flows) - n_spl)),
         "affine_coupling_fwd_kernel": ("affine coupling forward (O, z1 read; z, log s written)", N * (C + C + C + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
         "affine_coupling_bwd_kernel": ("affine coupling backward", N * (C * 5 + C / 2) * 4.0 * (len(dec.flows) - n_spl)),
         "wn_input_fwd4_kernel": ("WN input assembly [context | z half] written as its split pair only (round 5: no fp32 copy)",

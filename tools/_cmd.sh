@@ -1,7 +1,9 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 1500 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/pytest_gpu.txt 2>&1
-tail -25 gpurun_out/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 1500 gpurun_out/bench_default.json
+timeout 600 bash tools/prof_step.sh r05f > /dev/null 2>&1
+timeout 900 bash tools/prof_step.sh r05f_c5 --config radmmm_splines --frames 2000 > /dev/null 2>&1
+PROBE_ARGS="--joint" timeout 900 bash tools/prof_full_step.sh r05f_joint > /dev/null 2>&1
+ls gpurun_out | grep r05f
+head -12 gpurun_out/r05f_kernel_stats.txt | cut -c1-130
+head -8 gpurun_out/r05f_c5_kernel_stats.txt | cut -c1-130
+tail -3 gpurun_out/prof_r05f_c5/bench.log | cut -c1-300
