@@ -25,6 +25,7 @@
 #define RADMMM_EPI_STORE(...) __VA_ARGS__
 #endif
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "rowgemm_epilogue.h"
@@ -141,6 +142,16 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 //   EK_DGRAD    C + split copy, y multiplied by act'(dact_src)   side input: dact_src
 enum { EK_GENERIC = 0, EK_PLAIN, EK_SPLIT, EK_RES, EK_DGRAD, EK_COUNT };
 
+// f(integral_constant<int, I>) for I = First, First + Step, ... < Last: loop indices that are constants INSIDE a lambda (an index
+// that is a run-time parameter until inlining keeps a register array in scratch memory)
+template <int I, int Last, int Step, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < Last) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + Step, Last, Step>(f);
+  }
+}
+
 template <int MB, int I>
 __device__ __forceinline__ void take_block(const f32x16 (&acc)[MB][2], int sel, float (&v)[2][16]) {
   if constexpr (I < MB) {
@@ -164,21 +175,57 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* ptr, long 
 // softplus on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each; radmmm::softplus_f's libm-style
 // __logf costs ~12 instructions more per element): max(x, 0) + log1p(exp(-|x|)), log1p(e) = log(u) * e / (u - 1) with
 // u = fl(1 + e) keeps full relative accuracy for small e.  u is in [1, 2]: no denormal handling needed around the log.
+template <bool SHORTCUT = false>
 __device__ __forceinline__ float softplus_nb(float x) {
   const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(x));
   const float u = 1.f + e;
   const float d = u - 1.f;
   const float l = (0.693147180559945309f * __builtin_amdgcn_logf(u)) * (e * __builtin_amdgcn_rcpf(d));
   const float lp = (d == 0.f) ? e : l;
-  return x > 20.f ? x : fmaxf(x, 0.f) + lp;
+  // (no `x > 20 ? x : ...` shortcut: there e < 2.1e-9 < ulp(x) / 2, so u == 1, lp == e and x + e rounds to x -- the same bits,
+  //  and without the select the compiler emits straight-line code instead of a divergent branch around the transcendentals,
+  //  so that the chains of the 32 elements of a row block interleave: one wave per SIMD has nothing else to hide their latency)
+  //  SHORTCUT = true keeps the select (the one-row-at-a-time epilogues: same bits, fewer live registers).
+  if constexpr (SHORTCUT) return x > 20.f ? x : fmaxf(x, 0.f) + lp;
+  else return fmaxf(x, 0.f) + lp;
 }
-
 // split copy of one column pair (col even) of one row: hi fp16 pair, second array = fp16 lo pair (X8 false) or the 8-bit
 // cross array (X8: format fmt = RADMMM_SPLIT_X8A / X8B through the offsets vXh / vXl), optional fp16 lo pair beside it.
 // v* are per-lane byte offsets (out of range for columns >= N), sH the row's scalar byte offset (all arrays of a split
 // copy have the same row pitch in bytes).  Returns max |scale * x|.
-template <bool X8>
+template <bool X8, bool has_lo16>
 __device__ __forceinline__ float store_pair_split(__amdgpu_buffer_rsrc_t rH, __amdgpu_buffer_rsrc_t rL, __amdgpu_buffer_rsrc_t rLo16,
+                                                  int vH, int vXh, int vXl, int sH, float x8_mul, float s, float y0, float y1) {
+  const float u0 = y0 * s, u1 = y1 * s;
+  const float amax = fmaxf(fabsf(u0), fabsf(u1));
+  const float t0 = radmmm::clamp_f16(u0), t1 = radmmm::clamp_f16(u1);
+  const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+  const float r0 = t0 - (float)h0, r1 = t1 - (float)h1;
+  f16x2 hp;
+  hp[0] = h0; hp[1] = h1;
+  RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hp), rH, vH, sH, 0));
+  if constexpr (!X8) {
+    f16x2 lp;
+    lp[0] = (_Float16)r0; lp[1] = (_Float16)r1;
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rL, vH, sH, 0));
+  } else {
+    const float lm = x8_mul * 2048.f;
+    const int w8h = __builtin_amdgcn_cvt_pk_fp8_f32(radmmm::clamp_e4m3(t0 * x8_mul), radmmm::clamp_e4m3(t1 * x8_mul), 0, false);
+    const int w8l = __builtin_amdgcn_cvt_pk_fp8_f32(radmmm::clamp_e4m3(r0 * lm), radmmm::clamp_e4m3(r1 * lm), 0, false);
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8h, rL, vXh, sH, 0));
+    RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b16((unsigned short)w8l, rL, vXl, sH, 0));
+    if constexpr (has_lo16) {
+      f16x2 lp;
+      lp[0] = (_Float16)r0; lp[1] = (_Float16)r1;
+      RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lp), rLo16, vH, sH, 0));
+    }
+  }
+  return amax;
+}
+
+// the same with the optional fp16 lo part chosen at run time (the one-row-at-a-time epilogues: round 4's code, kept verbatim)
+template <bool X8>
+__device__ __forceinline__ float store_pair_split_rt(__amdgpu_buffer_rsrc_t rH, __amdgpu_buffer_rsrc_t rL, __amdgpu_buffer_rsrc_t rLo16,
                                                   bool has_lo16, int vH, int vXh, int vXl, int sH, float x8_mul, float s, float y0,
                                                   float y1) {
   const float u0 = y0 * s, u1 = y1 * s;
@@ -223,6 +270,10 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   constexpr bool DPAIR = DACT && DACTK_ >= 3;
   constexpr int DACTK = DPAIR ? DACTK_ - 2 : DACTK_;
   constexpr bool SIDE = DACT || C2M;
+  // rows per group of the element loop below: four under the FP8-cross scheme's forward kinds at tile heights <= 224 rows, else
+  // one (round 4's loop, verbatim).  Measured / compiled (tools/spill_report.py): the data-gradient kinds spill 344 registers
+  // with groups of four (+10 % per launch), the 256-row tiles 34-100, the f16-pair kinds 2-3.
+  constexpr int GR = (DACT || MB >= 8 || !X8) ? 1 : 4;
   const int jj = lane & 31, h = lane >> 5;
   const int col = n0 + wave * 64 + 2 * jj;
   const bool cok = col + 1 < p.N;                               // N is even on this path
@@ -294,7 +345,7 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
   auto row_of = [](int e) { return 8 * (e >> 2) + (e & 3); };     // + 4 h: tile row of accumulator element e
   auto actf = [&](float x) __attribute__((always_inline)) {
     if constexpr (ACTK == 0) return x;
-    else if constexpr (ACTK == 1) return softplus_nb(x);
+    else if constexpr (ACTK == 1) return softplus_nb<GR == 1>(x);
     else return radmmm::act_apply(x, act);
   };
   auto dactf = [&](float y) __attribute__((always_inline)) {
@@ -347,40 +398,104 @@ __device__ __forceinline__ void direct_blocks(const f32x16 (&acc)[MB][2], const 
     for (int e = 0; e < 16; ++e) rfs[e] = rowf[I * 32 + row_of(e) + 4 * h];
     float v[2][16];
     take_block<MB, 0>(acc, I, v);
+    // GR = four rows (eight elements) at a time.  Phase 1, the values: STRAIGHT-LINE code (no branch between the elements -- the
+    // activation and its derivative are select-free, the column sums are accumulated with a 0 / 1 factor whether wanted or
+    // not), so that the scheduler interleaves the eight dependent chains (v_exp -> add -> v_log -> v_rcp ...): with one wave
+    // per SIMD nothing else hides a transcendental's latency.  Phase 2, the stores and split conversions of those rows, in
+    // the launch-uniform variant (one scalar branch per group instead of one per element).  GR == 1: round 4's loop.
+    if constexpr (GR == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ru = r0 + row_of(e);                               // uniform part of the row
-      const float4 rf = rfs[e];
-      float x0 = (v[0][e] * rf.x + b0) * rf.y, x1 = (v[1][e] * rf.x + b1) * rf.y;
-      const f32x2 sidef = __builtin_bit_cast(f32x2, side[e]);
-      if constexpr (DPAIR) {
-        const f16x2 hp = __builtin_bit_cast(f16x2, side[e][0]);
-        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)(side[e][1] >> xlo_sh), false);
-        x0 *= dactf(fmaf(lo[0], dp_lsc, (float)hp[0]));
-        x1 *= dactf(fmaf(lo[1], dp_lsc, (float)hp[1]));
-      } else if constexpr (DACT) {
-        x0 *= dactf(sidef[0]);
-        x1 *= dactf(sidef[1]);
+      for (int e = 0; e < 16; ++e) {
+        const int ru = r0 + row_of(e);                               // uniform part of the row
+        const float4 rf = rfs[e];
+        float x0 = (v[0][e] * rf.x + b0) * rf.y, x1 = (v[1][e] * rf.x + b1) * rf.y;
+        const f32x2 sidef = __builtin_bit_cast(f32x2, side[e]);
+        if constexpr (DPAIR) {
+          const f16x2 hp = __builtin_bit_cast(f16x2, side[e][0]);
+          const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)(side[e][1] >> xlo_sh), false);
+          x0 *= dactf(fmaf(lo[0], dp_lsc, (float)hp[0]));
+          x1 *= dactf(fmaf(lo[1], dp_lsc, (float)hp[1]));
+        } else if constexpr (DACT) {
+          x0 *= dactf(sidef[0]);
+          x1 *= dactf(sidef[1]);
+        }
+        if (cs_on) {                                                 // (uniform)
+          const float m = (rf.z != 0.f && ru + 4 * h < p.M) ? 1.f : 0.f;
+          cs0 = fmaf(m, x0, cs0);
+          cs1 = fmaf(m, x1, cs1);
+        }
+        x0 = actf(x0 * rf.z);
+        x1 = actf(x1 * rf.z);
+        f32x2 y;
+        y[0] = x0; y[1] = x1;
+        RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0));
+        if constexpr (C2M) {
+          f32x2 c2;
+          c2[0] = sidef[0] + x0; c2[1] = sidef[1] + x1;              // (side reads as zero when not accumulating)
+          RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0));
+          if (c2split)
+            sat = fmaxf(sat, store_pair_split_rt<X8>(rH, rL, rLo16, false, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, c2[0], c2[1]));
+        }
+        if constexpr (SPLIT)
+          sat = fmaxf(sat, store_pair_split_rt<X8>(rH, rL, rLo16, has_lo16, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, x0, x1));
       }
-      if (cs_on) {                                                 // (uniform)
-        const float m = (rf.z != 0.f && ru + 4 * h < p.M) ? 1.f : 0.f;
-        cs0 = fmaf(m, x0, cs0);
-        cs1 = fmaf(m, x1, cs1);
-      }
-      x0 = actf(x0 * rf.z);
-      x1 = actf(x1 * rf.z);
-      f32x2 y;
-      y[0] = x0; y[1] = x1;
-      RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0));
-      if constexpr (C2M) {
-        f32x2 c2;
-        c2[0] = sidef[0] + x0; c2[1] = sidef[1] + x1;              // (side reads as zero when not accumulating)
-        RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0));
-        if (c2split)
-          sat = fmaxf(sat, store_pair_split<X8>(rH, rL, rLo16, false, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, c2[0], c2[1]));
-      }
-      if constexpr (SPLIT)
-        sat = fmaxf(sat, store_pair_split<X8>(rH, rL, rLo16, has_lo16, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, x0, x1));
+    } else {
+      auto store_rows = [&](auto E0, auto LO16, auto C2S) __attribute__((always_inline)) {
+        constexpr int e0 = decltype(E0)::value;
+#pragma unroll
+        for (int e = e0; e < e0 + GR; ++e) {
+          const int ru = r0 + row_of(e);
+          const float x0 = v[0][e], x1 = v[1][e];
+          f32x2 y;
+          y[0] = x0; y[1] = x1;
+          RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), rC, vC, ru * p.ldc * 4, 0));
+          if constexpr (C2M) {
+            const f32x2 sidef = __builtin_bit_cast(f32x2, side[e]);
+            f32x2 c2;
+            c2[0] = sidef[0] + x0; c2[1] = sidef[1] + x1;            // (side reads as zero when not accumulating)
+            RADMMM_EPI_STORE(__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c2), rC2, vC2, ru * p.ldc2 * 4, 0));
+            if constexpr (decltype(C2S)::value)
+              sat = fmaxf(sat, store_pair_split<X8, false>(rH, rL, rLo16, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, c2[0], c2[1]));
+          }
+          if constexpr (SPLIT)
+            sat = fmaxf(sat, store_pair_split<X8, decltype(LO16)::value>(rH, rL, rLo16, vH, vXh, vXl, ru * ldh * 2, x8_mul, sp_scale, x0, x1));
+        }
+      };
+      static_for<0, 16, GR>([&](auto E0) __attribute__((always_inline)) {
+        constexpr int e0 = decltype(E0)::value;
+#pragma unroll
+        for (int e = e0; e < e0 + GR; ++e) {
+          const int ru = r0 + row_of(e);                             // uniform part of the row
+          const float4 rf = rfs[e];
+          float x0 = (v[0][e] * rf.x + b0) * rf.y, x1 = (v[1][e] * rf.x + b1) * rf.y;
+          if constexpr (DPAIR) {
+            const f16x2 hp = __builtin_bit_cast(f16x2, side[e][0]);
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)(side[e][1] >> xlo_sh), false);
+            x0 *= dactf(fmaf(lo[0], dp_lsc, (float)hp[0]));
+            x1 *= dactf(fmaf(lo[1], dp_lsc, (float)hp[1]));
+          } else if constexpr (DACT) {
+            const f32x2 sidef = __builtin_bit_cast(f32x2, side[e]);
+            x0 *= dactf(sidef[0]);
+            x1 *= dactf(sidef[1]);
+          }
+          {
+            const float m = (cs_on && rf.z != 0.f && ru + 4 * h < p.M) ? 1.f : 0.f;
+            cs0 = fmaf(m, x0, cs0);
+            cs1 = fmaf(m, x1, cs1);
+          }
+          v[0][e] = actf(x0 * rf.z);
+          v[1][e] = actf(x1 * rf.z);
+        }
+        if constexpr (C2M) {
+          if (c2split) store_rows(E0, std::false_type{}, std::true_type{});
+          else store_rows(E0, std::false_type{}, std::false_type{});
+        } else if constexpr (SPLIT && X8) {
+          if (has_lo16) store_rows(E0, std::true_type{}, std::false_type{});
+          else store_rows(E0, std::false_type{}, std::false_type{});
+        } else {
+          store_rows(E0, std::false_type{}, std::false_type{});
+        }
+      });
     }
     if constexpr (SIDE) {
       if (c2src) {

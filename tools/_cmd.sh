@@ -1,9 +1,16 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 600 bash tools/prof_step.sh r05f > /dev/null 2>&1
-timeout 900 bash tools/prof_step.sh r05f_c5 --config radmmm_splines --frames 2000 > /dev/null 2>&1
-PROBE_ARGS="--joint" timeout 900 bash tools/prof_full_step.sh r05f_joint > /dev/null 2>&1
-ls gpurun_out | grep r05f
-head -12 gpurun_out/r05f_kernel_stats.txt | cut -c1-130
-head -8 gpurun_out/r05f_c5_kernel_stats.txt | cut -c1-130
-tail -3 gpurun_out/prof_r05f_c5/bench.log | cut -c1-300
+export RADMMM_DEBUG=1
+E=$PWD/rad_mmm_amd/libradmmm_hip_epi.so
+(RADMMM_LIB_PATH=$E timeout 1200 python -m pytest tests/test_hip_round3.py tests/test_hip_round4.py tests/test_hip_round5.py -m gpu -q -x -k "not config5" 2>&1 | tail -4)
+for rep in 1 2; do
+for v in "" _epi; do
+for what in "5-tap fwd, SPLIT epilogue, pair only" "fused dgrad, dact from the split pair, pair only" "1x1 res fwd" "1x1 plain"; do
+RADMMM_LIB_PATH=$PWD/rad_mmm_amd/libradmmm_hip$v.so timeout 300 python tools/floor_probe.py --tag "lib${v:-_product}" --only "$what" 2>&1 | grep '^{' | cut -c1-160
+done
+done
+done
+for i in 1 2; do
+(timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
+(RADMMM_LIB_PATH=$E timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
+done
