@@ -1,7 +1,9 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 1500 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/pytest_gpu.txt 2>&1
-tail -3 gpurun_out/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py --full-step > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 600 gpurun_out/bench_default.json
+export RADMMM_DEBUG=1
+E=$PWD/rad_mmm_amd/libradmmm_hip_epi.so
+(RADMMM_LIB_PATH=$E timeout 1200 python -m pytest tests/test_hip_round3.py tests/test_hip_round4.py tests/test_hip_round5.py -m gpu -q -x -k "not config5" 2>&1 | tail -3)
+for i in 1 2 3; do
+(timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
+(RADMMM_LIB_PATH=$E timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1)
+done
