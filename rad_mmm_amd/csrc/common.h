@@ -14,6 +14,7 @@ const char* debug_env(const char* name);
 
 // rowgemm16_f32.hip: 16-row-granular tiling of radmmm_rowgemm_f32 (descriptor already validated)
 int launch_rowgemm16(const radmmm_rowgemm_desc& d, hipStream_t stream);
+int launch_rowgemm_mix(const radmmm_rowgemm_desc& d, hipStream_t stream);   // rowgemm_mix.hip: 0 launched, 1 not its shape
 // wgrad16_f32.hip: fast path of radmmm_wgrad_f32 (0 launched, <0 error, 1 not applicable)
 int launch_wgrad16(const radmmm_wgrad_desc& d, hipStream_t stream);
 

@@ -367,6 +367,12 @@ extern "C" int radmmm_rowgemm_f32(const radmmm_rowgemm_desc* d, radmmm_stream_t 
   RADMMM_REQUIRE(d->sign == 1 || d->sign == -1, "rowgemm: sign must be +-1");
   RADMMM_REQUIRE(!(d->pconv || d->rowscale == 2) || (d->ratio_taps >= 1 && d->ratio_dil >= 1), "rowgemm: ratio_taps/ratio_dil required with pconv/rowscale=2");
   RADMMM_REQUIRE(!d->dact || d->dact_src, "rowgemm: dact needs dact_src");
+  {
+    // the flow steps' 160 x 160 channel mix and its data gradient: the whole weight in LDS, no barrier in the K loop
+    // (rowgemm_mix.hip)
+    const int rc = radmmm::launch_rowgemm_mix(*d, static_cast<hipStream_t>(stream));
+    if (rc <= 0) return rc;
+  }
   static const bool use32 = [] {
     const char* e = radmmm::debug_env("RADMMM_ROWGEMM_TILE");
     return e && atoi(e) == 32;

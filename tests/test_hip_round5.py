@@ -489,3 +489,35 @@ def test_flow_step_without_an_fp32_skip_sum_is_bit_identical(monkeypatch):
             assert float((g - g0).abs().max()) <= 2e-6 * float(g0.abs().max()), n
         else:
             assert torch.equal(_bits(g), _bits(g0)), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,layout,bias,lda,ldc", [(32, 400, 0, True, 160, 160), (32, 400, 1, False, 160, 160), (1, 77, 0, False, 192, 164),
+                                                     (3, 50, 1, True, 160, 176)])
+def test_channel_mix_kernel_matches_the_generic_fp32_gemm_and_float64(B, T, layout, bias, lda, ldc):
+    """rowgemm_mix.hip (the flow steps' 160 x 160 channel mix and its data gradient: weight resident in LDS, 40 k quads without a
+    barrier) behind radmmm_rowgemm_f32: against the generic tiling (forced by an all-zero `add` input, which the mix kernel does
+    not take) -- same ascending k order into one fp32 accumulator per output, so the results agree to the last bit -- and
+    against float64."""
+    from rad_mmm_amd._lib import rowgemm
+    M, NK = B * T, 160
+    g = torch.Generator().manual_seed(B * 1000 + T + layout)
+    A = torch.zeros(M, lda)
+    A[:, :NK] = torch.randn(M, NK, generator=g)
+    W = torch.randn(NK, NK, generator=g) * 0.1
+    bv = torch.randn(NK, generator=g) if bias else None
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    bd = bv.to(DEV) if bias else None
+    out = {}
+    for kind in ("mix", "generic"):
+        C = torch.full((M, ldc), float("nan"), device=DEV)
+        extra = dict(add=torch.zeros(M, ldc, device=DEV), ldadd=ldc) if kind == "generic" else {}
+        rowgemm(A=Ad, lda=lda, B=Wd, ldb=NK, b_layout=layout, C=C, ldc=ldc, M=M, N=NK, K=NK, T=T, bias=bd, **extra)
+        torch.cuda.synchronize()
+        out[kind] = C[:, :NK].cpu()
+        assert torch.isnan(C[:, NK:]).all()                     # nothing written beyond the N columns
+    ref = A[:, :NK].double() @ (W.double().t() if layout == 0 else W.double())
+    if bias:
+        ref = ref + bv.double()
+    assert float((out["mix"].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(out["mix"].view(torch.int32), out["generic"].view(torch.int32))
