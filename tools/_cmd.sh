@@ -1,7 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 600 bash tools/prof_step.sh r05f > /dev/null 2>&1
-timeout 900 bash tools/prof_step.sh r05f_c5 --config radmmm_splines --frames 2000 > /dev/null 2>&1
-PROBE_ARGS="--joint" timeout 900 bash tools/prof_full_step.sh r05f_joint > /dev/null 2>&1
-head -8 gpurun_out/r05f_kernel_stats.txt | cut -c1-130
-grep -a "step_only" gpurun_out/prof_r05f/bench.log gpurun_out/prof_r05f_c5/bench.log | cut -c1-200
+timeout 900 python bench.py --full-step > gpurun_out/bench_d.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_d.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['full_step']['ms_per_step'])
+PY
