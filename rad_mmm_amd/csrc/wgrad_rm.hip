@@ -77,38 +77,6 @@ __device__ __forceinline__ void frag_wait4(Frag& a, Frag& b, Frag& c, Frag& d) {
                : "n"(N) : "memory");
 }
 
-// accumulators of row block I -> LDS -> coalesced float4 rows of P (as wgrad_h3.hip's store_blocks)
-template <int I>
-__device__ __forceinline__ void store_blocks(const f32x16 (&acc)[8][2], float* smf, float* P, int ldp, int Mc, int Nc, float sc,
-                                             int m0, int n0, int tid, int lane, int wave, bool vec_ok) {
-  if constexpr (I < 8) {
-    if (I > 0) radmmm::lds_barrier();
-    float* wbase = smf + (4 * (lane >> 5)) * TN + wave * 64 + (lane & 31);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) wbase[((e & 3) + 8 * (e >> 2)) * TN + j * 32] = acc[I][j][e] * sc;
-    radmmm::lds_barrier();
-    const int c4 = (tid & 63) * 4, col = n0 + c4;
-#pragma unroll 4
-    for (int k = 0; k < 8; ++k) {
-      const int rl = k * 4 + (tid >> 6);
-      const int row = m0 + I * 32 + rl;
-      if (row < Mc && col < Nc) {
-        const float4 a4 = *reinterpret_cast<const float4*>(smf + rl * TN + c4);
-        if (vec_ok && col + 3 < Nc) {
-          *reinterpret_cast<float4*>(P + (long long)row * ldp + col) = a4;
-        } else {
-          const float v[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < Nc) P[(long long)row * ldp + col + e] = v[e];
-        }
-      }
-    }
-    store_blocks<I + 1>(acc, smf, P, ldp, Mc, Nc, sc, m0, n0, tid, lane, wave, vec_ok);
-  }
-}
 
 __global__ __launch_bounds__(256, 1) void wgrad_rm_kernel(const RmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -257,8 +225,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm_kernel(const RmArgs a) {
     }
   }
   float* P = a.P + (long long)split * a.split_stride + (long long)tap * a.Mc * a.ldp;
-  const bool vec_ok = (a.ldp % 4 == 0) && radmmm::aligned16(a.P) && (a.split_stride % 4 == 0);
-  store_blocks<0>(acc, reinterpret_cast<float*>(sm), P, a.ldp, a.Mc, a.Nc, a.acc_scale, m0, n0, tid, lane, wave, vec_ok);
+  // accumulators straight to P, 128 contiguous bytes per half wave and row (wgrad_rm8.hip has the measurement)
+  {
+    const int colb = n0 + wave * 64 + (lane & 31);
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + I * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = colb + j * 32;
+          if (row < a.Mc && col < a.Nc) P[(long long)row * a.ldp + col] = acc[I][j][e] * a.acc_scale;
+        }
+  }
 }
 
 }  // namespace
