@@ -1,5 +1,13 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_round3.py tests/test_hip_round4.py tests/test_hip_round5.py tests/test_hip_lstm.py tests/test_hip_edge.py tests/test_attribute_predictors.py -m gpu -q -x 2>&1 | tail -3
-(timeout 600 python bench.py --steps 20 --warmup 5 --step-only 2>/dev/null | tail -1 | cut -c1-150)
-(timeout 600 python bench.py --config radmmm_splines --frames 2000 --steps 10 --warmup 3 --step-only 2>/dev/null | tail -1 | cut -c1-150)
+timeout 1500 python -m pytest tests -m gpu -q --durations=10 > gpurun_out/pytest_gpu.txt 2>&1
+tail -2 gpurun_out/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py --full-step > gpurun_out/bench_e.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_e.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['full_step']['ms_per_step'])
+PY
+timeout 600 bash tools/prof_step.sh r05g > /dev/null 2>&1
+head -6 gpurun_out/r05g_kernel_stats.txt | cut -c1-130
