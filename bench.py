@@ -209,19 +209,84 @@ def host_threads() -> int:
     return max(1, min(n, 32))
 
 
+def _latest_trace(suffix):
+    """profiles/r0N_<suffix> of the latest round that committed one (the kernel traces quoted by roofline_hbm / roofline_mfma)"""
+    for r in (6, 5):
+        name = f"r0{r}_{suffix}"
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return name
+    return f"r05_{suffix}"
+
+
+def mfma_rooflines(dec, cfg, B, T):
+    """EVERY GEMM class of the headline step against the dense f16 MFMA peak, not only the best one
+    (`roofline` = the 5-tap forward).  Algorithmic flops per step (2 M N K taps per launch) are computed here from
+    the model's shapes; the in-step durations are per-kernel sums over a step and are QUOTED from the committed rocprofv3
+    kernel trace of this very workload (tools/prof_step.sh), labelled static, exactly as `roofline_hbm` does.  Launches that
+    share a kernel name (one template instantiation serving two convs) are one row with the flops of both."""
+    n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
+    if (B, T) != (32, 800) or n_spl or cfg.cond_dims != 1048 or dec.gemm_precision != "f8x":
+        return None
+    trace = _latest_trace("kernel_stats.json")
+    try:
+        with open(os.path.join(ROOT, "profiles", trace)) as f:
+            ks = json.load(f)["kernels"]
+    except Exception:
+        return None
+    M = B * (T // cfg.n_group_size)
+    nf = len(dec.flows)
+    wn = dec.flows[0].coupling_tfn.affine_param_predictor
+    W = wn.n_channels
+    nl = wn.n_layers
+    Kp = (wn.start.weight_v.shape[1] + 31) // 32 * 32
+    C = wn.end.weight.shape[0]
+    g = lambda n, k, taps=1: 2.0 * M * n * k * taps
+    rows = [
+        # (name substring in the trace, what, launches per step, flop per step)
+        ("rowgemm_win_kernelILi7ELi2ELb0", "in_layer forward (5 taps, softplus, split pair) x %d + in_layer 0's data gradient" % nl,
+         nf * (nl + 1), nf * (nl + 1) * g(W, W, 5)),
+        ("rowgemm_win_kernelILi7ELi4ELb1", "fused data gradient: 5 taps of in_layer j+1 + the 1x1 of res_skip j as one launch",
+         nf * (nl - 1), nf * (nl - 1) * (g(W, W, 5) + g(W, W))),
+        ("wgrad_rm8_kernel", "all weight gradients of the WN convs (4 x 5 taps, 4 x 1 tap, start, end per flow step)",
+         nf * (2 * nl + 2), nf * (nl * g(W, W, 5) + nl * g(W, W) + g(W, Kp) + g(C, W))),
+        ("rowgemm_one_kernelILi7ELi1E", "res_skip forward, layers 0..%d (1x1, softplus, fp32 out)" % (nl - 2), nf * (nl - 1), nf * (nl - 1) * g(W, W)),
+        ("rowgemm_one_kernelILi7ELi3E", "res_skip forward, last layer (adds the earlier outputs, writes the skip sum's pair)", nf, nf * g(W, W)),
+        ("rowgemm_one_kernelILi7ELi4E", "res_skip data gradient of the last layer (1x1)", nf, nf * g(W, W)),
+        ("rowgemm_one_kernelILi7ELi2E", "start conv forward (1x1, K = %d, split pair)" % Kp, nf, nf * g(W, Kp)),
+        ("rowgemm_one_kernelILi8ELi1E", "start conv data gradient (1x1, N = %d)" % Kp, nf, nf * g(Kp, W)),
+        ("rowgemm_one_kernelILi4ELi1E", "end conv forward (1x1, N = %d)" % C, nf, nf * g(C, W)),
+    ]
+    out = []
+    for sub, what, launches, flop in rows:
+        hit = [v for k, v in ks.items() if sub in k and v.get("ms_per_step")]
+        ms = sum(v["ms_per_step"] for v in hit)
+        if ms <= 0:
+            continue
+        tf = flop / (ms * 1e-3) / 1e12
+        out.append({"kernel": sub, "what": what, "launches_per_step": launches, "ms_per_step": ms, "flop_per_step": flop,
+                    "achieved": tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F16_MFMA_TFLOPS})
+    one = [r for r in out if r["kernel"].startswith("rowgemm_one")]
+    return {"bound": "mfma", "durations_static": True,
+            "durations_source": f"profiles/{trace} (rocprofv3 --kernel-trace over `bench.py --step-only` of this workload, tools/prof_step.sh)",
+            "note": "algorithmic flops (one fp32-class product per multiply-add) against the dense f16 MFMA peak; the FP8-cross scheme "
+                    "executes two f16-equivalent MFMA passes per product, so the matrix pipe's own utilisation is twice `frac`",
+            "one_tap_family_ms_per_step": sum(r["ms_per_step"] for r in one),
+            "kernels": out}
+
+
 def hbm_rooflines(dec, cfg, B, T):
     """SURVEY 8(d)'s second regime: the HBM-bound kernel classes of the step, each as algorithmic bytes per step / in-step time
     per step against the 8 TB/s peak.  Bytes are computed here from the model's shapes; the in-step durations cannot be taken
     from inside the process (they are per-kernel sums over a step) and are QUOTED from the committed rocprofv3 kernel trace of
-    this very workload, profiles/r05_kernel_stats.json (tools/prof_step.sh), labelled static."""
+    this very workload, profiles/r0N_kernel_stats.json of the latest round (tools/prof_step.sh), labelled static."""
     import math
     # a trace belongs to ONE workload: the default bench line's (RADTTS, B = 32, T = 800) or BASELINE configs[4]'s
     # (`--config radmmm_splines --frames 2000`); any other shape has no committed trace and gets no static figures
     n_spl = sum(1 for f in dec.flows if getattr(f, "use_spline", False))
     if (B, T) == (32, 800) and not n_spl and cfg.cond_dims == 1048:
-        trace = "r05_kernel_stats.json"
+        trace = _latest_trace("kernel_stats.json")
     elif (B, T) == (32, 2000) and n_spl == 2:
-        trace = "r05_c5_kernel_stats.json"
+        trace = _latest_trace("c5_kernel_stats.json")
     else:
         return None
     path = os.path.join(ROOT, "profiles", trace)
@@ -718,11 +783,18 @@ def main():
         from rad_mmm_amd.optim import FlatRAdam
         opt = FlatRAdam(dec.named_parameters(), lr=1e-6, weight_decay=1e-6, reducer=reducer)   # tiny lr: loss stays put
 
+    from rad_mmm_amd.ddp import reduce_loss_dict
+    glob = {"handle": None}                   # the last step's coalesced loss-term reduce
+
     def step():
         reducer.prepare()
         out = dec(gb["mel"], gb["spk"], gb["context"], sl, gb["f0"], gb["energy"], gb["accent"])
         losses = crit(out, None, sl, 0)
         loss = losses["loss_mel"][0]
+        if use_dist:
+            # what the reference's loop does with `self.log(..., sync_dist=True)` per term and step
+            # (tts_lightning_modules.py:746-749), as ONE asynchronous collective behind the forward pass; every rank, every step
+            glob["handle"] = reduce_loss_dict(losses)
         loss.backward()
         reducer.finish()
         if opt is not None:
@@ -759,6 +831,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * B * T * args.steps / dt
     loss_val = float(loss.detach())
+    # the mean over ranks of the last timed step's loss terms (rank 0 alone would print its own utterances' NLL)
+    loss_global = ({k: float(v) for k, v in glob["handle"].wait().items()} if glob["handle"] is not None else None)
     # self-diagnosis of the data-parallel run: the world RCCL really spans (an all-reduce of ones), the time the compute
     # stream waited for all-reduces after backward (exposed communication; per bucket in issue order = last flow first),
     # the slowest rank's figure, and the knobs in force
@@ -917,6 +991,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "precision": prec,
                        "includes_optimizer": bool(args.optimizer)},
             "loss_mel": loss_val,
+            "loss_mel_global": (loss_global or {}).get("loss_mel"),
+            "loss_terms_global": loss_global,
             "distributed": dist_info,
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -1006,6 +1082,7 @@ def main():
         # what the split producers reported over the whole run (ops.GradScale; published without host synchronisation)
         res["saturation"] = sat_report if sat_report is not None else saturation_report()
         res["roofline_hbm"] = hbm_rooflines(dec, cfg, B, T)
+        res["roofline_mfma"] = mfma_rooflines(dec, cfg, B, T)
         if hip_out is not None:
             res["cpu_baseline"], res["parity_vs_cpu"] = cpu_baseline(cfg, sd, batch, hip_out)
     if use_dist:

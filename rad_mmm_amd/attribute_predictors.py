@@ -200,7 +200,10 @@ def dap_forward_many(daps, calls):
     shared = {}                                            # channels-last copy of a context several predictors read: made once
 
     def rows_of(t):
-        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+        # (a tensor and its .detach() share storage, shape and strides but not their place in the autograd graph: the rows are
+        #  shared only between callers that hold the SAME graph node -- ADVICE r5)
+        node = (id(t.grad_fn) if t.grad_fn is not None else id(t)) if t.requires_grad else 0
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), node)
         if key not in shared:
             shared[key] = _rows(t)
         return shared[key]

@@ -173,6 +173,25 @@ __global__ __launch_bounds__(256, 2) void rowgemm_h3_kernel(const radmmm_rowgemm
 
 }  // namespace
 
+// Which kernel a descriptor takes -- ONE decision for the launcher and for radmmm_rowgemm_h3_colsum_rows (the two had
+// drifted apart under the RADMMM_H3_1X1 experiment switch).  Default: the wide-tile kernel (rowgemm_h3w.hip), one workgroup per
+// CU.  A small batch does not give it enough tiles (M = 3200: 100 workgroups of its smallest 128 x 256 tile on 256 CUs): below
+// half a round this file's 128 x 128 kernel, two workgroups per CU, is faster (B = 8, T = 800: 40.0 vs 43.9 ms per step).
+// RADMMM_H3_TILE=128 / 256 forces one or the other (A/B runs; RADMMM_DEBUG=1 only, read per launch then: tests switch it).
+static bool takes_narrow_kernel(const radmmm_rowgemm_h3_desc& d) {
+  const radmmm_rowgemm_desc& p = d.base;
+  const char* forced_env = radmmm::debug_env("RADMMM_H3_TILE");
+  const int forced = forced_env ? atoi(forced_env) : 0;
+  static const bool narrow_1x1 = [] {                 // experiment: short-K launches on the 2-workgroup-per-CU kernel
+    const char* e = radmmm::debug_env("RADMMM_H3_1X1");
+    return e && atoi(e) == 128;
+  }();
+  const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
+  // (the FP8 cross-term scheme exists on the wide kernel only)
+  if (d.nprod == 2 || d.extra_tap) return false;
+  return forced == 128 || (forced != 256 && wide_wgs < 128) || (narrow_1x1 && p.taps == 1);
+}
+
 extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_t stream) {
   RADMMM_REQUIRE(d != nullptr, "rowgemm_h3: null descriptor");
   const radmmm_rowgemm_desc& p = d->base;
@@ -214,20 +233,7 @@ extern "C" int radmmm_rowgemm_h3(const radmmm_rowgemm_h3_desc* d, radmmm_stream_
   const long long a_bytes = ((long long)p.M + (d->extra_tap ? d->extra_a_rows : 0)) * d->lda_h * 2;
   const long long b_bytes = ((long long)(ntaps - 1) * d->b_tap_stride_h + (long long)p.N * d->ldb_h) * 2;
   RADMMM_REQUIRE(a_bytes < 0x7fffffffLL && b_bytes < 0x7fffffffLL, "rowgemm_h3: operand >= 2 GiB");
-  // default: the wide-tile kernel (rowgemm_h3w.hip), one workgroup per CU.  A small batch does not give it enough
-  // tiles (M = 3200: 100 workgroups of its smallest 128 x 256 tile on 256 CUs): below half a round this file's
-  // 128 x 128 kernel, two workgroups per CU, is faster (B = 8, T = 800: 40.0 vs 43.9 ms per step).
-  // RADMMM_H3_TILE=128 / 256 forces one or the other (A/B runs).
-  const char* forced_env = radmmm::debug_env("RADMMM_H3_TILE");   // (RADMMM_DEBUG=1 only; read per launch then: tests switch it)
-  const int forced = forced_env ? atoi(forced_env) : 0;
-  static const bool narrow_1x1 = [] {                 // experiment: short-K launches on the 2-workgroup-per-CU kernel
-    const char* e = radmmm::debug_env("RADMMM_H3_1X1");
-    return e && atoi(e) == 128;
-  }();
-  const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
-  // (the FP8 cross-term scheme exists on the wide kernel only)
-  const bool narrow = d->nprod != 2 && !d->extra_tap && (forced == 128 || (forced != 256 && wide_wgs < 128));
-  if (!narrow && !(narrow_1x1 && p.taps == 1 && d->nprod != 2 && !d->extra_tap))
+  if (!takes_narrow_kernel(*d))
     return radmmm::launch_rowgemm_h3w(*d, static_cast<hipStream_t>(stream), (int)a_bytes, (int)b_bytes);
   static int once = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_h3_kernel),
@@ -256,11 +262,7 @@ extern "C" int radmmm_rowgemm_h3_colsum_rows(const radmmm_rowgemm_h3_desc* d) {
   if (!d) return 0;
   const radmmm_rowgemm_desc& p = d->base;
   if (p.M <= 0 || p.N <= 0 || !p.colsum_scratch) return 0;
-  const char* forced_env = radmmm::debug_env("RADMMM_H3_TILE");
-  const int forced = forced_env ? atoi(forced_env) : 0;
-  const long long wide_wgs = (long long)((p.M + 127) / 128) * ((p.N + 255) / 256);
-  const bool narrow = d->nprod != 2 && !d->extra_tap && (forced == 128 || (forced != 256 && wide_wgs < 128));
-  if (narrow) return 0;
+  if (takes_narrow_kernel(*d)) return 0;
   return radmmm::h3w_colsum_rows(*d);
 }
 

@@ -91,7 +91,11 @@ class BucketedGradReducer:
         self.active = dist.is_initialized()      # reduce even at world size 1 (RCCL smoke test)
         # the mean comes out of the collective itself where the backend has it (RCCL: ReduceOp.AVG); gloo (CPU tests) sums
         # and the buckets are scaled after the wait
-        self._avg = self.active and dist.get_backend(process_group) == "nccl"
+        # (world size 1: the mean IS the sum -- and RCCL runs AVG as a pre-multiplied sum, which at one rank still launches a
+        #  kernel that reads, scales by 1.0 and rewrites every bucket: `oneRankReduce<FuncPreMulSum<float>>`, 17 launches = 876 MB
+        #  each way = 1.31 ms of kernels beside the GEMMs per step, the bulk of the "+1.7 ms of the process-group path at world
+        #  size 1" of VERDICT r5 -- profiles/r06_pg_overhead.txt; an in-place SUM at one rank launches nothing)
+        self._avg = self.active and dist.get_backend(process_group) == "nccl" and self.world > 1
         self.profile = False                     # bench.py: record HIP events around the waits of finish()
         self._prof_events = None
         if direct is None:
@@ -283,3 +287,57 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=
             t.copy_(tmp.bool())
         else:
             dist.broadcast(t.data, src, group=process_group)
+
+
+class LossDictReduce:
+    """Handle of one coalesced mean-reduce of a step's loss terms (reduce_loss_dict).  wait() -> {name: 0-d tensor}: the
+    mean over ranks of every term, on the device the terms live on; the current stream waits for the collective there (no
+    host synchronisation -- the caller's logger decides when to read the numbers)."""
+
+    def __init__(self, names, flat, handle, scale):
+        self._names, self._flat, self._handle, self._scale = names, flat, handle, scale
+
+    def wait(self) -> Dict[str, torch.Tensor]:
+        if self._handle is not None:
+            self._handle.wait()
+            self._handle = None
+            if self._scale != 1.0:
+                self._flat.mul_(self._scale)
+                self._scale = 1.0
+        return {n: self._flat[i] for i, n in enumerate(self._names)}
+
+
+def reduce_loss_dict(losses, process_group=None, async_op: bool = True) -> LossDictReduce:
+    """the reference mean-reduces EVERY loss term across ranks EVERY step for logging --
+    `self.log("train/" + k, v, sync_dist=True, on_step=True)` inside the loop over the loss dict
+    (tts_lightning_modules.py:746-749): one tiny all-reduce per term and step, each a launch + a sync point of its own.
+    Here the terms of a step travel as ONE fp32 vector in ONE collective (RCCL: ReduceOp.AVG; gloo: sum, scaled at wait()),
+    issued asynchronously behind the forward pass -- it rides RCCL's stream while backward runs and is never waited for on
+    the critical path.  `losses`: {name: (value, weight)} (what the criteria return; a value may be a python number, e.g. the
+    binarisation term before kl_loss_start_iter) or {name: value}.  The terms are packed in sorted-name order, so ranks
+    cannot disagree on the layout; every rank must call it with the same set of names (same config, same global_step).
+    Without a process group (or at world size 1) the handle carries the local values and no collective is issued."""
+    names = sorted(losses)
+    vals = []
+    dev = None
+    for n in names:
+        v = losses[n]
+        v = v[0] if isinstance(v, (tuple, list)) else v
+        if isinstance(v, torch.Tensor):
+            dev = v.device if dev is None else dev
+        vals.append(v)
+    if dev is None:
+        dev = torch.device("cpu")
+    flat = torch.stack([v.detach().to(device=dev, dtype=torch.float32).reshape(()) if isinstance(v, torch.Tensor)
+                        else torch.full((), float(v), device=dev, dtype=torch.float32) for v in vals]) if vals else \
+        torch.zeros(0, device=dev)
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1 or not vals:
+        return LossDictReduce(names, flat, None, 1.0)
+    avg = dist.get_backend(process_group) == "nccl"
+    scale = 1.0 if avg else 1.0 / dist.get_world_size(process_group)
+    h = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=process_group, async_op=async_op)
+    if async_op:
+        return LossDictReduce(names, flat, h, scale)
+    if scale != 1.0:
+        flat.mul_(scale)
+    return LossDictReduce(names, flat, None, 1.0)

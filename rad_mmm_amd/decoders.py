@@ -72,7 +72,7 @@ class FlowStep(nn.Module):
         return b
 
     def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
-                   scale_box=None, ctx_acc=None):
+                   scale_box=None, ctx_acc=None, ctx_slot=0):
         conv = self.invtbl_conv
         # (`initialized` is a device buffer: it is read once -- a host synchronisation -- and the answer is remembered FOR THAT
         #  VERSION OF THE BUFFER: any in-place write (`fill_`, `copy_`, load_state_dict, a re-init utility) bumps the tensor's
@@ -95,7 +95,7 @@ class FlowStep(nn.Module):
             n_valid = int(seq_lens.lengths_host.sum())
             z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box)
         else:
-            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box, ctx_acc)
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box, ctx_acc, ctx_slot)
         return z_out, log_det_W, log_s
 
 
@@ -399,8 +399,9 @@ class RADMMMFlow(nn.Module):
         # buffer in place (radmmm_wn_input_bwd's ctx_accum) and only the last one to run hands it to autograd, instead of
         # eight [B T', D] tensors summed by seven stock add launches (ops.AffineFlowStepH3Fn.backward)
         n_aff = sum(1 for f in self.flows if not f.use_spline)
-        ctx_acc = ({"buf": None, "left": n_aff, "total": n_aff}
+        ctx_acc = ({"task": None, "buf": None, "seen": set()}          # (state per backward traversal: ops.ctx_acc_add)
                    if (n_aff > 1 and torch.is_grad_enabled() and self.gemm_precision in ops.NPROD) else None)
+        aff_slot = 0                                                   # ordinal among the affine steps; slot 0 runs last in backward
         for i, flow in enumerate(self.flows):
             off = 0
             if i in self.exit_steps:
@@ -408,7 +409,8 @@ class RADMMMFlow(nn.Module):
                 off = self.n_early_size
             z_in = z
             z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off, self.gemm_precision, scale_box,
-                                                  None if flow.use_spline else ctx_acc)
+                                                  None if flow.use_spline else ctx_acc, aff_slot)
+            aff_slot += 0 if flow.use_spline else 1
             if guard_now and i == len(self.flows) - 1:
                 self._guard_measure(flow, z_in, z, cond2, unfolded, lens32, B, Tg, off)
             log_s_list.append(log_s.view(B, Tg, -1).transpose(1, 2))

@@ -79,15 +79,20 @@ class AttentionBinarizationLoss(nn.Module):
 
     def forward(self, hard_attention, soft_attention):
         on = hard_attention == 1
-        sel = on.to(soft_attention.dtype)
         # positions the alignment does not select never reach the log (their value is replaced by 1 first): an exact 0 there
         # (every padded text column of the masked softmax, an underflowed probability) would otherwise give log's backward
         # 0 / 0 = NaN although its weight `sel` is 0 -- the reference's boolean gather cannot see those elements at all
         # (torch's own BCE on the substituted tensor: its value clamps log at -100 and its gradient is
         #  (x - 1) / max(x (1 - x), 1e-12) -- finite at a SELECTED probability of exactly 0 too, as in the reference's call)
-        ones = torch.ones_like(soft_attention)
-        bce = F.binary_cross_entropy(torch.where(on, soft_attention, ones), ones, reduction="none")
-        return (sel * bce).sum() / sel.sum()
+        # (F.binary_cross_entropy is on autocast's banned list -- "unsafe to autocast", whatever the input dtype -- so under
+        #  Lightning's bf16-mixed the call would raise from the first step past kl_loss_start_iter on: the term runs with
+        #  autocast off on an fp32 copy, like every kernel of this package; tests/test_tts_step.py covers it)
+        with torch.autocast(device_type=soft_attention.device.type, enabled=False):
+            soft = soft_attention.float()
+            sel = on.to(soft.dtype)
+            ones = torch.ones_like(soft)
+            bce = F.binary_cross_entropy(torch.where(on, soft, ones), ones, reduction="none")
+            return (sel * bce).sum() / sel.sum()
 
 
 class AttentionLoss(nn.Module):

@@ -1243,6 +1243,47 @@ def check_saturation(box) -> None:
         box.check()
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """The one side stream per device of the WN forward's pairing (AffineFlowStepH3Fn.forward): res_skip[j] (1x1) runs beside
+    in_layer[j+1] (5 taps); created on first use, never synchronised with the host."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def ctx_acc_add(acc: dict, slot: int, alloc, write):
+    """The affine flow steps' context gradients accumulate in ONE buffer per backward traversal (RADMMMFlow.forward makes
+    `acc`, one per forward pass; `slot` = the step's ordinal among the affine steps).  write(dst, accumulate) launches the
+    step's contribution.  Slot 0 -- the first affine step: its output feeds every later one, so autograd runs it LAST whenever it
+    runs at all -- hands the sum to autograd and clears the state; the other steps return None.
+    The state is keyed on autograd's graph-task id: a traversal that reaches only some steps (`inputs=` pruning,
+    torch.autograd.grad on an early-exit output, an exception half way through) leaves a partial sum behind, and the NEXT
+    traversal -- another id -- starts a fresh buffer instead of adding to the stale one; a pruned traversal that never reaches
+    slot 0 drops a gradient nobody asked for (every path from the context to an input goes through slot 0's node or through a
+    step that returns its own share below).  A step whose slot already contributed in this traversal (a node run twice:
+    cannot happen in one graph task) raises rather than double-count."""
+    task = torch._C._current_graph_task_id()
+    if acc.get("task") != task:
+        acc["task"], acc["buf"], acc["seen"] = task, None, set()
+    if slot in acc["seen"]:
+        raise RuntimeError("context-gradient accumulation: affine flow step %d ran twice in one backward traversal" % slot)
+    first = acc["buf"] is None
+    if first:
+        acc["buf"] = alloc()
+    buf = acc["buf"]
+    write(buf, not first)
+    acc["seen"].add(slot)
+    if slot != 0:
+        return None
+    acc["task"], acc["buf"], acc["seen"] = None, None, set()
+    return buf
+
+
 class AffineFlowStepH3Fn(torch.autograd.Function):
     """Same contract as AffineFlowStepFn; the WN convs run on radmmm_rowgemm_h3 (split operands on the f16 / fp8 matrix
     cores, fp32 accumulate).  meta["nprod"]: 3 = split-f16 (three f16 products), 2 = f16 product + FP8 cross terms
@@ -1319,6 +1360,18 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         OUT = None if (res_src and out_pair) else _empty(N, Wc, like=z_in)
         OUTh, OUTl = _halves(N, Wc, like=z_in)
         R = []
+        # Round 6 (measured before anything was built: tools/pair_overlap_probe.py,
+        # profiles/r06_pair_overlap.txt): res_skip[j] and in_layer[j+1] both read only h_{j+1} (common.py:829-832), so the 1x1
+        # launches of layers 0 .. nl-2 can run on a side stream BESIDE the next 5-tap launch -- what a grouped persistent grid
+        # would do at best, with the hardware's own workgroup dispatcher.  One flow step's forward chain stand-alone: 1241 ->
+        # 1190 us.  In the training step: 40.18 / 40.24 / 40.15 -> 40.13 / 40.16 / 40.16 ms, i.e. NOTHING (the 24 idle CUs and the
+        # exposed 1x1 epilogues are not where the step's time is), so the pairing is OFF and this stays as the A/B switch
+        # RADMMM_RES_STREAM=1 (RADMMM_DEBUG).  Same launches, same values; every tensor the side stream touches is kept alive
+        # by this function until the main stream has joined it in front of the last layer's launch.
+        pair_res = bool(res_src and NPR == 2 and nl >= 2 and z_in.is_cuda and debug_env("RADMMM_RES_STREAM", "0") == "1")
+        main_st = torch.cuda.current_stream(z_in.device) if pair_res else None
+        side_st = side_stream(z_in.device) if pair_res else None
+        side_done: List = []
         for j in range(nl):
             d = 2 ** j
             kt = in_p[3 * j].shape[2]
@@ -1334,6 +1387,23 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
             pairs.append((Hnh, Hnlo if Hnlo is not None else Hnl))
             Rj = _empty(N, Wc, like=z_in)
             last = j == nl - 1
+            if pair_res and not last:
+                # res_skip[j] on the side stream, behind in_layer[j] (it reads h_{j+1} and its own weights only); the main
+                # stream goes on to in_layer[j+1] and meets the side stream again in front of the last layer's launch
+                ev = torch.cuda.Event()
+                ev.record(main_st)
+                with torch.cuda.stream(side_st):
+                    side_st.wait_event(ev)
+                    rowgemm_h3(Ah=Hh, Al=Hl, lda_h=Wc, Bh=Wrh[j], Bl=Wrl[j], ldb_h=Wc, C=Rj, ldc=Wc, M=N, N=Wc, K=Wc,
+                               bias=res_p[3 * j + 2], act=act, **gin, **gout)
+                    done = torch.cuda.Event()
+                    done.record(side_st)
+                side_done.append(done)
+                R.append(Rj)
+                continue
+            if pair_res:                                # (last layer: its epilogue sums the earlier layers' outputs)
+                for done in side_done:
+                    main_st.wait_event(done)
             if res_src:
                 # Round 5: the skip sum is formed ONCE, by the last layer's epilogue, from the earlier layers' outputs
                 # (radmmm_rowgemm_desc.c2_src: ((R0 + R1) + R2) + R3, the running sum's association and bits) -- the earlier
@@ -1647,17 +1717,9 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
         # step reads the same context), in place; the step that runs last returns the buffer, the others return None
         acc = meta.get("ctx_acc")
         if acc is not None and ctx.needs_input_grad[2]:
-            first = acc["buf"] is None
-            if first:
-                acc["buf"] = _empty(N, D, like=z_in)
-            g_cond = acc["buf"]
-            check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0 if first else 1, ptr(gz1), ZLD, N, D, h, stream()),
-                  "wn_input_bwd")
-            acc["left"] -= 1
-            if acc["left"] > 0:
-                g_cond = None
-            else:                                                        # (re-armed: a second backward over a retained graph)
-                acc["buf"], acc["left"] = None, acc["total"]
+            g_cond = ctx_acc_add(acc, meta.get("ctx_slot", 0), lambda: _empty(N, D, like=z_in),
+                                 lambda dst, accum: check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(dst), D, 1 if accum else 0, ptr(gz1),
+                                                                                  ZLD, N, D, h, stream()), "wn_input_bwd"))
         else:
             g_cond = _empty(N, D, like=z_in)
             check(lib.radmmm_wn_input_bwd(ptr(gX0), Kp, ptr(g_cond), D, 0, ptr(gz1), ZLD, N, D, h, stream()), "wn_input_bwd")

@@ -55,6 +55,9 @@ class TTSTrainingStep(nn.Module):
         self.accent_embed_regularization_loss = accent_embed_regularization_loss
         self.speaker_accent_cross_regularization_loss = speaker_accent_cross_regularization_loss
         self.binarize = False                                    # validation uses the flag training last set (:644-646)
+        # mean-reduce the step's loss terms across ranks for logging (Lightning's `sync_dist=True`): outputs["losses_global"]
+        # is a handle whose wait() returns {name: global mean}; a no-op without a process group
+        self.sync_dist = True
 
     # ---- tts_lightning_modules.py:543-545, 246-268 ---------------------------------------------
     @staticmethod
@@ -157,6 +160,11 @@ class TTSTrainingStep(nn.Module):
         loss = None
         for v, w in losses.values():
             loss = v * w if loss is None else loss + v * w
+        if self.sync_dist:
+            # the reference logs every term with sync_dist=True (tts_lightning_modules.py:746-749: a mean all-reduce per term and
+            # step); here: one coalesced collective behind the forward pass, waited for by whoever logs (ddp.reduce_loss_dict)
+            from .ddp import reduce_loss_dict
+            outputs["losses_global"] = reduce_loss_dict(dict(losses, loss=(loss, 1.0)))
         return loss, losses, outputs
 
     def _embedding_regularisers(self, spk_vecs, accent_vecs):

@@ -92,6 +92,24 @@ def _worker(rank, world, port, q):
     from rad_mmm_amd.ops import _all_reduce_or
     fl = torch.tensor([[1, 4], [2, 4 | 128]][rank], dtype=torch.int32)
     ok = ok and _all_reduce_or(fl).tolist() == [3, 132] and fl.tolist() == [[1, 4], [2, 132]][rank]
+    # the step's loss terms mean-reduced across ranks in ONE collective (the reference: one per term,
+    # tts_lightning_modules.py:746-749); python numbers among the values, names packed in sorted order on every rank
+    from rad_mmm_amd.ddp import reduce_loss_dict
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        ld = ({"loss_mel": (torch.tensor(1.0 + rank), 1.0), "loss_ctc": (torch.tensor(0.5 * (rank + 1)), 0.1),
+               "binarization_loss": (0.0, 1.0)} if rank == 0 else
+              {"binarization_loss": (0.0, 1.0), "loss_ctc": (torch.tensor(0.5 * (rank + 1)), 0.1),
+               "loss_mel": (torch.tensor(1.0 + rank), 1.0)})                       # another insertion order on rank 1
+        h = reduce_loss_dict(ld)
+        got = {k: float(v) for k, v in h.wait().items()}
+        got2 = {k: float(v) for k, v in reduce_loss_dict(ld, async_op=False).wait().items()}
+    finally:
+        dist.all_reduce = real
+    want = {"loss_mel": 1.5, "loss_ctc": 0.75, "binarization_loss": 0.0}
+    ok = ok and len(calls) == 2 and got == want and got2 == want and float(ld["loss_mel"][0]) == 1.0 + rank
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -108,6 +126,13 @@ def test_bucketed_reducer_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_loss_dict_reduce_without_a_process_group_is_local():
+    from rad_mmm_amd.ddp import reduce_loss_dict
+    h = reduce_loss_dict({"b": (torch.tensor(2.0), 1.0), "a": 3, "c": torch.tensor([4.0])})
+    assert {k: float(v) for k, v in h.wait().items()} == {"a": 3.0, "b": 2.0, "c": 4.0}
+    assert reduce_loss_dict({}).wait() == {}
 
 
 def test_bucket_key():

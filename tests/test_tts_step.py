@@ -297,6 +297,48 @@ def test_training_step_under_autocast_runs_in_fp32_where_it_matters(monkeypatch)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def test_autocast_step_past_kl_start_has_a_live_binarisation_term(monkeypatch):
+    """the binarisation loss is torch's BCE, which autocast bans on CUDA ("unsafe to autocast").  The autocast test
+    above runs at global_step 0 where the term is the constant 0.0; this one runs with the term LIVE (global_step >
+    kl_loss_start_iter, MAS binarisation on) under bf16 autocast: it must not raise, must equal the fp32 run's term within bf16
+    rounding of the attention, and backward must give finite gradients."""
+    import radmmm_synth as S
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import AttentionBinarizationLoss, RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    import torch.nn.functional as F
+    g = np.load(os.path.join(HERE, "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    dev = "cuda:0"
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10)
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion")]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}, strict=False)
+    model = model.to(dev).train()
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])).to(dev) for k in g.files if k.startswith("batch.")}
+    loss32, losses32, _ = model.training_step(batch, global_step=10)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss16, losses16, out = model.training_step(batch, global_step=10)
+    loss16.backward()
+    b32, b16 = float(losses32["binarization_loss"][0]), float(losses16["binarization_loss"][0])
+    assert b32 > 0 and abs(b32 - float(g["hard.binarization_loss"])) <= 1e-4 * b32       # the term is live and pinned
+    assert abs(b16 - b32) <= 3e-2 * b32, (b16, b32)
+    assert torch.isfinite(loss16) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # the module alone on a bf16 attention (what a caller under autocast may hand over): fp32 arithmetic inside, no raise
+    hard = (torch.rand(2, 1, 12, 7, device=dev) > 0.8).float()
+    soft = torch.rand(2, 1, 12, 7, device=dev).clamp_min(1e-3).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v = AttentionBinarizationLoss()(hard, soft.bfloat16())
+    ref = -(torch.log(soft.detach().bfloat16().float())[hard == 1]).mean()
+    assert v.dtype == torch.float32 and abs(float(v) - float(ref)) <= 1e-5 * abs(float(ref))
+    v.backward()
+    assert torch.isfinite(soft.grad).all()
+
+
 def test_training_step_with_host_lengths_never_synchronises():
     """Round 4: with the host copies of the lengths in the batch (`input_lengths_host` /
     `output_lengths_host`, what the collate function has before the batch moves to the device) a whole training step --

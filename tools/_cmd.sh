@@ -1,13 +1,11 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 1500 python -m pytest tests -m gpu -q --durations=10 > gpurun_out/pytest_gpu.txt 2>&1
-tail -2 gpurun_out/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py --full-step > gpurun_out/bench_e.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_e.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['full_step']['ms_per_step'])
-PY
-timeout 600 bash tools/prof_step.sh r05g > /dev/null 2>&1
-head -6 gpurun_out/r05g_kernel_stats.txt | cut -c1-130
+mkdir -p gpurun_out
+export RADMMM_DEBUG=1
+for i in 1 2 3; do
+RADMMM_RES_STREAM=0 timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-120 | sed 's/^/off  /' | tee -a gpurun_out/r06_b_ab.txt
+RADMMM_RES_STREAM=1 timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-120 | sed 's/^/on   /' | tee -a gpurun_out/r06_b_ab.txt
+done
+RADMMM_BENCH_SPAWN=1 timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | grep step_only | cut -c1-120 | sed 's/^/pg on /' | tee -a gpurun_out/r06_b_ab.txt
+RADMMM_BENCH_SPAWN=1 RADMMM_RES_STREAM=0 timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | grep step_only | cut -c1-120 | sed 's/^/pg off/' | tee -a gpurun_out/r06_b_ab.txt
+timeout 900 python -m pytest tests/test_hip_round6.py tests/test_hip_round5.py tests/test_tts_step.py -m gpu -q -x 2>&1 | tail -15 | tee gpurun_out/r06_b_pytest.txt
