@@ -137,15 +137,28 @@ def conv_norm(p: Params, prefix: str, x: Tensor, mask: Optional[Tensor], dilatio
 
 
 def wn_forward(p: Params, prefix: str, z0: Tensor, ctx: Tensor, mask: Optional[Tensor],
-               n_layers: int, activation: str = "softplus", partial: bool = True) -> Tensor:
-    """WN.forward.  common.py:816-835 (no gated tanh, no residual path)."""
-    act = F.softplus if activation == "softplus" else torch.relu
+               n_layers: int, activation: str = "softplus", partial: bool = True,
+               kinks: Optional[Dict] = None) -> Tensor:
+    """WN.forward.  common.py:816-835 (no gated tanh, no residual path).
+    Test accounting of relu's kink (not reference behaviour; affine_activation='relu' only): kinks["record"] receives the
+    pre-activations under (prefix, layer, "in" | "res"); kinks["gates"] (same keys, bool) overrides the decision pre > 0 of the
+    activation and of its derivative, as dap_forward's `gates` does."""
+    base = F.softplus if activation == "softplus" else torch.relu
+    rec = (kinks or {}).get("record")
+    gts = (kinks or {}).get("gates")
+
+    def act(pre, key):
+        if rec is not None:
+            rec[key] = pre.detach()
+        if gts is not None and activation != "softplus":
+            return torch.where(gts[key], pre, torch.zeros_like(pre))
+        return base(pre)
     h = F.conv1d(torch.cat((z0, ctx), 1), _wn_weight(p, prefix + "start."), p[prefix + "start.bias"])
     out = torch.zeros_like(h)
     for i in range(n_layers):
-        h = act(conv_norm(p, f"{prefix}in_layers.{i}.", h, mask, 2 ** i, partial))
+        h = act(conv_norm(p, f"{prefix}in_layers.{i}.", h, mask, 2 ** i, partial), (prefix, i, "in"))
         r = act(F.conv1d(h, _wn_weight(p, f"{prefix}res_skip_layers.{i}."),
-                         p[f"{prefix}res_skip_layers.{i}.bias"]))
+                         p[f"{prefix}res_skip_layers.{i}.bias"]), (prefix, i, "res"))
         out = out + r
     return F.conv1d(out, p[prefix + "end.weight"], p[prefix + "end.bias"])
 
@@ -176,12 +189,12 @@ def scaling_and_log(su: Tensor, fn: str) -> Tuple[Tensor, Tensor]:
 
 def affine_coupling_forward(p: Params, prefix: str, z: Tensor, ctx: Tensor, mask: Optional[Tensor],
                             n_layers: int, scaling_fn: str = "tanh",
-                            activation: str = "softplus", partial: bool = True
-                            ) -> Tuple[Tensor, Tensor]:
+                            activation: str = "softplus", partial: bool = True,
+                            kinks: Optional[Dict] = None) -> Tuple[Tensor, Tensor]:
     """AffineTransformationLayer.forward (affine_model='wavenet').  common.py:1163-1185."""
     h = z.shape[1] // 2
     z0, z1 = z[:, :h], z[:, h:]
-    o = wn_forward(p, prefix + "affine_param_predictor.", z0, ctx, mask, n_layers, activation, partial)
+    o = wn_forward(p, prefix + "affine_param_predictor.", z0, ctx, mask, n_layers, activation, partial, kinks)
     s, log_s = scaling_and_log(o[:, :h], scaling_fn)
     return torch.cat((z0, s * z1 + o[:, h:]), 1), log_s
 
@@ -448,9 +461,9 @@ def preprocess_context(p: Params, cfg: DecoderConfig, context: Tensor, spk: Tens
 def decoder_forward(p: Params, cfg: DecoderConfig, mel: Tensor, spk: Tensor, context: Tensor,
                     lengths: Tensor, f0: Optional[Tensor] = None, energy: Optional[Tensor] = None,
                     accent: Optional[Tensor] = None, training: bool = True,
-                    spline_records: Optional[List[Dict]] = None) -> Dict[str, object]:
+                    spline_records: Optional[List[Dict]] = None, wn_kinks: Optional[Dict] = None) -> Dict[str, object]:
     """RADMMMFlow.forward.  decoders.py:168-205.  spline_records (test accounting): one dict per spline flow, handed to
-    spline_coupling_forward as `record`."""
+    spline_coupling_forward as `record`; wn_kinks (test accounting): wn_forward's `kinks`."""
     g = cfg.n_group_size
     ctx = preprocess_context(p, cfg, context, spk, lengths, f0, energy, accent)
     z = squeeze_time(mel, g)
@@ -475,7 +488,7 @@ def decoder_forward(p: Params, cfg: DecoderConfig, mel: Tensor, spk: Tensor, con
         else:
             z, ls = affine_coupling_forward(p, pre + "coupling_tfn.", z, ctx, mask,
                                             cfg.n_conv_layers_per_step, cfg.scaling_fn,
-                                            cfg.affine_activation, cfg.use_partial_padding)
+                                            cfg.affine_activation, cfg.use_partial_padding, wn_kinks)
         log_s_list.append(ls)
         log_det_list.append(ld)
     z_out.append(z)
@@ -890,7 +903,8 @@ def dap_forward(p: Params, prefix: str, text_enc: Tensor, spk: Tensor, lens: Ten
 
 def tts_joint_step(p: Params, cfg: DecoderConfig, batch: Dict[str, Tensor], predictors: Dict[str, Dict],
                    binarize: bool = True, bin_loss: bool = True, n_enc_conv: int = 3,
-                   ctc_loss_weight: float = 0.1, binarization_loss_weight: float = 1.0) -> Dict[str, object]:
+                   ctc_loss_weight: float = 0.1, binarization_loss_weight: float = 1.0,
+                   dap_gates: Optional[Dict[str, Dict]] = None, dap_record: Optional[Dict[str, Dict]] = None) -> Dict[str, object]:
     """TTSModel.training_step (tts_lightning_modules.py:643-750) with dropout off, on CPU: mel scaling (:543-545), speaker /
     accent / text embeddings (:246-268), text encoder, alignment attention with the prior (:440-475), per-item MAS when
     `binarize` (:270-284), context = txt_enc . attn^T (:669), flow decoder + RADMMMLoss (loss.py:518-537: flow NLL, CTC x
@@ -900,7 +914,10 @@ def tts_joint_step(p: Params, cfg: DecoderConfig, batch: Dict[str, Tensor], pred
     `predictors`: {"f0" | "energy" | "voiced" | "duration": dict(n_layers, target_scale, target_offset, log_target, weight,
     prefix)}.  batch: mel [B, 80, T], speaker_ids, accent_ids, text [B, L], input_lengths, output_lengths, attn_prior
     [B, T, L], f0, energy_avg [B, T], voiced_mask [B, T].  Returns losses {name: (value, weight)}, `loss` (their weighted
-    sum, :746-749), `pred` {name: x_hat} and the intermediate attn / context."""
+    sum, :746-749), `pred` {name: x_hat} and the intermediate attn / context.
+    Pinned to the reference's own components on tests/golden/tts_step.npz (tests/test_oracle_joint.py).  dap_gates /
+    dap_record: {predictor name: dap_forward's `gates` / `record`} -- the test accounting of the predictors' ReLU kinks
+    (tests/test_joint_step.py), not reference behaviour."""
     in_lens, out_lens = batch["input_lengths"].long(), batch["output_lengths"].long()
     mel = (batch["mel"] + 5) / 2
     spk = p["speaker_embeddings.weight"][batch["speaker_ids"]]
@@ -938,7 +955,8 @@ def tts_joint_step(p: Params, cfg: DecoderConfig, batch: Dict[str, Tensor], pred
             target, src, lens = raw[:, None], context.detach(), out_lens
             tmask = batch["voiced_mask"][:, None].bool() if name == "f0" else lengths_to_mask(out_lens, T)[:, None]
         x = dap_tx_data(target, spec.get("target_scale", 1.0), spec.get("target_offset", 0.0), spec.get("log_target", False))
-        x_hat = dap_forward(p, pre, src, spk_acc, lens, spec["n_layers"])
+        x_hat = dap_forward(p, pre, src, spk_acc, lens, spec["n_layers"], gates=(dap_gates or {}).get(name),
+                            record=dap_record.setdefault(name, {}) if dap_record is not None else None)
         w = x_hat.shape[2]
         m = tmask[:, :, :w]
         losses[spec["prefix"] + "loss"] = (F.mse_loss(x_hat[m], x[:, :, :w][m], reduction="sum") / tmask.sum(), spec.get("weight", 1.0))

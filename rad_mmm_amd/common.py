@@ -228,7 +228,8 @@ class AffineTransformationLayer(nn.Module):
         for i, l in enumerate(self.affine_param_predictor.in_layers):
             assert l.dilation == 2 ** i, "ops.AffineFlowStepFn assumes dilation 2^i"
 
-    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision="fp32", scale_box=None, ctx_acc=None, ctx_slot=0):
+    def run(self, z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision="fp32", scale_box=None, ctx_acc=None, ctx_slot=0,
+            flow_index=None):
         """Fused [1x1 mix -> WN -> coupling] on channels-last operands.  Returns z_out, log_s.
         precision "fp32": fp32 MFMA GEMMs; "h3": split-f16 GEMMs (fp32-class accuracy, f16 matrix
         cores) when the WN width allows it (multiple of 32); "f8x": the hi.hi product on the f16 cores and both cross
@@ -244,6 +245,6 @@ class AffineTransformationLayer(nn.Module):
         meta = dict(B=B, T=T, C=self.n_mel_channels, D=self.n_context_dim, n_layers=wn.n_layers,
                     act=ACT[wn.affine_activation], scaling=SCALE[self.scaling_fn],
                     partial=bool(wn.use_partial_padding), scale_box=scale_box if scale_box is not None else {},
-                    nprod=nprod, ctx_acc=ctx_acc, ctx_slot=ctx_slot)
+                    nprod=nprod, ctx_acc=ctx_acc, ctx_slot=ctx_slot, flow_index=flow_index)
         fn = ops.AffineFlowStepH3Fn if (precision in ops.NPROD and wn.n_channels % 32 == 0) else ops.AffineFlowStepFn
         return fn.apply(meta, z_cl, cond_cl, lens32, W_eff, b_eff, *head, *layers)

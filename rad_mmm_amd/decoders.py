@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import fp32_region, debug_env
+from ._trace import trace_range
 from .common import (AffineTransformationLayer, DataInitializedInvertible1x1Conv,
                      Invertible1x1ConvLUS, SequenceLength)
 
@@ -72,7 +73,7 @@ class FlowStep(nn.Module):
         return b
 
     def forward_cl(self, z_cl, cond_cl, seq_lens: SequenceLength, lens32, B, T, col_offset, precision="fp32",
-                   scale_box=None, ctx_acc=None, ctx_slot=0):
+                   scale_box=None, ctx_acc=None, ctx_slot=0, flow_index=None):
         conv = self.invtbl_conv
         # (`initialized` is a device buffer: it is read once -- a host synchronisation -- and the answer is remembered FOR THAT
         #  VERSION OF THE BUFFER: any in-place write (`fill_`, `copy_`, load_state_dict, a re-init utility) bumps the tensor's
@@ -95,7 +96,8 @@ class FlowStep(nn.Module):
             n_valid = int(seq_lens.lengths_host.sum())
             z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, n_valid, scale_box)
         else:
-            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box, ctx_acc, ctx_slot)
+            z_out, log_s = self.coupling_tfn.run(z_cl, cond_cl, lens32, W_eff, b_eff, B, T, precision, scale_box, ctx_acc, ctx_slot,
+                                                 flow_index)
         return z_out, log_det_W, log_s
 
 
@@ -380,7 +382,8 @@ class RADMMMFlow(nn.Module):
         if not mel.is_cuda:
             raise RuntimeError("rad_mmm_amd.decoders.RADMMMFlow runs on an MI355X only (no CPU path)")
         g = self.n_group_size
-        cond = self.preprocess_context_cl(context.float(), spk_vecs.float(), out_lens, f0, energy_avg, accent_vecs)
+        with trace_range("context.fwd"):
+            cond = self.preprocess_context_cl(context.float(), spk_vecs.float(), out_lens, f0, energy_avg, accent_vecs)
         B, Tg, D = cond.shape
         C0 = mel.shape[1] * g
         z = ops.squeeze_rows(mel.float(), g, ZLD, 0)             # [B*T', ZLD]: squeeze + zero padding in one pass
@@ -408,8 +411,9 @@ class RADMMMFlow(nn.Module):
                 z_out.append(z[:, : self.n_early_size])
                 off = self.n_early_size
             z_in = z
-            z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off, self.gemm_precision, scale_box,
-                                                  None if flow.use_spline else ctx_acc, aff_slot)
+            with trace_range(f"flow{i}.fwd"):                      # (rocprofv3 markers, RADMMM_ROCTX=1: rad_mmm_amd/_trace.py)
+                z, log_det_W, log_s = flow.forward_cl(z, cond2, unfolded, lens32, B, Tg, off, self.gemm_precision, scale_box,
+                                                      None if flow.use_spline else ctx_acc, aff_slot, i)
             aff_slot += 0 if flow.use_spline else 1
             if guard_now and i == len(self.flows) - 1:
                 self._guard_measure(flow, z_in, z, cond2, unfolded, lens32, B, Tg, off)

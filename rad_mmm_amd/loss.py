@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .common import SequenceLength
+from ._trace import traced
 
 
 def compute_flow_loss(z, log_det_W_list, log_s_list, n_elements, n_dims, lens32, sigma=1.0):
@@ -128,6 +129,7 @@ class RADTTSLoss(nn.Module):
         self.attn_loss = AttentionLoss(CTC_blank_logprob, kl_loss_start_iter, binarization_loss_weight,
                                        ctc_loss_weight)
 
+    @traced("loss")
     def forward(self, model_output, in_lens: Optional[SequenceLength], out_lens: SequenceLength, global_step):
         loss_dict = {}
         if len(model_output["z_mel"]):

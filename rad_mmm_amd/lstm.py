@@ -13,6 +13,7 @@ import os
 import torch
 
 from ._lib import lib, check, ptr, stream, amp_fwd, amp_bwd, rowgemm_h3, debug_env
+from ._trace import traced
 
 
 def _scratch(B, H, which, like):
@@ -65,6 +66,7 @@ class BiLSTMFn(torch.autograd.Function):
 
     @staticmethod
     @amp_bwd
+    @traced("lstm.bwd")
     def backward(ctx, dy):
         B, T, I, H = ctx.dims
         if getattr(ctx, "_consumed", False):
@@ -207,6 +209,7 @@ class MergedBiLSTMFn(torch.autograd.Function):
 
     @staticmethod
     @amp_bwd
+    @traced("lstm_merged.bwd")
     def backward(ctx, *dys):
         B, T, H, P = ctx.dims
         HP = P * H

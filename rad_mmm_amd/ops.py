@@ -1199,6 +1199,8 @@ def module_scale_box(module, new_forward_on=None) -> "GradScale":
     """The GradScale a module outside the decoder (text encoder, alignment attention) keeps for its stand-alone conv_norm
     calls: with a throw-away dict every conv's backward reads its gradient's maximum on the host -- a synchronisation per
     conv and step.  new_forward_on = device: mark the start of a training forward (publishes the previous pass's stats)."""
+    if debug_env("RADMMM_CONV_OWN_SCALE", "0") == "1":      # A/B aid: every conv's backward scales by its OWN gradient's maximum
+        return {}
     box = module.__dict__.get("_scale_box")
     if box is None:
         box = module.__dict__["_scale_box"] = GradScale()
@@ -1241,6 +1243,20 @@ def check_saturation(box) -> None:
     clamp instead of at the next pass."""
     if os.environ.get("RADMMM_CHECK_SATURATION", "0") == "1" and isinstance(box, GradScale):
         box.check()
+
+
+def traced_bwd(fn):
+    """backward of a flow step inside a roctx range `flow<i>.bwd` (RADMMM_ROCTX=1, rad_mmm_amd/_trace.py); off: one test"""
+    import functools
+    from . import _trace
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        if not _trace.ENABLED:
+            return fn(ctx, *grads)
+        with _trace.trace_range("flow%s.bwd" % getattr(ctx, "meta", {}).get("flow_index", "?")):
+            return fn(ctx, *grads)
+    return wrapped
 
 
 _SIDE_STREAMS: dict = {}
@@ -1451,6 +1467,7 @@ class AffineFlowStepH3Fn(torch.autograd.Function):
 
     @staticmethod
     @amp_bwd
+    @traced_bwd
     def backward(ctx, g_zout, g_logs):
         meta, nl = ctx.meta, ctx.nl
         NPR = meta.get("nprod", 3)

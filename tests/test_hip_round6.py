@@ -86,6 +86,11 @@ def test_dap_forward_many_does_not_share_rows_between_a_context_and_its_detached
     mk = lambda: ConvLSTMLinearDAP(n_speaker_dim=16, in_dim=32, out_dim=1, reduction_factor=4, n_backbone_layers=2, n_hidden=32,
                                    kernel_size=3, p_dropout=0.0).to(DEV).train()
     pa, pd = mk(), mk()
+    for d in (pa, pd):           # converge spectral norm's power iteration, then freeze it: every pass sees the same W_hh
+        for _ in range(20):
+            for hook in d.feat_pred_fn.bilstm._forward_pre_hooks.values():
+                hook(d.feat_pred_fn.bilstm, ())
+        d.eval()
     B, T = 3, 40
     lens = SequenceLength(torch.tensor([40, 33, 17], device=DEV))
     spk = torch.randn(B, 16, device=DEV)
@@ -106,7 +111,9 @@ def test_dap_forward_many_does_not_share_rows_between_a_context_and_its_detached
     for order in (("a", "d"), ("d", "a")):
         g, res = run(order)
         assert res["d"]["x_hat"].requires_grad          # (through the predictor's own parameters only)
-        assert float((g - g_alone).abs().max()) <= 1e-6 * float(g_alone.abs().max()), order
+        # (the two predictors' bi-LSTMs run as one merged recurrence here, alone as a single one: fp32 summation order; a leak of
+        #  the detached predictor's loss would be O(1))
+        assert float((g - g_alone).abs().max()) <= 2e-4 * float(g_alone.abs().max()), (order, float((g - g_alone).abs().max()))
 
 
 @pytest.mark.gpu

@@ -97,3 +97,40 @@ def test_joint_step_restatement_is_self_consistent():
     hard = r["attn"].round()
     assert bool(((hard == 0) | (hard == 1)).all()) and bool((hard[0, 0].sum(1) == 1).all())
     assert int(hard[1, 0, :, L - 3:].sum()) == 0                      # nothing aligned to the padded text positions
+
+
+def test_joint_step_restatement_reproduces_the_reference_fixture():
+    """VERDICT r5 item 4a -- the PIN of oracle.tts_joint_step (tts_lightning_modules.py:643-750): without predictors, on the
+    batch and weights of tests/golden/tts_step.npz, it reproduces the loss terms, the summed loss, the attention and the
+    decoder context that the REFERENCE's own components produced under TTSModel.training_step's glue
+    (tests/golden/make_golden.py, section "tts_step") -- soft alignments (global_step 0: no MAS, binarisation term off) and
+    MAS-binarised ones (global_step 10) -- to 1e-5.  Module construction only: no kernel runs on the CPU."""
+    import os
+    import radmmm_synth as S
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.encoder import Encoder
+    from rad_mmm_amd.loss import RADMMMLoss
+    from rad_mmm_amd.tts_step import TTSTrainingStep
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tts_step.npz"))
+    kw = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg.")}
+    model = TTSTrainingStep(Encoder(3, 32, 5), RADMMMFlow(use_accent=True, **kw), RADMMMLoss(sigma=1.0, kl_loss_start_iter=5),
+                            n_speakers=3, n_accents=2, n_text_tokens=40, n_text_dim=32, n_speaker_dim=16, n_accent_dim=8,
+                            use_accent=True, binarization_start_iter=10)
+    names = [n for n in model.state_dict() if not n.startswith("decoder_criterion")]
+    proc = S.procedural_decoder_state({n: tuple(model.state_dict()[n].shape) for n in names})
+    p = {n: torch.from_numpy(np.asarray(v)) for n, v in proc.items()}
+    p = {n: (v.float() if v.is_floating_point() else v) for n, v in p.items()}
+    cfg = O.DecoderConfig(**kw)
+    batch = {k[6:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("batch.")}
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    for tag, binarize in (("soft", False), ("hard", True)):
+        with torch.no_grad():
+            r = O.tts_joint_step(p, cfg, batch, {}, binarize=binarize, bin_loss=binarize)
+        assert rel(r["attn"], torch.from_numpy(g[f"{tag}.attn"])) < (1e-5 if tag == "soft" else 1e-12), tag
+        assert rel(r["context"], torch.from_numpy(g[f"{tag}.context"])) < 1e-5, tag
+        for k, (v, w) in r["losses"].items():
+            ref = float(g[f"{tag}.{k}"])
+            assert abs(float(v) - ref) <= 1e-5 * max(abs(ref), 1e-3), (tag, k, float(v), ref)
+        if not binarize:
+            assert float(g["soft.binarization_loss"]) == 0.0          # (the term the restatement leaves out is the constant 0)
+        assert abs(float(r["loss"]) - float(g[f"{tag}.loss"])) <= 1e-5 * abs(float(g[f"{tag}.loss"])), tag

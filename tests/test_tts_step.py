@@ -43,13 +43,17 @@ def test_training_step_matches_reference_components(tag, step, monkeypatch):
         ref = float(g[f"{tag}.{k}"])
         assert abs(float(v) - ref) <= 1e-4 * max(abs(ref), 1e-3), (k, float(v), ref)
     assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-4 * abs(float(g[f"{tag}.loss"]))
+    worst = (0.0, "")
     for k in g.files:
         if k.startswith(f"{tag}.gradnorm."):
             n = k[len(tag) + 10:]
             p = dict(model.named_parameters())[n]
             ref = float(g[k])
             if ref > 1e-6:
-                assert abs(float(p.grad.norm()) - ref) < 2e-3 * ref, (n, float(p.grad.norm()), ref)
+                e = abs(float(p.grad.norm()) - ref) / ref
+                worst = max(worst, (e, n))
+                assert e < 5e-4, (n, float(p.grad.norm()), ref)          # (measured: 3e-6)
+    print(f"tts_step[{tag}]: worst gradient-norm difference {worst[0]:.2e} ({worst[1]})")
 
 
 def test_joint_step_with_attribute_predictors_through_the_bucket_reducer(monkeypatch):
