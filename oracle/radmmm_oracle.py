@@ -933,7 +933,11 @@ def tts_joint_step(p: Params, cfg: DecoderConfig, batch: Dict[str, Tensor], pred
         hard = np.zeros_like(a)
         for b in range(a.shape[0]):                     # (the C restatement of the search: bit-equal to mas_width1, tests)
             hard[b, 0, : int(out_lens[b]), : int(in_lens[b])] = mas_width1_c(a[b, 0, : int(out_lens[b]), : int(in_lens[b])].copy())
-        attn = attn_soft + (torch.from_numpy(hard) - attn_soft).detach()
+        # (tts_lightning_modules.py:470-475: the map used for the context is the PLAIN 0/1 alignment -- the straight-through
+        #  variant `attn_hard` is computed there and dropped by the caller (:665 `attn, attn_soft, _, attn_logprob`), so the
+        #  context carries no gradient into the attention once alignments are binarised.  Round 6: this line was the
+        #  straight-through form until tests/test_joint_step.py compared backward passes; forward values are the same)
+        attn = torch.from_numpy(hard)
     context = torch.bmm(txt_enc, attn.squeeze(1).transpose(1, 2))
     dp = {k[len("decoder."):]: v for k, v in p.items() if k.startswith("decoder.")}
     out = decoder_forward(dp, cfg, mel, spk, context, out_lens, batch["f0"], batch["energy_avg"], acc)

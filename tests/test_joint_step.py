@@ -56,8 +56,8 @@ def test_joint_step_at_the_shipped_size_matches_the_oracle(monkeypatch):
 
 
 def test_joint_step_backward_at_the_shipped_size_matches_the_oracles_autograd(monkeypatch):
-    """the BACKWARD of the joint step at the shipped model size.  Eight utterances of the bench batch
-    (T = 800, 150 tokens; the step's terms are means over utterances, so eight are the step at B = 8), dropout off on both
+    """the BACKWARD of the joint step at the shipped model size.  Twelve utterances of the bench batch
+    (T = 800, 150 tokens; the step's terms are means over utterances, so twelve are the step at B = 12), dropout off on both
     sides: every parameter gradient of the HIP step -- decoder, text encoder, attention, embeddings, the four predictors --
     against the autograd of the oracle's restatement (oracle.tts_joint_step, pinned to the reference's components by
     tests/test_oracle_joint.py), as the relative L2 error of the tensor AND the relative difference of its norm, both held to
@@ -78,7 +78,7 @@ def test_joint_step_backward_at_the_shipped_size_matches_the_oracles_autograd(mo
     monkeypatch.setenv("RADMMM_PRECISION", "f8x")
     monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
     dev = torch.device("cuda:0")
-    B, T, Bs = 32, 800, 8
+    B, T, Bs = 32, 800, 12      # (12 x 400 grouped frames = 4800 rows: the WN stack on the default FP8-cross kernels, >= 4096 rows)
     CFG = bench.CONFIGS["joint"]
     cfg, sd = bench.procedural_state(CFG)
     dec = RADMMMFlow(use_accent=True, **CFG)
@@ -157,14 +157,22 @@ def test_joint_step_backward_at_the_shipped_size_matches_the_oracles_autograd(mo
     ref = O.tts_joint_step(p, cfg, cb, specs, binarize=True, bin_loss=True, dap_gates=gates)
     ref["loss"].backward()
     assert abs(float(loss) - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
-    rows, bad = [], {}
+    rows, bad, zeros = [], {}, []
+    gmax = {}
+    for n in g_hip:
+        if p[n].grad is not None:
+            k = n.split(".")[0]
+            gmax[k] = max(gmax.get(k, 0.0), float(p[n].grad.norm()))
     for n in sorted(g_hip):
         gr = p[n].grad
         if gr is None:
             continue
         nr = float(gr.norm())
-        if nr < 1e-12:                                       # (analytically zero: e.g. a bias in front of an instance norm)
-            assert float(g_hip[n].norm()) <= 1e-6 * max(1.0, float(p[n].detach().norm())), n
+        if nr < 1e-5 * gmax[n.split(".")[0]]:
+            # analytically zero -- the scale and the bias of a conv in front of an instance norm (text encoder): both sides hold
+            # rounding residue 1e-6 and less of the module's other gradients, not comparable in relative terms
+            assert float(g_hip[n].norm()) <= 1e-4 * gmax[n.split(".")[0]], (n, float(g_hip[n].norm()))
+            zeros.append(n)
             continue
         l2 = float((g_hip[n] - gr).norm()) / nr
         dn = abs(float(g_hip[n].norm()) - nr) / nr
@@ -173,13 +181,14 @@ def test_joint_step_backward_at_the_shipped_size_matches_the_oracles_autograd(mo
             bad[n] = (l2, dn)
     rows.sort(reverse=True)
     print(f"{len(rows)} parameter gradients compared; worst relative L2 errors:")
-    for l2, dn, n in rows[:40]:
-        print(f"   {l2:.2e} (norm {dn:.2e})  |g_cpu| {float(p[n].grad.norm()):.3e}  |param| {float(p[n].detach().norm()):.3e}  {n}")
+    for l2, dn, n in rows[:10]:
+        print(f"   {l2:.2e} (norm {dn:.2e})  |g_cpu| {float(p[n].grad.norm()):.3e}  {n}")
+    print(f"{len(zeros)} analytically zero gradients (scale / bias in front of an instance norm) held to 1e-4 of their module's largest: {zeros}")
     groups = {}
     for l2, dn, n in rows:
         k = n.split(".")[0]
         groups[k] = max(groups.get(k, 0.0), l2)
     print({k: f"{v:.1e}" for k, v in groups.items()})
-    assert len(rows) >= 300 and not bad, bad
+    assert len(rows) >= 300 and len(zeros) <= 8 and not bad, bad
     # predictors have parameters with gradients, and all four were compared
     assert all(any(n.startswith(f"{name}_predictor.") for _, _, n in rows) for name in specs)

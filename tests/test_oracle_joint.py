@@ -123,9 +123,26 @@ def test_joint_step_restatement_reproduces_the_reference_fixture():
     cfg = O.DecoderConfig(**kw)
     batch = {k[6:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("batch.")}
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    pnames = {n for n, _ in model.named_parameters()}
     for tag, binarize in (("soft", False), ("hard", True)):
-        with torch.no_grad():
-            r = O.tts_joint_step(p, cfg, batch, {}, binarize=binarize, bin_loss=binarize)
+        q = {n: (v.clone().requires_grad_(True) if (n in pnames and v.is_floating_point()) else v) for n, v in p.items()}
+        r = O.tts_joint_step(q, cfg, batch, {}, binarize=binarize, bin_loss=binarize)
+        # ... and its BACKWARD: the gradient norm of every parameter the fixture recorded from the reference's components
+        # (the forward values alone cannot see a misplaced .detach(): round 6 found the context built from the
+        # straight-through alignment here, tts_lightning_modules.py:470-475 / :665)
+        r["loss"].backward()
+        n_cmp = 0
+        for k in g.files:
+            if k.startswith(f"{tag}.gradnorm."):
+                n = k[len(tag) + 10:]
+                ref = float(g[k])
+                if ref > 1e-6:
+                    assert q[n].grad is not None, n
+                    assert abs(float(q[n].grad.norm()) - ref) <= 2e-4 * ref, (tag, n, float(q[n].grad.norm()), ref)
+                    n_cmp += 1
+        assert n_cmp >= 40, n_cmp
+        r = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in r.items()}
+        r["losses"] = {k: (v.detach() if torch.is_tensor(v) else v, w) for k, (v, w) in r["losses"].items()}
         assert rel(r["attn"], torch.from_numpy(g[f"{tag}.attn"])) < (1e-5 if tag == "soft" else 1e-12), tag
         assert rel(r["context"], torch.from_numpy(g[f"{tag}.context"])) < 1e-5, tag
         for k, (v, w) in r["losses"].items():

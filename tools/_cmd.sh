@@ -1,6 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-export RADMMM_DEBUG=1
-RADMMM_CONVNORM_H3_MIN_ROWS=100000000 timeout 1500 python -m pytest tests/test_joint_step.py -m gpu -q -s -k backward > gpurun_out/r06_f_joint_fp32conv.txt 2>&1; echo "--- conv_norm on fp32 kernels"; grep -n "kink\|compared\|^   [0-9]\|^{" gpurun_out/r06_f_joint_fp32conv.txt | head -16
-RADMMM_CONV_OWN_SCALE=1 timeout 1500 python -m pytest tests/test_joint_step.py -m gpu -q -s -k backward > gpurun_out/r06_f_joint_ownscale.txt 2>&1; echo "--- every conv its own gradient scale"; grep -n "kink\|compared\|^   [0-9]\|^{" gpurun_out/r06_f_joint_ownscale.txt | head -16
+timeout 1500 python -m pytest tests/test_joint_step.py -m gpu -q -s -k backward > gpurun_out/r06_g_joint.txt 2>&1; grep -n "kink\|compared\|^   [0-9]\|^{\|analytically\|passed\|failed" gpurun_out/r06_g_joint.txt | head -30
+timeout 1500 python -m pytest tests/test_hip_edge.py tests/test_hip_aux.py tests/test_tts_step.py tests/test_hip_round6.py tests/test_ddp_nccl.py -m gpu -q 2>&1 | tail -5
