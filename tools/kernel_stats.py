@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total/avg ms, share) from a rocprofv3 --kernel-trace results .db
 (rocpd sqlite schema), for when the --stats CSVs were not merged back.
-usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps] [--json FILE]
+usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps] [--json FILE] [--by-range]
   -> prints a table; with `steps`, also ms per step; with --hist, the launch-duration clusters of the
      kernels whose name contains SUBSTR (one kernel serves several GEMM shapes: the per-shape average is
      what bench.py's roofline leg times, the all-shapes average is what --stats prints); with --gaps, how much of the
      busiest window (the last `steps` steps: the 60 % of the dispatches at the end of the trace) the GPU spent between
-     kernels (end of one dispatch -> start of the next, same device), by gap size."""
+     kernels (end of one dispatch -> start of the next, same device), by gap size; with --by-range (a trace taken with
+     `RADMMM_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --hip-trace`), kernel time grouped by the innermost roctx range
+     (rad_mmm_amd/_trace.py: flow<i>.fwd, flow<i>.bwd, context.fwd, lstm.bwd, loss) whose host-side launch produced the
+     dispatch: dispatch -> its event's correlation id -> the HIP launch call with that correlation id -> the marker range
+     on the same thread that encloses the call's start."""
 import sqlite3
 import sys
 
@@ -16,6 +20,9 @@ def main():
     gaps = "--gaps" in argv
     if gaps:
         argv.remove("--gaps")
+    by_range = "--by-range" in argv
+    if by_range:
+        argv.remove("--by-range")
     jpath = None
     if "--json" in argv:
         i = argv.index("--json")
@@ -75,6 +82,8 @@ def main():
         print("  gaps > 5 us by (kernel before, kernel after), largest totals:")
         for (a, b), (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:30]:
             print(f"    {n:5d} x  total {t / 1e6:7.3f} ms   after {short(a):48s} before {short(b)}")
+    if by_range:
+        ranges_report(db, tabs, kd, ks, steps)
     if hist:
         durs = [r[0] / 1e3 for r in db.execute(
             f"select d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id where s.kernel_name like ?",
@@ -87,6 +96,66 @@ def main():
                 c = durs[start:i]
                 print(f"  {len(c):6d} launches  {c[0]:8.1f} .. {c[-1]:8.1f} us   mean {sum(c) / len(c):8.1f} us")
                 start = i
+
+
+def ranges_report(db, tabs, kd, ks, steps):
+    """kernel time per roctx range (see the module docstring)"""
+    import bisect
+    rg = next(t for t in tabs if t.startswith("rocpd_region"))
+    ev = next(t for t in tabs if t.startswith("rocpd_event"))
+    st = next(t for t in tabs if t.startswith("rocpd_string"))
+    cats = db.execute(f"select s.string, count(*) from {rg} r join {ev} e on e.id = r.event_id join {st} s on s.id = e.category_id "
+                      f"group by s.string").fetchall()
+    print("\nregion categories in the trace:", ", ".join(f"{c} x {n}" for c, n in cats))
+    mk = [c for c, _ in cats if "MARKER" in c.upper() or "ROCTX" in c.upper()]
+    if not mk:
+        print("no marker regions in this trace (run with RADMMM_ROCTX=1 and rocprofv3 --marker-trace --hip-trace)")
+        return
+    q = ",".join("?" * len(mk))
+    marks = db.execute(f"select r.tid, r.start, r.end, n.string from {rg} r join {ev} e on e.id = r.event_id join {st} c on c.id = e.category_id "
+                       f"join {st} n on n.id = r.name_id where c.string in ({q}) order by r.start", mk).fetchall()
+    print(f"{len(marks)} marker ranges; names: {sorted({m[3] for m in marks})[:24]}")
+    # HIP launch calls by correlation id: (tid, host start)
+    api = {}
+    for corr, tid, start in db.execute(f"select e.correlation_id, r.tid, r.start from {rg} r join {ev} e on e.id = r.event_id "
+                                       f"join {st} c on c.id = e.category_id where c.string like 'HIP_RUNTIME_API%'"):
+        api.setdefault(corr, (tid, start))
+    per_tid = {}
+    for tid, a, b, name in marks:
+        per_tid.setdefault(tid, []).append((a, b, name))
+    starts = {tid: [m[0] for m in v] for tid, v in per_tid.items()}
+
+    def innermost(tid, t):
+        v = per_tid.get(tid)
+        if not v:
+            return "(no range)"
+        i = bisect.bisect_right(starts[tid], t) - 1
+        while i >= 0:                                   # ranges nest and are sorted by start: walk back to the first one still open
+            if v[i][1] >= t:
+                return v[i][2]
+            i -= 1
+        return "(no range)"
+    agg, tot, lost = {}, 0, 0
+    for corr, dur, kname in db.execute(f"select e.correlation_id, d.end - d.start, s.kernel_name from {kd} d join {ev} e on e.id = d.event_id "
+                                       f"join {ks} s on s.id = d.kernel_id"):
+        h = api.get(corr)
+        if h is None:
+            lost += 1
+            name = "(launch call not in the trace)"
+        else:
+            name = innermost(*h)
+        a = agg.setdefault(name, [0, 0, {}])
+        a[0] += 1
+        a[1] += dur
+        a[2][kname] = a[2].get(kname, 0) + dur
+        tot += dur
+    print(f"\n{'range':28s} {'launches':>9s} {'total_ms':>10s} {'%':>6s}" + ("  ms/step" if steps else "") + "   largest kernels")
+    short = lambda n: n.replace("_ZN12_GLOBAL__N_1", "").replace("_ZN2at6native", "at:")[:34]
+    for name, (n, t, ks_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        top = ", ".join(f"{short(k)} {v / 1e6:.1f}" for k, v in sorted(ks_.items(), key=lambda kv: -kv[1])[:3])
+        print(f"{name[:28]:28s} {n:9d} {t / 1e6:10.2f} {100 * t / max(tot, 1):6.2f}" + (f" {t / 1e6 / steps:8.2f}" if steps else "") + "   " + top)
+    if lost:
+        print(f"({lost} dispatches without a traced launch call)")
 
 
 if __name__ == "__main__":
