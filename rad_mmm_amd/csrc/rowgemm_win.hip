@@ -176,6 +176,12 @@ __global__ __launch_bounds__(256, 1) void rowgemm_win_kernel(const radmmm_rowgem
 #elif defined(RADMMM_SKIP_LO_READS)         // TIMING-ONLY build (wrong results): the cross-term MFMAs run on the hi fragments -- what do
     fal[t] = fah[t];                        // the 14 lo-fragment LDS reads per wave and K step cost a power-bound launch?
 #else
+#ifdef RADMMM_WIN_SKIP6       // TIMING-ONLY build (wrong results): 6 of the 36 fragment reads per wave and K step are not
+    if ((t & 1) == 0 && t < 12) {   // issued -- the read count of a 2 x 2 wave layout on 16 x 16 MFMAs (30 per wave), same MFMAs, same DMA
+      fal[t] = fah[t];              // (profiles/r06_tile_probes.txt)
+      return;
+    }
+#endif
     fal[t] = *reinterpret_cast<const f16x8*>(sm + ((t & 1) ? aad1 : aad0)[t >> 1][tap] + par * G::W_BYTES + G::W_PLANE);
 #endif
   };

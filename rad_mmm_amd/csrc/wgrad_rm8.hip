@@ -383,6 +383,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         if (i == 6) {
           // tile s + 1 has landed as far as this wave fetched it, every read of tile s is complete: publish, and free
           // tile s's stage for tile s + 3
+#ifdef RADMMM_WG8_GY_EVERY
+          if ((l_rel % RADMMM_WG8_GY_EVERY) != 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else
+#endif
           asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -437,7 +441,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         // slot 4
         acc[i][0] = WG8_MFMA_X(a8, b8[0], acc[i][0], x_sa, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i < 6) dma_piece(nbuf, 2 * i, l_rel, nmask);
+        // -DRADMMM_WG8_GY_EVERY=n, TIMING-ONLY (wrong results; VERDICT r5 item 2b measured before built): the GY pieces of a
+        // tile (0..3 hi, 8 / 9 lo8: half of the 12) are issued in one step of n only -- the stage keeps older GY frames, real
+        // data -- i.e. the instruction and L2 -> LDS byte mix of a tile that keeps GY resident for all five taps (n = 5: 40 % of
+        // the DMA pieces gone); the step's wait counts what the step issued.  profiles/r06_tile_probes.txt
+#ifdef RADMMM_WG8_GY_EVERY
+#define WG8_PIECE_ON(w) (((w) >= 4 && (w) != 8 && (w) != 9) || gy_step)
+        const bool gy_step = (l_rel % RADMMM_WG8_GY_EVERY) == 0;
+#else
+#define WG8_PIECE_ON(w) true
+#endif
+        if (i < 6 && WG8_PIECE_ON(2 * i)) dma_piece(nbuf, 2 * i, l_rel, nmask);
         if (i == 1) nmask = row_mask();                            // (first needed by block 2's pieces)
         h8n[0] = cvt4_fp8(ga0[nx1].lo[0], ga0[nx1].lo[1], g_inv);
         h8n[1] = cvt4_fp8(ga0[nx1].hi[0], ga0[nx1].hi[1], g_inv);
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_rm8_kernel(const Rm8Args a) {
         // slot 5
         acc[i][1] = WG8_MFMA_X(a8, b8[1], acc[i][1], x_sa, x_sb);
         __builtin_amdgcn_sched_barrier(0);                         // (the MFMA opens its slot)
-        if (i < 6) dma_piece(nbuf, 2 * i + 1, l_rel, nmask);
+        if (i < 6 && WG8_PIECE_ON(2 * i + 1)) dma_piece(nbuf, 2 * i + 1, l_rel, nmask);
         h8n[2] = cvt4_fp8(ga1[nx1].lo[0], ga1[nx1].lo[1], g_inv);
         h8n[3] = cvt4_fp8(ga1[nx1].hi[0], ga1[nx1].hi[1], g_inv);
         ah8[(i + 1) & 1] = h8n;

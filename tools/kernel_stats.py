@@ -9,8 +9,8 @@ usage: kernel_stats.py results.db [steps] [--hist SUBSTR] [--gaps] [--json FILE]
      kernels (end of one dispatch -> start of the next, same device), by gap size; with --by-range (a trace taken with
      `RADMMM_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --hip-trace`), kernel time grouped by the innermost roctx range
      (rad_mmm_amd/_trace.py: flow<i>.fwd, flow<i>.bwd, context.fwd, lstm.bwd, loss) whose host-side launch produced the
-     dispatch: dispatch -> its event's correlation id -> the HIP launch call with that correlation id -> the marker range
-     on the same thread that encloses the call's start."""
+     dispatch: dispatch -> its event's stack id -> the HIP launch call with that stack id -> the marker range on the same
+     thread that encloses the call's start (backward ranges live on autograd's thread, like their launches)."""
 import sqlite3
 import sys
 
@@ -112,14 +112,23 @@ def ranges_report(db, tabs, kd, ks, steps):
         print("no marker regions in this trace (run with RADMMM_ROCTX=1 and rocprofv3 --marker-trace --hip-trace)")
         return
     q = ",".join("?" * len(mk))
-    marks = db.execute(f"select r.tid, r.start, r.end, n.string from {rg} r join {ev} e on e.id = r.event_id join {st} c on c.id = e.category_id "
-                       f"join {st} n on n.id = r.name_id where c.string in ({q}) order by r.start", mk).fetchall()
+    import json
+    # (the range's text is the event's extdata {"message": ...}; the region's name is the API function, roctxThreadRangeA)
+    marks = []
+    for tid, a, b, ext, fn in db.execute(f"select r.tid, r.start, r.end, e.extdata, n.string from {rg} r join {ev} e on e.id = r.event_id "
+                                         f"join {st} c on c.id = e.category_id join {st} n on n.id = r.name_id where c.string in ({q}) "
+                                         f"order by r.start", mk):
+        try:
+            msg = json.loads(ext).get("message") if ext else None
+        except Exception:
+            msg = None
+        marks.append((tid, a, b, msg or fn))
     print(f"{len(marks)} marker ranges; names: {sorted({m[3] for m in marks})[:24]}")
-    # HIP launch calls by correlation id: (tid, host start)
+    # a dispatch's event carries the stack id of the HIP call that launched it: stack id -> (thread, host start of the call)
     api = {}
-    for corr, tid, start in db.execute(f"select e.correlation_id, r.tid, r.start from {rg} r join {ev} e on e.id = r.event_id "
-                                       f"join {st} c on c.id = e.category_id where c.string like 'HIP_RUNTIME_API%'"):
-        api.setdefault(corr, (tid, start))
+    for sid, tid, start in db.execute(f"select e.stack_id, r.tid, r.start from {rg} r join {ev} e on e.id = r.event_id "
+                                      f"join {st} c on c.id = e.category_id where c.string like 'HIP_RUNTIME_API%'"):
+        api.setdefault(sid, (tid, start))
     per_tid = {}
     for tid, a, b, name in marks:
         per_tid.setdefault(tid, []).append((a, b, name))
@@ -136,7 +145,7 @@ def ranges_report(db, tabs, kd, ks, steps):
             i -= 1
         return "(no range)"
     agg, tot, lost = {}, 0, 0
-    for corr, dur, kname in db.execute(f"select e.correlation_id, d.end - d.start, s.kernel_name from {kd} d join {ev} e on e.id = d.event_id "
+    for corr, dur, kname in db.execute(f"select e.stack_id, d.end - d.start, s.kernel_name from {kd} d join {ev} e on e.id = d.event_id "
                                        f"join {ks} s on s.id = d.kernel_id"):
         h = api.get(corr)
         if h is None:
