@@ -168,30 +168,62 @@ class MergedBiLSTMFn(torch.autograd.Function):
     G' [B*T, 2, 4, P, H], the block-diagonal W_hh' [2, 4 P H, P H] and dy' are assembled here, and the input projections /
     weight gradients stay per LSTM (small GEMMs).  The zero blocks cost MFMA work nobody waits for.
 
-    forward(lens, P, x_0 .. x_{P-1}, then per LSTM: w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+    forward(lens, P, box, x_0 .. x_{P-1}, then per LSTM: w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
     -> y_0 .. y_{P-1}, each [B, T, 2H]."""
 
     @staticmethod
     @amp_fwd
-    def forward(ctx, lens, P, *args):
+    def forward(ctx, lens, P, box, *args):
         xs, ws = args[:P], args[P:]
+        ctx.box = box
         B, T, I = xs[0].shape
         H = ws[1].shape[1]
         HP = P * H
         dev = xs[0].device
-        G = torch.empty(B * T, 2, 4, P, H, device=dev, dtype=torch.float32)
         W_hh = torch.zeros(2, 4, P, H, P, H, device=dev, dtype=torch.float32)        # [dir][gate][p][unit] x [p'][unit']
         x2s, W_ihs = [], []
+        # Round 6: frame-rate batches run the P input projections as ONE split-f16 GEMM on the concatenated inputs with a
+        # block-structured weight (row (dir, gate, p, unit) holds W_ih_p's row in columns [p I, (p + 1) I), zeros elsewhere): the
+        # result IS the merged gate layout, and in backward the same pair of operands gives dW_ih / dx / dW_hh on the row-major
+        # split kernels (three f16 products, 2e-6) -- instead of 3 x {fp32 library GEMM at 40 TFLOP/s + a strided scatter of 105 MB}
+        # each way (joint step: 2.96 ms of `Cijk_*` launches per step, profiles/r05_joint_kernel_stats.txt).  The zero blocks
+        # cost 2/3 of 121 GFLOP of MFMA work nobody waits for.  RADMMM_MERGED_LSTM_GEMMS=torch (RADMMM_DEBUG): the library path.
+        I = xs[0].shape[2]
+        split = bool(box is not None and B * T >= 4096 and all(x.shape[2] == I for x in xs) and (P * I) % 32 == 0 and H % 8 == 0
+                     and T >= 32 and B <= 1024 and debug_env("RADMMM_MERGED_LSTM_GEMMS", "hip") != "torch")
+        ctx.split = split
+        if split:
+            from . import ops
+            Kc = P * I
+            x_cat = torch.cat([x.reshape(B * T, I) for x in xs], 1)                # [B*T, P*I]
+            Wb = torch.zeros(2, 4, P, H, P, I, device=dev, dtype=torch.float32)
+            bias = torch.empty(2, 4, P, H, device=dev, dtype=torch.float32)
+        else:
+            G = torch.empty(B * T, 2, 4, P, H, device=dev, dtype=torch.float32)
         for p in range(P):
             w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ws[8 * p: 8 * p + 8]
-            x2 = xs[p].reshape(B * T, -1).contiguous()
-            W_ih = torch.cat((w_ih_f, w_ih_r), 0)                                   # [8H, I_p]
-            bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r))
-            G[:, :, :, p, :] = torch.addmm(bias, x2, W_ih.t()).view(B * T, 2, 4, H)
+            if split:
+                Wb[0, :, p, :, p, :] = w_ih_f.view(4, H, I)
+                Wb[1, :, p, :, p, :] = w_ih_r.view(4, H, I)
+                bias[0, :, p, :] = (b_ih_f + b_hh_f).view(4, H)
+                bias[1, :, p, :] = (b_ih_r + b_hh_r).view(4, H)
+            else:
+                x2 = xs[p].reshape(B * T, -1).contiguous()
+                W_ih = torch.cat((w_ih_f, w_ih_r), 0)                               # [8H, I_p]
+                bias_p = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r))
+                G[:, :, :, p, :] = torch.addmm(bias_p, x2, W_ih.t()).view(B * T, 2, 4, H)
+                x2s.append(x2)
+                W_ihs.append(W_ih)
             W_hh[0, :, p, :, p, :] = w_hh_f.view(4, H, H)
             W_hh[1, :, p, :, p, :] = w_hh_r.view(4, H, H)
-            x2s.append(x2)
-            W_ihs.append(W_ih)
+        if split:
+            Wb = Wb.view(8 * HP, Kc)
+            xh, xl = ops.split_f16(x_cat, Kc, 1.0, Kc)
+            Wh, Wl = ops.split_f16(Wb, Kc, ops.W_SCALE, Kc)
+            G = torch.empty(B * T, 8 * HP, device=dev, dtype=torch.float32)
+            rowgemm_h3(nprod=3, Ah=xh, Al=xl, lda_h=Kc, Bh=Wh, Bl=Wl, ldb_h=Kc, acc_scale=1.0 / ops.W_SCALE, C=G, ldc=8 * HP,
+                       M=B * T, N=8 * HP, K=Kc, T=T, bias=bias.view(8 * HP))
+            x2s, W_ihs = [xh, xl], [Wb]
         G = G.view(B * T, 8 * HP)
         W_hh = W_hh.view(2, 4 * HP, HP)
         y = torch.empty(B * T, 2 * HP, device=dev, dtype=torch.float32)
@@ -203,6 +235,7 @@ class MergedBiLSTMFn(torch.autograd.Function):
                                   stream()), "lstm_fwd")
         ctx.dims = (B, T, H, P)
         ctx.has_lens = lens is not None
+        ctx.n_x2 = len(x2s)
         ctx.save_for_backward(G, c, y, W_hh, lens if lens is not None else torch.empty(0, device=dev), *x2s, *W_ihs)
         y4 = y.view(B, T, 2, P, H)
         return tuple(y4[:, :, :, p, :].reshape(B, T, 2 * H) for p in range(P))
@@ -218,7 +251,7 @@ class MergedBiLSTMFn(torch.autograd.Function):
                                "gradients in place)")
         ctx._consumed = True
         G, c, y, W_hh, lens = ctx.saved_tensors[:5]
-        x2s, W_ihs = ctx.saved_tensors[5: 5 + P], ctx.saved_tensors[5 + P: 5 + 2 * P]
+        x2s, W_ihs = ctx.saved_tensors[5: 5 + ctx.n_x2], ctx.saved_tensors[5 + ctx.n_x2:]
         lens = lens if ctx.has_lens else None
         dev = G.device
         dy = torch.zeros(B, T, 2, P, H, device=dev, dtype=torch.float32)
@@ -231,9 +264,48 @@ class MergedBiLSTMFn(torch.autograd.Function):
         wtpack, Pbuf, dcbuf = _scratch(B, HP, 2, dy2), _scratch(B, HP, 3, dy2), _scratch(B, HP, 4, dy2)
         check(lib.radmmm_lstm_bwd(ptr(G), ptr(c), ptr(dy2), ptr(W_hh), ptr(lens), ptr(wtpack), ptr(Pbuf), ptr(dcbuf), B, T, HP,
                                   ptr(gscale), stream()), "lstm_bwd")
+        grads = [None] * (3 + P + 8 * P)
+        if ctx.split:
+            # the merged tensors as they are: dG' [B*T, 8 HP] is the row-major operand of all four gradient GEMMs (BiLSTMFn.backward)
+            from . import ops
+            box = ctx.box
+            (xh, xl), Wb = x2s, W_ihs[0]
+            I = Wb.shape[1] // P
+            Kc = P * I
+            SG = ops.grad_scale(box, dy2)
+            flag = ops.sat_flag_bwd_of(box)
+            gh, gl = ops.split_f16(G, 8 * HP, SG, 8 * HP, 3, 0, flag)
+            db = ops.colsum(G, 8 * HP).view(2, 4, P, H)
+            dWb = ops.wgrad_rm_slabs((gh, gl), (xh, xl), B, T, 8 * HP, Kc, 1, 1, 1.0 / SG).sum(0)[0].view(2, 4, P, H, P, I)
+            y4 = y.view(B, T, 2, HP)
+            hp = torch.zeros(2, B, T, HP, device=dev, dtype=torch.float32)
+            hp[0, :, 1:] = y4[:, :-1, 0]                                             # forward direction: h_{t-1}
+            hp[1, :, :-1] = y4[:, 1:, 1]                                             # reverse direction: h_{t+1}
+            dWhh = []
+            for d in range(2):
+                hpair = ops.split_f16(hp[d].view(B * T, HP), HP, 1.0, HP)
+                dWhh.append(ops.wgrad_rm_slabs((gh[:, 4 * HP * d: 4 * HP * (d + 1)], gl[:, 4 * HP * d: 4 * HP * (d + 1)]), hpair, B, T,
+                                               4 * HP, HP, 1, 1, 1.0 / SG).sum(0)[0].view(4, P, H, P, H))
+            dx = None
+            if any(ctx.needs_input_grad[3 + p] for p in range(P)):
+                Wt = Wb.t().contiguous()                                             # [P I, 8 HP]: the K-contiguous operand of dx = dG' Wb
+                Wth, Wtl = ops.split_f16(Wt, 8 * HP, ops.W_SCALE, 8 * HP)
+                dx = torch.empty(B * T, Kc, device=dev, dtype=torch.float32)
+                rowgemm_h3(nprod=3, Ah=gh, Al=gl, lda_h=8 * HP, Bh=Wth, Bl=Wtl, ldb_h=8 * HP, acc_scale=1.0 / (SG * ops.W_SCALE),
+                           C=dx, ldc=Kc, M=B * T, N=Kc, K=8 * HP, T=T)
+            for p in range(P):
+                if dx is not None and ctx.needs_input_grad[3 + p]:
+                    grads[3 + p] = dx[:, p * I: (p + 1) * I].reshape(B, T, I)
+                dbp = db[:, :, p, :]
+                base = 3 + P + 8 * p
+                grads[base: base + 8] = [dWb[0, :, p, :, p, :].reshape(4 * H, I), dWhh[0][:, p, :, p, :].reshape(4 * H, H),
+                                         dbp[0].reshape(4 * H), dbp[0].reshape(4 * H),
+                                         dWb[1, :, p, :, p, :].reshape(4 * H, I), dWhh[1][:, p, :, p, :].reshape(4 * H, H),
+                                         dbp[1].reshape(4 * H), dbp[1].reshape(4 * H)]
+            ops.check_saturation(box)
+            return tuple(grads)
         dG5 = G.view(B * T, 2, 4, P, H)                                              # now the pre-activation gradients
         y5 = y.view(B, T, 2, P, H)
-        grads = [None] * (2 + P + 8 * P)
         for p in range(P):
             dG = dG5[:, :, :, p, :].reshape(B * T, 8 * H)
             yp = y5[:, :, :, p, :]                                                   # [B, T, 2, H]
@@ -245,9 +317,9 @@ class MergedBiLSTMFn(torch.autograd.Function):
             db = dG.sum(0)
             dW_hh_f = dG[:, : 4 * H].t() @ hp[:, 0]
             dW_hh_r = dG[:, 4 * H:].t() @ hp[:, 1]
-            if ctx.needs_input_grad[2 + p]:
-                grads[2 + p] = (dG @ W_ihs[p]).view(B, T, -1)
-            base = 2 + P + 8 * p
+            if ctx.needs_input_grad[3 + p]:
+                grads[3 + p] = (dG @ W_ihs[p]).view(B, T, -1)
+            base = 3 + P + 8 * p
             grads[base: base + 8] = [dW_ih[: 4 * H], dW_hh_f, db[: 4 * H], db[: 4 * H], dW_ih[4 * H:], dW_hh_r, db[4 * H:], db[4 * H:]]
         return tuple(grads)
 
@@ -260,7 +332,16 @@ def merged_bilstm(lstms, xs, lens32):
         assert l.num_layers == 1 and l.bidirectional and l.batch_first and l.proj_size == 0
         ws += [l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0, l.weight_ih_l0_reverse, l.weight_hh_l0_reverse,
                l.bias_ih_l0_reverse, l.bias_hh_l0_reverse]
-    return MergedBiLSTMFn.apply(lens32, len(lstms), *[x.contiguous() for x in xs], *ws)
+    box = None
+    if xs[0].is_cuda and torch.is_grad_enabled():
+        # scale state of the merged recurrence's split gradient tensors (ops.GradScale, as `bilstm` keeps one per LSTM): kept on
+        # the first module of the group, carried from pass to pass
+        from . import ops
+        box = lstms[0].__dict__.get("_radmmm_merged_grad_scale")
+        if box is None:
+            box = lstms[0].__dict__["_radmmm_merged_grad_scale"] = ops.GradScale()
+        box.new_forward(xs[0].device)
+    return MergedBiLSTMFn.apply(lens32, len(lstms), box, *[x.contiguous() for x in xs], *ws)
 
 
 def can_merge(lstms, xs) -> bool:
