@@ -148,3 +148,38 @@ def test_colsum_rows_follows_the_launchers_kernel_choice(monkeypatch):
         ref = y.double().sum(0)
         err = float((part.double().sum(0) - ref).abs().max() / ref.abs().max())
         assert err < 1e-5, (B, T, K, N, nprod, err)
+
+
+@pytest.mark.gpu
+def test_res_skip_launches_on_a_side_stream_give_the_same_bits(monkeypatch):
+    """RADMMM_RES_STREAM=1 (the A/B switch of DESIGN 4.15: res_skip[j] on a side stream beside in_layer[j+1]) launches the same
+    kernels on the same operands: outputs and every gradient bit-identical to the one-stream step, two passes in a row (the
+    second one re-uses the cached side stream and freshly recycled activation buffers)."""
+    import radmmm_synth as S
+    from rad_mmm_amd.common import SequenceLength
+    from rad_mmm_amd.decoders import RADMMMFlow
+    from rad_mmm_amd.loss import RADMMMLoss
+    kw = dict(KW, n_flows=2)
+    cfg = S.DecoderConfig(**kw)
+    sd = _T(S.procedural_decoder_state(S.decoder_state_shapes(cfg)))
+    b = {k: v.to(DEV) for k, v in _T(S.synthetic_batch(12, 800, cfg, 21, ragged=True)).items()}
+    sl = SequenceLength(b["lengths"])
+    crit = RADMMMLoss(n_group_size=2)
+    monkeypatch.setenv("RADMMM_DEBUG", "1")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RADMMM_RES_STREAM", mode)
+        dec = RADMMMFlow(use_accent=True, **kw)
+        dec.load_state_dict(sd)
+        dec = dec.to(DEV).train()
+        assert dec.gemm_precision == "f8x"
+        for _ in range(2):
+            dec.zero_grad(set_to_none=True)
+            out = dec(b["mel"], b["spk"], b["context"], sl, b["f0"], b["energy"], b["accent"])
+            crit(out, None, sl, 0)["loss_mel"][0].backward()
+        torch.cuda.synchronize()
+        res[mode] = (out["z_mel"].detach().clone(), {n: p.grad.detach().clone() for n, p in dec.named_parameters() if p.grad is not None})
+    assert torch.equal(_bits(res["0"][0]), _bits(res["1"][0]))
+    assert res["0"][1].keys() == res["1"][1].keys() and len(res["0"][1]) > 60
+    for n in res["0"][1]:
+        assert torch.equal(_bits(res["0"][1][n]), _bits(res["1"][1][n])), n
