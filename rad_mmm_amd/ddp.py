@@ -196,6 +196,7 @@ class BucketedGradReducer:
             b = self._by_param[id(p)]
             b["pending"] -= 1
             if b["pending"] == 0:
+                self._flush(b)                # (sink-less gradients of the same bucket that arrived earlier)
                 b["ready"] = True
         self._launch_ready()
 
