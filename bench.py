@@ -1086,9 +1086,9 @@ def main():
         # what the process-group path costs a step at world size 1 (an A/B of two processes on one box cannot
         # be taken from inside one run: quoted from the committed measurement, with what it was made of)
         res["process_group_overhead_ms"] = {
-            "value": 0.7, "static": True, "source": "profiles/r06_pg_overhead.txt",
+            "value": 0.5, "static": True, "source": "profiles/r06_pg_overhead.txt",
             "what": "RADMMM_BENCH_SPAWN=1 (RCCL at world size 1, bucketed all-reduce inside the step) minus the default run, same box, "
-                    "alternating: 40.81 / 41.00 against 40.15 / 40.24 ms; was +1.8 ms (41.84 / 41.69 against 39.97 / 39.93) until the "
+                    "alternating: 41.66 / 41.67 against 41.14 / 41.22 ms; was +1.8 ms (41.84 / 41.69 against 39.97 / 39.93) until the "
                     "one-rank ReduceOp.AVG -- RCCL's oneRankReduce<FuncPreMulSum>: 17 launches rewriting 876 MB beside the GEMMs, "
                     "1.31 ms of kernel time per step -- became an in-place SUM at world size 1 (rad_mmm_amd/ddp.py)"}
         if hip_out is not None:
