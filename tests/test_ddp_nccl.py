@@ -57,6 +57,10 @@ def test_bench_control_flow_at_world_size_two_on_one_gpu():
     assert d["backend"] == "gloo" and d["rccl_world_size"] == 2 and d["rccl_allreduce_of_ones"] == 2.0
     assert len(d["allreduce_alone_per_bucket"]) == d["gradient_buckets"] and res["saturation"]["nonfinite_passes"] == 0
     assert res["roofline"]["avg_launch_ms"] > 0
+    # the loss terms of the last timed step, mean-reduced over the ranks in one collective per step -- rank 0's own
+    # NLL (its own utterances) differs from the mean over both ranks
+    assert res["loss_mel_global"] is not None and set(res["loss_terms_global"]) >= {"loss_mel", "loss_prior_mel"}
+    assert abs(res["loss_mel_global"] - res["loss_mel"]) > 1e-6 * abs(res["loss_mel"])
 
 
 def _world2(*extra, port):

@@ -1,10 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_ddp_nccl.py -m gpu -q -k "control_flow" 2>&1 | tail -3
 for i in 1 2; do
-timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-110 | sed 's/^/default /' | tee -a gpurun_out/r06_pg_ab2.txt
-RADMMM_BENCH_SPAWN=1 timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | grep step_only | cut -c1-110 | sed 's/^/pg      /' | tee -a gpurun_out/r06_pg_ab2.txt
+timeout 900 python bench.py --config radmmm_splines --frames 2000 --no-throughput-mode --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c5', d['ms_per_step'], d['value'])"
 done
-timeout 900 bash tools/pmc_dominant.sh gpurun_out/pmc_r06 r06 2>&1 | tail -2 | cut -c1-400
-timeout 600 bash tools/prof_step.sh r06 > /dev/null 2>&1
-head -8 gpurun_out/r06_kernel_stats.txt | cut -c1-130
+timeout 300 python bench.py --step-only --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-120
