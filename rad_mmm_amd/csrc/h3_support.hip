@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_h3_multi_kernel(const WnMu
 // hi/lo [rows][ldh] split of scale * x (zero padded to ldh), any split format
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int ld, void* __restrict__ hi,
                                                         void* __restrict__ lo, int ldh, int rows, int cols, float scale,
-                                                        int fmt, float x8_mul, int* __restrict__ sat_flag) {
+                                                        int fmt, float x8_mul, int* __restrict__ sat_flag,
+                                                        void* __restrict__ lo16) {
   const int c4n = ldh / 4;
   const long long total = (long long)rows * c4n;
   float sat = 0.f;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? x[(long long)r * ld + c + e] : 0.f;
-    sat = fmaxf(sat, radmmm::store_split4_fmt(hi, lo, (long long)r * ldh, c, fmt, x8_mul, scale, v[0], v[1], v[2], v[3]));
+    // (lo16: with an 8-bit format the fp16 lo part as well, radmmm_split_opts.lo16 -- round 6: one pass gives a conv's input
+    //  both as the three-product GEMM's (hi, lo) pair and as the FP8-cross weight gradient's (hi, cross array) pair)
+    sat = fmaxf(sat, radmmm::store_split4_fmt(hi, lo, (long long)r * ldh, c, fmt, x8_mul, scale, v[0], v[1], v[2], v[3], lo16));
   }
   radmmm::raise_sat_flag(sat_flag, sat, fmt ? x8_mul : 0.f);
 }
@@ -353,7 +356,8 @@ extern "C" int radmmm_split_f16(const float* x, int ld, void* hi, void* lo, int 
   const long long total = (long long)rows * (ldh / 4);
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(split_f16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, hi, lo, ldh, rows,
-                     cols, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr);
+                     cols, scale, fmt, ldexpf(1.f, so ? so->x8_exp : 0), so ? so->sat_flag : nullptr,
+                     (so && fmt != RADMMM_SPLIT_F16) ? so->lo16 : nullptr);
   return radmmm::check_launch("split_f16");
 }
 

@@ -556,7 +556,8 @@ class ConvNormFn(torch.autograd.Function):
         return None, gx, g_v, g_g, g_bias, None
 
 
-def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none", scale_box=None, nprod=None):
+def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, act="none", scale_box=None, nprod=None,
+              wgrad8=False):
     """scale_box: dict shared by the convs of one backward pass (gradient scale of the split-f16 path,
     fixed by the first node that runs; without it every conv's backward syncs once for its own)."""
     meta = dict(B=B, T=T, dil=dil, partial=bool(partial), mask_out=bool(mask_out), act=ACT[act],
@@ -573,6 +574,12 @@ def conv_norm(x, v, g, bias, lens, B, T, dil=1, partial=False, mask_out=False, a
     meta["nprod"] = 3 if prec == "f8x" else NPROD.get(prec, 3)
     if nprod == 2 and prec == "f8x" and x.shape[0] >= int(debug_env("RADMMM_F8X_MIN_ROWS", "4096")) and v.shape[0] % 32 == 0:
         meta["nprod"] = 2          # a caller that has established the FP8-cross scheme's accuracy for this conv (FiLM blocks)
+    # Round 6: a conv that keeps three products for its outputs and data gradients (the FiLM blocks: the spline's log-Jacobian
+    # amplifies errors of its parameters in backward as well) can still take the FP8-cross kernel for its WEIGHT
+    # gradient -- a leaf: its rounding (~1e-4 of the tensor, the WN convs' own weight-gradient accuracy) goes nowhere else --
+    # on the slot-pinned radmmm_wgrad_rm8 instead of the three-product radmmm_wgrad_rm (configs[4]: 6.8 ms per step)
+    meta["wgrad8"] = bool(wgrad8 and prec == "f8x" and meta["nprod"] == 3 and x.shape[0] >= int(debug_env("RADMMM_F8X_MIN_ROWS", "4096"))
+                          and debug_env("RADMMM_FILM_WGRAD8", "1") != "0")
     h3_ok = (prec in NPROD and (taps // 2) * dil <= 16 and x.shape[0] >= min_rows and
              x.shape[0] * max(round_up(Cin, 32), Cout) < 2 ** 30)
     if h3_ok and Cin % 32 != 0 and x.is_cuda and debug_env("RADMMM_CONVNORM_PAD", "1") != "0":
@@ -781,12 +788,13 @@ def transpose_split(Wh, Wl, rows, cols, ld_dst, nprod=3, out=None):
     return Th, Tl
 
 
-def split_f16(x, cols, scale, ldh=None, nprod=3, x8_exp=0, sat_flag=None):
+def split_f16(x, cols, scale, ldh=None, nprod=3, x8_exp=0, sat_flag=None, lo16=None):
+    """lo16 (nprod 2 only): an fp16 [rows, ldh] tensor that receives the fp16 lo part beside the 8-bit cross array"""
     rows = x.shape[0]
     ldh = ldh or round_up(cols, 32 if nprod == 2 else 8)
     hi, lo = _halves(rows, ldh, like=x)
     check(lib.radmmm_split_f16(ptr(x), x.shape[1], ptr(hi), ptr(lo), ldh, rows, cols, scale,
-                               split_opts(fmt_a(nprod), x8_exp, sat_flag), stream()), "split_f16")
+                               split_opts(fmt_a(nprod), x8_exp, sat_flag, lo16), stream()), "split_f16")
     return hi, lo
 
 
@@ -1776,9 +1784,17 @@ class ConvNormH3Fn(torch.autograd.Function):
         # 1056 = 33 x 32) gets one zero K step more, so that it qualifies for the one-tap kernel, which walks K in pairs of
         # steps (split_f16 / split_weight zero-fill the pad columns; +3 % work for the faster loop)
         Kx = round_up(Cin, 64) if (taps == 1 and Cin % 64) else Cin
-        xh, xl = split_f16(x, Cin, 1.0, Kx, NPR, X8_ACT_EXP, flag)
-        Wh, Wl, inv = split_weight(v, g, Kx, nprod=NPR)
         ldy = round_up(Cout, 4)
+        # weight gradient on the FP8-cross kernel (conv_norm's wgrad8): ONE split pass writes the input as hi + 8-bit cross array
+        # (the weight gradient's pair) AND the fp16 lo part (the three-product GEMM's second operand)
+        wg8 = bool(meta.get("wgrad8") and NPR == 3 and T >= 32 and B <= 1024 and Kx % 32 == 0 and Cout % 4 == 0 and ldy % 4 == 0 and
+                   debug_env("RADMMM_WGRAD_RM", "1") != "0" and debug_env("RADMMM_DACT_ROWS", "1") != "0")
+        if wg8:
+            xl = torch.empty(N, Kx, device=x.device, dtype=torch.float16)
+            xh, xx = split_f16(x, Cin, 1.0, Kx, 2, X8_ACT_EXP, flag, lo16=xl)
+        else:
+            xh, xl = split_f16(x, Cin, 1.0, Kx, NPR, X8_ACT_EXP, flag)
+        Wh, Wl, inv = split_weight(v, g, Kx, nprod=NPR)
         y = torch.zeros(N, ldy, device=x.device, dtype=torch.float32) if ldy != Cout else _empty(N, ldy, like=x)
         rowgemm_h3(nprod=NPR, a8_exp=X8_ACT_EXP, b8_exp=X8_W_EXP, Ah=xh, Al=xl, lda_h=Kx, Bh=Wh, Bl=Wl, ldb_h=Kx,
                    b_tap_stride_h=Wh.stride(0), acc_scale=1.0 / W_SCALE,
@@ -1788,10 +1804,11 @@ class ConvNormH3Fn(torch.autograd.Function):
         ctx.meta = meta
         ctx.has_g, ctx.has_bias, ctx.has_lens = g is not None, bias is not None, lens is not None
         # the row-major split pair of x is the weight gradient's operand (radmmm_wgrad_rm) when it is an fp16 pair
-        ctx.has_xpair = bool(NPR in (2, 3) and T >= 32 and B <= 1024 and Cin % (32 if NPR == 2 else 8) == 0 and
-                             debug_env("RADMMM_WGRAD_RM", "1") != "0")
+        ctx.has_xpair = bool(wg8 or (NPR in (2, 3) and T >= 32 and B <= 1024 and Cin % (32 if NPR == 2 else 8) == 0 and
+                                     debug_env("RADMMM_WGRAD_RM", "1") != "0"))
+        ctx.wg8 = wg8
         ctx.save_for_backward(x, v, g if g is not None else v, lens if lens is not None else v, Wh, Wl,
-                              inv if inv is not None else v, y, *((xh, xl) if ctx.has_xpair else ()))
+                              inv if inv is not None else v, y, *(((xh, xx) if wg8 else (xh, xl)) if ctx.has_xpair else ()))
         return y
 
     @staticmethod
@@ -1821,12 +1838,22 @@ class ConvNormH3Fn(torch.autograd.Function):
         # element over two passes; 32 000-row FiLM convs: dact_mul 77 + colsum 27 us -> one launch)
         fused_rows = (xpair is not None and Cout % 4 == 0 and ldy % 4 == 0 and N == B * T and
                       debug_env("RADMMM_DACT_ROWS", "1") != "0")
+        wg8 = bool(getattr(ctx, "wg8", False) and fused_rows)
+        gpx = None
         if fused_rows:
             gpre = None
             nparts = B * (-(-T // 64))
             part = _empty(nparts, Cout, like=y)
+            if wg8:
+                # (hi, 8-bit cross array) for the weight gradient + the fp16 lo part for the three-product data gradient, one pass
+                gpx = gpl
+                gpl = torch.zeros(N, Kp, device=y.device, dtype=torch.float16) if Kp != Cout else torch.empty(N, Kp, device=y.device,
+                                                                                                           dtype=torch.float16)
+                so = split_opts(SPLIT_X8A, GE, flag, gpl)
+            else:
+                so = split_opts(fmt_a(NPR), GE, flag)
             check(lib.radmmm_dact_mul_rows(ptr(gy), ldy, ptr(y), ldy, Cout, B, T, act, rowscale, ptr(lens), taps, dil, SG,
-                                           ptr(gph), ptr(gpl), Kp, split_opts(fmt_a(NPR), GE, flag), ptr(part), stream()),
+                                           ptr(gph), ptr(gpx if wg8 else gpl), Kp, so, ptr(part), stream()),
                   "dact_mul_rows")
             g_bias = _empty(Cout, like=y)
             check(lib.radmmm_colsum_final(ptr(part), ptr(g_bias), nparts, Cout, stream()), "colsum_final")
@@ -1838,8 +1865,8 @@ class ConvNormH3Fn(torch.autograd.Function):
         if xpair is not None:
             if not fused_rows:
                 g_bias = colsum(gpre, Cout, 2 if partial else 0, T, lens, taps, dil)
-            if NPR == 2:           # (hi, 8-bit cross array) pairs: the FP8-cross weight gradient (radmmm_wgrad_rm8)
-                slabs = wgrad_rm8_slabs((gph, gpl), GE, xpair, X8_ACT_EXP, B, T, Cout, Cin, taps, dil, 1.0 / SG,
+            if NPR == 2 or wg8:    # (hi, 8-bit cross array) pairs: the FP8-cross weight gradient (radmmm_wgrad_rm8)
+                slabs = wgrad_rm8_slabs((gph, gpx if wg8 else gpl), GE, xpair, X8_ACT_EXP, B, T, Cout, Cin, taps, dil, 1.0 / SG,
                                         lens if partial else None)
             else:
                 slabs = wgrad_rm_slabs((gph, gpl), xpair, B, T, Cout, Cin, taps, dil, 1.0 / SG, lens if partial else None)

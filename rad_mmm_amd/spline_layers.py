@@ -121,7 +121,7 @@ class FiLMResBlock(nn.Module):
         pp = self.use_partial_padding
         cn = lambda m, t, act: ops.conv_norm(t, m.conv.weight_v, m.conv.weight_g, m.conv.bias, lens32, B, T,
                                              dil=m.dilation, partial=pp, mask_out=True, act=act, scale_box=scale_box,
-                                             nprod=FILM_BLOCK_NPROD)
+                                             nprod=FILM_BLOCK_NPROD, wgrad8=True)
         x1r = cn(self.input_conv, x, "leaky_relu")            # act(x1) is all that is used downstream
         c1 = cn(self.cond_conv, cond, "none")
         h2 = cn(self.hidden_conv, x1r, "none")

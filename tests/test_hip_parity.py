@@ -474,9 +474,19 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
         mine = float(p.grad.norm())
         assert abs(mine - gn) < 5e-4 * gn + 2e-7, (n, mine, gn)
         worst = max(worst, abs(mine - gn) / (gn + 1e-6))
+    n_zero = 0
     for n, gr in sub(g, "gradp.").items():
         p = dict(dec.named_parameters())[n]
         d = np.abs(p.grad.cpu().numpy() - gr)
+        if n.endswith(("hidden_conv.conv.weight_g", "hidden_conv.conv.bias")) and "gradnorm." + n[: n.rindex(".")] + ".weight_v" in g:
+            # the scale and the bias of the conv that feeds a masked batch-norm have an analytically ZERO gradient (the
+            # normalisation removes both): the fixture holds the reference's rounding residue (1e-7), this side its own --
+            # not comparable in relative terms; held to 1e-4 of the same conv's weight_v gradient instead (round 6: the FiLM
+            # convs' weight gradients moved to the FP8-cross kernel, whose residue is not the three-product kernel's)
+            wv = float(g["gradnorm." + n[: n.rindex(".")] + ".weight_v"])
+            assert np.linalg.norm(gr) < 1e-4 * wv and np.linalg.norm(p.grad.cpu().numpy()) < 1e-4 * wv, (n, wv)
+            n_zero += 1
+            continue
         e = d.max()
         assert e < etol * np.abs(gr).max() + 1e-8, n
         assert np.linalg.norm(d) < 5e-4 * np.linalg.norm(gr) + 1e-8, (n, np.linalg.norm(d) / np.linalg.norm(gr))
@@ -492,7 +502,8 @@ def test_decoder_golden(R, golden, tag, precision, monkeypatch):
     print(f"{tag}/{precision}: z rel err {rel_err(zm, g['z_mel']):.2e}, loss rel err "
           f"{abs(float(lm) - float(g['loss_mel'])) / abs(float(g['loss_mel'])):.2e}, grad.mel rel {rel_err(mel.grad.cpu(), g['grad.mel']):.2e}, "
           f"worst grad-norm rel err {worst:.2e}, worst elementwise grad rel err {worst_el:.2e}, "
-          f"{n_over} of {n_all} full-tensor gradient elements beyond 5e-4 of their tensor's maximum")
+          f"{n_over} of {n_all} full-tensor gradient elements beyond 5e-4 of their tensor's maximum"
+          + (f"; {n_zero} analytically-zero gradients (conv scale / bias in front of a batch-norm) held to 1e-4 of their conv's" if n_zero else ""))
 
 
 def test_context_lstm_two_streams_matches_packed_path(R):
