@@ -26,6 +26,11 @@ class _ConvHolder(nn.Module):
         self.conv = _WNConv(cin, cout, k, w_init_gain=gain)
 
 
+# weight gradients of the predictors' convs on the FP8-cross kernel (ops.conv_norm's wgrad8: a leaf -- outputs and data gradients keep
+# three products).  Round 6 A/B: joint step 63.67 / 63.57 -> 63.17 / 63.25 ms; every parameter gradient stays inside the 5e-4
+# elementwise bars of tests/test_attribute_predictors.py (B = 32, T = 400) and within 4e-6 (L2) of the oracle's autograd in the joint
+# step (tests/test_joint_step.py).  RADMMM_DAP_WGRAD8=0: the three-product radmmm_wgrad_rm.
+DAP_WGRAD8 = os.environ.get("RADMMM_DAP_WGRAD8", "1") != "0"
 PAD = 32        # channel padding of the conv inputs: Cin % 32 == 0 puts a conv on the split-f16 GEMM kernels (ops.conv_norm); the shipped
                 # predictors have in_dim 520 and a 56-channel conv-stack input, which ran on the fp32-MFMA kernels at ~170 us a launch
 
@@ -62,7 +67,7 @@ class BottleneckLayer(nn.Module):
         c = self.projection_fn.conv
         # ConvNorm without partial padding: conv of the padded batch as it is, then * mask (common.py:179-191)
         return ops.conv_norm(x_rows, _pad_in(c.weight_v, x_rows.shape[1]), c.weight_g, c.bias, lens32, B, T, dil=1, partial=False,
-                             mask_out=True, act="leaky_relu" if self.leaky else "relu", scale_box=scale_box)
+                             mask_out=True, act="leaky_relu" if self.leaky else "relu", scale_box=scale_box, wgrad8=DAP_WGRAD8)
 
 
 class ConvLSTMLinear(nn.Module):
@@ -96,7 +101,7 @@ class ConvLSTMLinear(nn.Module):
             c = holder.conv
             v = _pad_in(c.weight_v, h.shape[1]) if h.shape[1] % PAD == 0 else c.weight_v
             h = ops.conv_norm(h, v, c.weight_g, c.bias, lens32, B, T, dil=1, partial=False, mask_out=True,
-                              act="relu", scale_box=scale_box)
+                              act="relu", scale_box=scale_box, wgrad8=DAP_WGRAD8)
             h = F.dropout(h, self.p_dropout, self.training)
         for hook in self.bilstm._forward_pre_hooks.values():        # materialise the spectral-normed weight_hh_l0*
             hook(self.bilstm, ())
