@@ -28,7 +28,7 @@ class _ConvHolder(nn.Module):
 
 # weight gradients of the predictors' convs on the FP8-cross kernel (ops.conv_norm's wgrad8: a leaf -- outputs and data gradients keep
 # three products).  Round 6 A/B: joint step 63.67 / 63.57 -> 63.17 / 63.25 ms; every parameter gradient stays inside the 5e-4
-# elementwise bars of tests/test_attribute_predictors.py (B = 32, T = 400) and within 4e-6 (L2) of the oracle's autograd in the joint
+# elementwise bars of tests/test_attribute_predictors.py (B = 32, T = 400) and within 4e-6 (L2) of the CPU restatement's autograd in the joint
 # step (tests/test_joint_step.py).  RADMMM_DAP_WGRAD8=0: the three-product radmmm_wgrad_rm.
 DAP_WGRAD8 = os.environ.get("RADMMM_DAP_WGRAD8", "1") != "0"
 PAD = 32        # channel padding of the conv inputs: Cin % 32 == 0 puts a conv on the split-f16 GEMM kernels (ops.conv_norm); the shipped
